@@ -1,0 +1,556 @@
+"""CPU ORACLE for the Grounded-VideoLLM inference hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain torch-on-CPU (fp32) restatement of the reference algorithm.  It is the
+*checker* for the HIP path: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  The product path
+(``grounded-video-llm_amd/``) never imports, calls or falls back to anything in here.
+
+Parity status: PINNED against outputs of the reference's own modules run in this container
+(``oracle/make_golden.py`` imports /root/reference through ``oracle/ref_shims.py`` and writes
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` replays them).  Third-party
+arithmetic that is not under /root/reference (transformers GenerationMixin greedy loop,
+DynamicCache, peft LoRA, flash-attn) is restated from its published semantics: "parity
+unpinned" for the LoRA merge (peft 0.3.0 is absent here) and for the HF generate() loop
+beyond what the full-sequence forward pins.
+
+Every function cites the reference file:line it follows (paths relative to /root/reference).
+
+Numerics: ``emu=False`` is exact fp32 (what the reference computes on a CPU host, SURVEY
+App. A last paragraph).  ``emu=True`` inserts bf16 roundings at the points where the
+reference *GPU* path (autocast bf16 / bf16 weights) rounds, following SURVEY Appendix A; the
+HIP path is compared against both.
+"""
+from __future__ import annotations
+
+import math
+import re
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+IMAGE_TOKEN_INDEX = -200          # datasets/chat/base_template.py:14
+IGNORE_INDEX = -100               # datasets/chat/base_template.py:13
+DEFAULT_IMAGE_TOKEN = "<image>"   # datasets/chat/base_template.py:15
+GROUNDING_TOKEN = "<timestamp_grounding>"  # datasets/chat/base_template.py:16
+
+OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)   # mm_utils/utils.py:147
+OPENAI_DATASET_STD = (0.26862954, 0.26130258, 0.27577711)   # mm_utils/utils.py:148
+INTERNVIDEO_MEAN = (0.485, 0.456, 0.406)                    # mm_utils/utils.py:150
+INTERNVIDEO_STD = (0.229, 0.224, 0.225)                     # mm_utils/utils.py:151
+
+
+# --------------------------------------------------------------------------------------
+# rounding helper
+# --------------------------------------------------------------------------------------
+def _r(x: torch.Tensor, emu: bool) -> torch.Tensor:
+    """Round to bf16 and come back to fp32 when emulating the reference GPU numerics."""
+    return x.to(torch.bfloat16).to(torch.float32) if emu else x
+
+
+def _lin(x, w, b, emu):
+    """nn.Linear under autocast: operands cast to bf16, fp32 accumulate, bf16 result."""
+    y = F.linear(_r(x, emu), _r(w, emu), None if b is None else _r(b, emu))
+    return _r(y, emu)
+
+
+# --------------------------------------------------------------------------------------
+# a1 / a14 -- integer paths
+# --------------------------------------------------------------------------------------
+def get_frame_indices(num_frames: int, vlen: int, sample: str = "middle") -> List[int]:
+    """mm_utils/video_utils.py:13-38 ('middle' branch: midpoint of each linspace interval)."""
+    if sample != "middle":
+        raise NotImplementedError("only the inference path's 'middle' sampling is on the hot path")
+    acc_samples = min(num_frames, vlen)
+    intervals = np.linspace(start=0, stop=vlen, num=acc_samples + 1).astype(int)
+    ranges = [(int(intervals[i]), int(intervals[i + 1]) - 1) for i in range(len(intervals) - 1)]
+    frame_indices = [(a + b) // 2 for a, b in ranges]
+    if len(frame_indices) < num_frames:  # padded with last frame, :33-36
+        padded = [frame_indices[-1]] * num_frames
+        padded[: len(frame_indices)] = frame_indices
+        frame_indices = padded
+    return frame_indices
+
+
+def spatial_frame_indices(num_frames: int, num_segs: int) -> List[int]:
+    """inference.py:82-83."""
+    per = int(num_frames // num_segs)
+    return [(i * per) + int(per / 2) for i in range(num_segs)]
+
+
+def seconds_to_temporal_tokens(query: str, duration: float, num_temporal_tokens: int = 300) -> str:
+    """inference.py:107 -- '(\\d+) seconds' -> '<k>' with k = int(float(sec)/duration*N)."""
+    return re.sub(r"(\d+) seconds",
+                  lambda m: f"<{int(float(m.group(1)) / duration * num_temporal_tokens)}>", query)
+
+
+def quantize_timestamp(time: float, duration: float, num_temporal_tokens: int = 300) -> int:
+    """datasets/mix_grounded.py:84-85 (training-side order of operations, clipped to N)."""
+    return min(int(num_temporal_tokens * time / duration), num_temporal_tokens)
+
+
+def parse_time_interval(text: str, duration: float, num_temporal_tokens: int = 300, llm: str = "phi3.5") -> str:
+    """inference.py:125-134 -- '<k>' -> seconds string (Phi keeps the leading space)."""
+    def rep(m):
+        x = int(m.group(1))
+        t = duration * x / num_temporal_tokens
+        if llm == "phi3.5":
+            return f" {t:.2f} seconds"
+        elif llm == "llama3":
+            return f"{t:.2f} seconds"
+        return None  # reference returns None for other llm values -> re.sub raises; keep it loud
+    return re.sub(r"<(\d+)>", rep, text)
+
+
+# prompt templates -- datasets/chat/base_template.py:86-134
+_SYSTEM = {
+    "phi3.5": "<|system|>\nYou are a helpful AI assistant that can generate responses based on visual inputs.",
+    "llama3": "<|start_header_id|>system<|end_header_id|>You are a helpful language and vision assistant. You are able to understand the visual content that the user provides, and assist the user with a variety of tasks using natural language.",
+    "vicuna": "You are a helpful language and vision assistant. You are able to understand the visual content that the user provides, and assist the user with a variety of tasks using natural language.",
+}
+_USER = {"phi3.5": "\n<|user|>\n", "llama3": "<|start_header_id|>user<|end_header_id|>", "vicuna": "\nUSER: "}
+_ASSIST = {"phi3.5": ("\n<|assistant|>\n", "<|endoftext|>"),
+           "llama3": ("<|start_header_id|>assistant<|end_header_id|>", "<|eot_id|>"),
+           "vicuna": ("\nASSISTANT: ", "</s>")}
+
+
+def template_encode(llm: str, conv: Sequence[Dict[str, str]]) -> str:
+    """Template.encode -> _prompt, datasets/chat/base_template.py:49-112."""
+    qs, ans = [], []
+    first_is_not_question = 0
+    for i, m in enumerate(conv):
+        if i == 0 and m["from"] != "human":
+            first_is_not_question = 1
+            continue
+        (qs if i % 2 == first_is_not_question else ans).append(m["value"])
+    assert len(qs) == len(ans)
+    msg = ""
+    for i, (q, a) in enumerate(zip(qs, ans)):
+        if i == 0:
+            msg += _SYSTEM[llm]
+        if DEFAULT_IMAGE_TOKEN in q and GROUNDING_TOKEN not in q:
+            q = q.replace(DEFAULT_IMAGE_TOKEN, "").strip()
+            q = (DEFAULT_IMAGE_TOKEN + "\n" + q).strip()
+        msg += _USER[llm] + q
+        msg += _ASSIST[llm][0] + a + _ASSIST[llm][1]
+    return msg
+
+
+def build_prompt(llm: str, mode: str, text: str, duration: float = 0.0, num_temporal_tokens: int = 300) -> str:
+    """inference.py:93-113 -- the three prompt modes; trailing eos removed."""
+    if mode == "grounding":
+        value = DEFAULT_IMAGE_TOKEN + " " + GROUNDING_TOKEN + "\n" + text
+    elif mode == "qa":
+        value = DEFAULT_IMAGE_TOKEN + "\n" + text
+    elif mode == "referring":
+        value = DEFAULT_IMAGE_TOKEN + "\n" + seconds_to_temporal_tokens(text, duration, num_temporal_tokens)
+    else:
+        raise AssertionError(mode)
+    conv = [{"from": "human", "value": value}, {"from": "gpt", "value": ""}]
+    return template_encode(llm, conv).replace(_ASSIST[llm][1], "")
+
+
+def tokenizer_image_token(prompt: str, tokenize: Callable[[str], List[int]], bos_token_id: Optional[int],
+                          image_token_index: int = IMAGE_TOKEN_INDEX) -> List[int]:
+    """models/llava_next_video.py:409-426."""
+    chunks = [tokenize(c) for c in prompt.split(DEFAULT_IMAGE_TOKEN)]
+    ids: List[int] = []
+    offset = 0
+    if len(chunks) > 0 and len(chunks[0]) > 0 and chunks[0][0] == bos_token_id:
+        offset = 1
+        ids.append(chunks[0][0])
+    sep = [image_token_index] * (offset + 1)
+    inter = [e for sub in zip(chunks, [sep] * len(chunks)) for e in sub][:-1]
+    for x in inter:
+        ids.extend(x[offset:])
+    return ids
+
+
+def left_pad_truncate(batch_ids: Sequence[Sequence[int]], pad_id: int, max_txt_len: int):
+    """models/llava_next_video.py:626-647 -- flip / pad_sequence / truncate / flip back."""
+    L = max(len(x) for x in batch_ids)
+    ids = torch.full((len(batch_ids), L), pad_id, dtype=torch.long)
+    mask = torch.zeros((len(batch_ids), L), dtype=torch.long)
+    for i, x in enumerate(batch_ids):
+        ids[i, L - len(x):] = torch.tensor(list(x), dtype=torch.long)
+        mask[i, L - len(x):] = 1
+    if L > max_txt_len:      # keeps the LAST max_txt_len tokens (truncation happens on the flipped tensor)
+        ids, mask = ids[:, L - max_txt_len:], mask[:, L - max_txt_len:]
+    return ids, mask
+
+
+# --------------------------------------------------------------------------------------
+# a2 / a3 -- CLIP ViT-L/14-336 (models/modeling_clip.py)
+# --------------------------------------------------------------------------------------
+def clip_embeddings(px: torch.Tensor, W: Dict[str, torch.Tensor], emu=False, prefix="vision_model.") -> torch.Tensor:
+    """CLIPVisionEmbeddings.forward :182-191 + pre_layrnorm :851.  px [N,3,H,W] -> [N,1+P,C] fp32."""
+    w = W[prefix + "embeddings.patch_embedding.weight"]
+    ps = w.shape[-1]
+    pe = _r(F.conv2d(_r(px, emu), _r(w, emu), None, stride=ps), emu)         # conv is autocast->bf16
+    pe = pe.flatten(2).transpose(1, 2)
+    cls = W[prefix + "embeddings.class_embedding"].expand(px.shape[0], 1, -1)
+    x = torch.cat([cls, pe], dim=1) + W[prefix + "embeddings.position_embedding.weight"][None]
+    C = x.shape[-1]
+    return F.layer_norm(x, (C,), W[prefix + "pre_layrnorm.weight"], W[prefix + "pre_layrnorm.bias"], 1e-5)
+
+
+def clip_layer(x: torch.Tensor, W: Dict[str, torch.Tensor], i: int, num_heads: int, emu=False,
+               prefix="vision_model.", eps=1e-5, round_scores=False) -> torch.Tensor:
+    """CLIPEncoderLayer.forward :355-393, CLIPAttention.forward :252-328, CLIPMLP :339-343."""
+    p = f"{prefix}encoder.layers.{i}."
+    N, S, C = x.shape
+    hd = C // num_heads
+    h = F.layer_norm(x, (C,), W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], eps)
+    q = _lin(h, W[p + "self_attn.q_proj.weight"], W[p + "self_attn.q_proj.bias"], emu) * (hd ** -0.5)
+    k = _lin(h, W[p + "self_attn.k_proj.weight"], W[p + "self_attn.k_proj.bias"], emu)
+    v = _lin(h, W[p + "self_attn.v_proj.weight"], W[p + "self_attn.v_proj.bias"], emu)
+    q = _r(q, emu)
+    sh = lambda t: t.view(N, S, num_heads, hd).transpose(1, 2)
+    q, k, v = sh(q), sh(k), sh(v)
+    s = q @ k.transpose(-1, -2)
+    if round_scores:                 # eager bmm under autocast returns bf16 scores (:274)
+        s = _r(s, emu)
+    pr = torch.softmax(s.float(), dim=-1)
+    o = _r(_r(pr, emu) @ v, emu)                                            # bmm(attn_probs, v) in bf16 :314
+    o = o.transpose(1, 2).reshape(N, S, C)
+    o = _lin(o, W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"], emu)
+    x = x + o
+    h = F.layer_norm(x, (C,), W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], eps)
+    h = _lin(h, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"], emu)
+    h = _r(h * torch.sigmoid(1.702 * h), emu)                               # quick_gelu (transformers ACT2FN)
+    h = _lin(h, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"], emu)
+    return x + h
+
+
+def clip_penultimate(px, W, num_layers: int, num_heads: int, emu=False, prefix="vision_model.") -> torch.Tensor:
+    """vision_tower(...).hidden_states[-2][:, 1:]  (models/llava_next_video.py:504-505).
+
+    hidden_states has num_layers+1 entries (modeling_clip.py:626-651); [-2] is the output of layer
+    num_layers-1, so only num_layers-1 layers are needed."""
+    x = clip_embeddings(px, W, emu, prefix)
+    for i in range(num_layers - 1):
+        x = clip_layer(x, W, i, num_heads, emu, prefix)
+    return x[:, 1:]
+
+
+# --------------------------------------------------------------------------------------
+# a6 / a7 -- InternVideo2 (models/internvideo2.py)
+# --------------------------------------------------------------------------------------
+def interpolate_pos_embed_t(pos: torch.Tensor, orig_t: int, new_t: int, n_extra: int = 1) -> torch.Tensor:
+    """interpolate_pos_embed_internvideo2_new :290-303 (temporal, linear).  pos [1, n_extra+T*HW, C]."""
+    if orig_t == new_t:
+        return pos
+    C = pos.shape[-1]
+    extra, tok = pos[:, :n_extra], pos[:, n_extra:]
+    tok = tok.view(1, orig_t, -1, C).permute(0, 2, 3, 1).reshape(-1, C, orig_t)
+    tok = F.interpolate(tok, size=new_t, mode="linear")
+    tok = tok.view(1, -1, C, new_t).permute(0, 3, 1, 2).reshape(1, -1, C)
+    return torch.cat((extra, tok), dim=1)
+
+
+def _rmsnorm(x, w, eps, emu):
+    """RMSNorm.forward internvideo2.py:443-448 == Phi3RMSNorm modeling_phi3.py:319-324."""
+    xf = x.float()
+    var = xf.pow(2).mean(-1, keepdim=True)
+    xn = xf * torch.rsqrt(var + eps)
+    return _r(_r(w, emu) * _r(xn, emu), emu)
+
+
+def iv2_embed(px: torch.Tensor, W, emu=False) -> torch.Tensor:
+    """PatchEmbed.forward :721-725 + cls/pos :972-1011.  px [B,3,T,H,W] -> [B,1+T*L,C]."""
+    w, b = W["patch_embed.proj.weight"], W["patch_embed.proj.bias"]
+    ps = w.shape[-1]
+    x = F.conv3d(_r(px, emu), _r(w, emu), _r(b, emu), stride=(w.shape[2], ps, ps))
+    x = _r(x, emu).flatten(3).permute(0, 2, 3, 1)          # B T HW C
+    B, T, L, C = x.shape
+    x = x.reshape(B, T * L, C)
+    x = torch.cat((_r(W["cls_token"], emu).expand(B, -1, -1), x), dim=1)
+    return _r(x + _r(W["pos_embed"], emu), emu)
+
+
+def iv2_block(x, W, i: int, num_heads: int, emu=False, eps=1e-6) -> torch.Tensor:
+    """Block._inner_forward :680-684; Attention._naive_attn :564-583 (== _flash_attn :585-605)."""
+    p = f"blocks.{i}."
+    B, S, C = x.shape
+    hd = C // num_heads
+    h = _rmsnorm(x, W[p + "norm1.weight"], eps, emu)
+    qkv = _lin(h, W[p + "attn.qkv.weight"], None, emu)
+    q, k, v = qkv.reshape(B, S, 3, C).unbind(2)
+    q = _rmsnorm(q, W[p + "attn.q_norm.weight"], eps, emu)   # over the FULL width, all heads jointly :572
+    k = _rmsnorm(k, W[p + "attn.k_norm.weight"], eps, emu)
+    sh = lambda t: t.view(B, S, num_heads, hd).transpose(1, 2)
+    q, k, v = sh(q), sh(k), sh(v)
+    s = (q * (hd ** -0.5)) @ k.transpose(-1, -2)
+    o = _r(torch.softmax(s, dim=-1) @ v, emu)
+    o = o.transpose(1, 2).reshape(B, S, C)
+    o = _lin(o, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"], emu)
+    o = _r(o.float() * W[p + "ls1.gamma"].float(), emu)      # LayerScale force_fp32 :458-463
+    x = _r(x + o, emu)
+    h = _rmsnorm(x, W[p + "norm2.weight"], eps, emu)
+    h = _lin(h, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"], emu)
+    h = _r(F.gelu(h), emu)                                   # nn.GELU (erf) :616
+    h = _lin(h, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"], emu)
+    h = _r(h.float() * W[p + "ls2.gamma"].float(), emu)
+    return _r(x + h, emu)
+
+
+def iv2_encode(px, W, depth: int, num_heads: int, emu=False, x_vis_return_idx: int = -2) -> torch.Tensor:
+    """PretrainInternVideo2.forward(x, None, False, x_vis_return_idx=-2, x_vis_only=True)[:, 1:, :]
+    :970-1040 -- runs blocks 0..depth-2 (break at idx == depth + x_vis_return_idx :1028)."""
+    x = iv2_embed(px, W, emu)
+    for i in range(depth):
+        x = iv2_block(x, W, i, num_heads, emu)
+        if i == depth + x_vis_return_idx:
+            break
+    return x[:, 1:, :]
+
+
+# --------------------------------------------------------------------------------------
+# a4 / a5 / a8 / a9 -- glue + projectors (models/llava_next_video.py)
+# --------------------------------------------------------------------------------------
+def hd_merge_2x2_phi3(f: torch.Tensor) -> torch.Tensor:
+    """reshape_hd_patches_2x2merge_phi3(f, 1, 1) :454-476.  [N,576,1024] -> [N,12,12,4096]."""
+    N, L, C = f.shape
+    H = int(L ** 0.5)
+    return (f.reshape(N, H // 2, 2, H // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(N, H // 2, H // 2, 4 * C))
+
+
+def add_image_newline_phi3(fhd: torch.Tensor, sub_GN: torch.Tensor) -> torch.Tensor:
+    """add_image_newline_phi3 :478-489.  [N,h,w,4096] -> [N,h*(w+1),4096]."""
+    N, h, w, D = fhd.shape
+    nl = sub_GN.reshape(1, 1, 1, D).expand(N, h, 1, D)
+    return torch.cat([fhd, nl], dim=2).reshape(N, -1, D)
+
+
+def pool_spatial_llama(f: torch.Tensor, out_hw: int = 8) -> torch.Tensor:
+    """AdaptiveAvgPool3d([S, 8, 8]) on [bs,C,S,24,24] :509-517 == block mean.  [N,576,C] -> [N,64,C]."""
+    N, L, C = f.shape
+    H = int(math.sqrt(L))
+    k = H // out_hw
+    return f.reshape(N, out_hw, k, out_hw, k, C).mean(dim=(2, 4)).reshape(N, out_hw * out_hw, C)
+
+
+def pool_temporal(seg: torch.Tensor, T: int, pool: int = 4, emu=False) -> torch.Tensor:
+    """AdaptiveAvgPool3d([T,4,4]) on [B,1408,T,16,16] :543-549.  [B,T*256,C] -> [B,T*16,C]."""
+    B, TL, C = seg.shape
+    H = int(math.sqrt(TL // T))
+    k = H // pool
+    y = seg.reshape(B, T, pool, k, pool, k, C).mean(dim=(3, 5)).reshape(B, T * pool * pool, C)
+    return _r(y, emu)
+
+
+def mlp_projector(x, w0, b0, w1, b1, emu=False):
+    """Phi3_5_Projecter :50-54 / Video_Projecter :35-39 / LlavaMultiModalProjector: Linear-GELU(erf)-Linear."""
+    h = _r(F.gelu(_lin(x, w0, b0, emu)), emu)
+    return _lin(h, w1, b1, emu)
+
+
+def encode_images(spatial_px, temporal_px, Wclip, Wiv2, Wproj, llm: str, *, clip_layers=24, clip_heads=16,
+                  iv2_depth=40, iv2_heads=16, emu=False) -> torch.Tensor:
+    """LLAVA_NEXT_VIDEO.encode_images :491-566.
+
+    spatial_px [bs,S,3,336,336], temporal_px [bs,F,3,224,224] -> [bs, S*(img+seg+1), D].
+    Wproj keys: 'multi_modal_projector.*', 'video_projecter.*', and 'glb_GN','sub_GN' (phi3.5) or
+    'image_newline' (llama3)."""
+    bs, S = spatial_px.shape[:2]
+    F_ = temporal_px.shape[1]
+    fps = F_ // S
+    img = clip_penultimate(spatial_px.flatten(0, 1), Wclip, clip_layers, clip_heads, emu)   # [bs*S,576,1024]
+    if llm == "phi3.5":
+        img = add_image_newline_phi3(hd_merge_2x2_phi3(img), Wproj["sub_GN"])
+        img = mlp_projector(img, Wproj["multi_modal_projector.linear_0.weight"], Wproj["multi_modal_projector.linear_0.bias"],
+                            Wproj["multi_modal_projector.linear_1.weight"], Wproj["multi_modal_projector.linear_1.bias"], emu)
+    else:
+        img = pool_spatial_llama(img)
+        img = mlp_projector(img, Wproj["multi_modal_projector.linear_1.weight"], Wproj["multi_modal_projector.linear_1.bias"],
+                            Wproj["multi_modal_projector.linear_2.weight"], Wproj["multi_modal_projector.linear_2.bias"], emu)
+    img = img.reshape(bs, S, img.shape[1], img.shape[2])
+    t = temporal_px.reshape(bs, S, fps, *temporal_px.shape[2:]).permute(0, 1, 3, 2, 4, 5).flatten(0, 1)  # (bs S) c f h w
+    seg = iv2_encode(t, Wiv2, iv2_depth, iv2_heads, emu)                                                # [(bs S), f*256, 1408]
+    seg = pool_temporal(seg, fps, 4, emu)
+    seg = mlp_projector(seg, Wproj["video_projecter.up_proj.weight"], Wproj["video_projecter.up_proj.bias"],
+                        Wproj["video_projecter.down_proj.weight"], Wproj["video_projecter.down_proj.bias"], emu)
+    seg = seg.reshape(bs, S, seg.shape[1], seg.shape[2])
+    D = seg.shape[-1]
+    if llm == "phi3.5":
+        nl = Wproj["glb_GN"].reshape(-1)[None, :]
+        nl = mlp_projector(nl, Wproj["multi_modal_projector.linear_0.weight"], Wproj["multi_modal_projector.linear_0.bias"],
+                           Wproj["multi_modal_projector.linear_1.weight"], Wproj["multi_modal_projector.linear_1.bias"], emu)
+    else:
+        nl = _r(Wproj["image_newline"].reshape(1, -1), emu)
+    nl = nl.reshape(1, 1, 1, D).expand(bs, S, 1, D)
+    return torch.cat([img, seg, nl], dim=2).reshape(bs, -1, D)
+
+
+def splice(input_ids: torch.Tensor, visual: torch.Tensor, embed_w: torch.Tensor, emu=False) -> torch.Tensor:
+    """prepare_multimodal_inputs (non-'text' branch) :579-590 for ONE sample: embed(pre) | visual | embed(post)."""
+    idx = int(torch.where(input_ids == IMAGE_TOKEN_INDEX)[0][0])
+    e = _r(embed_w, emu)
+    return torch.cat([e[input_ids[:idx]], _r(visual, emu), e[input_ids[idx + 1:]]], dim=0)
+
+
+# --------------------------------------------------------------------------------------
+# a11 / a12 / a13 -- decoder LLMs (models/modeling_phi3.py, models/modeling_llama.py)
+# --------------------------------------------------------------------------------------
+class LLMConfig:
+    def __init__(self, kind: str, hidden: int, inter: int, layers: int, heads: int, kv_heads: int, vocab: int,
+                 rms_eps: float = 1e-5, rope_theta: float = 10000.0, max_pos: int = 131072, orig_max_pos: int = 4096,
+                 short_factor: Optional[Sequence[float]] = None, long_factor: Optional[Sequence[float]] = None):
+        self.kind, self.hidden, self.inter, self.layers = kind, hidden, inter, layers
+        self.heads, self.kv_heads, self.vocab = heads, kv_heads, vocab
+        self.rms_eps, self.rope_theta, self.max_pos, self.orig_max_pos = rms_eps, rope_theta, max_pos, orig_max_pos
+        self.short_factor, self.long_factor = short_factor, long_factor
+        self.head_dim = hidden // heads
+
+
+def rope_cos_sin(cfg: LLMConfig, positions: torch.Tensor, kv_seq_len: int, emu=False):
+    """Phi3LongRoPEScaledRotaryEmbedding.forward modeling_phi3.py:380-409 (short/long chosen by
+    kv_seq_len > original_max_position_embeddings) / Phi3RotaryEmbedding :347-366 /
+    LlamaRotaryEmbedding modeling_llama.py:119-133.  Returns cos, sin [S, head_dim] (bf16-rounded if emu)."""
+    d = cfg.head_dim
+    ar = torch.arange(0, d, 2, dtype=torch.int64).float() / d
+    if cfg.short_factor is not None:
+        fac = cfg.long_factor if kv_seq_len > cfg.orig_max_pos else cfg.short_factor
+        ext = torch.tensor(list(fac), dtype=torch.float32)
+        inv = 1.0 / (ext * cfg.rope_theta ** ar)
+        scale = cfg.max_pos / cfg.orig_max_pos
+        sf = 1.0 if scale <= 1.0 else math.sqrt(1 + math.log(scale) / math.log(cfg.orig_max_pos))
+    else:
+        inv = 1.0 / (cfg.rope_theta ** ar)
+        sf = 1.0
+    fr = positions.float()[:, None] * inv[None, :]
+    emb = torch.cat((fr, fr), dim=-1)
+    return _r(emb.cos() * sf, emu), _r(emb.sin() * sf, emu)
+
+
+def _rot_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def _apply_rope(t, cos, sin, emu):
+    """apply_rotary_pos_emb modeling_phi3.py:421-445 (each product and the sum round to bf16 under emu)."""
+    return _r(_r(t * cos, emu) + _r(_rot_half(t) * sin, emu), emu)
+
+
+def _qkv(cfg: LLMConfig, W, p, h, emu):
+    H, KV, d = cfg.heads, cfg.kv_heads, cfg.head_dim
+    if cfg.kind == "phi3":
+        qkv = _lin(h, W[p + "self_attn.qkv_proj.weight"], None, emu)     # fused :659-663
+        q, k, v = qkv[..., : H * d], qkv[..., H * d: H * d + KV * d], qkv[..., H * d + KV * d:]
+    else:
+        q = _lin(h, W[p + "self_attn.q_proj.weight"], None, emu)          # modeling_llama.py:432-434
+        k = _lin(h, W[p + "self_attn.k_proj.weight"], None, emu)
+        v = _lin(h, W[p + "self_attn.v_proj.weight"], None, emu)
+    return q, k, v
+
+
+def _mlp(cfg: LLMConfig, W, p, h, emu):
+    if cfg.kind == "phi3":
+        gu = _lin(h, W[p + "mlp.gate_up_proj.weight"], None, emu)         # :459-464, gate = first half
+        g, u = gu.chunk(2, dim=-1)
+        a = _r(u * _r(F.silu(g), emu), emu)
+        return _lin(a, W[p + "mlp.down_proj.weight"], None, emu)
+    g = _lin(h, W[p + "mlp.gate_proj.weight"], None, emu)                 # modeling_llama.py:236
+    u = _lin(h, W[p + "mlp.up_proj.weight"], None, emu)
+    a = _r(_r(F.silu(g), emu) * u, emu)
+    return _lin(a, W[p + "mlp.down_proj.weight"], None, emu)
+
+
+def llm_forward(cfg: LLMConfig, W, x: torch.Tensor, emu=False, cache=None, pos0: int = 0, last_only=False):
+    """Phi3Model.forward :1249-1383 + Phi3ForCausalLM.forward :1512-1526 (or the Llama twins
+    modeling_llama.py:934-1087, :1165-1231) for ONE un-padded sequence.
+
+    x [S, hidden] input embeddings at positions pos0..pos0+S-1.  cache: list (per layer) of
+    [K, V] tensors [KV, S_past, d] which is appended in place (DynamicCache.update semantics),
+    or None for a full forward.  Returns fp32 logits [S, V] (or [1, V] if last_only)."""
+    S = x.shape[0]
+    H, KV, d = cfg.heads, cfg.kv_heads, cfg.head_dim
+    pos = torch.arange(pos0, pos0 + S)
+    cos, sin = rope_cos_sin(cfg, pos, pos0 + S, emu)
+    x = _r(x, emu)
+    for li in range(cfg.layers):
+        p = f"model.layers.{li}."
+        h = _rmsnorm(x, W[p + "input_layernorm.weight"], cfg.rms_eps, emu)
+        q, k, v = _qkv(cfg, W, p, h, emu)
+        q = q.view(S, H, d).transpose(0, 1)
+        k = k.view(S, KV, d).transpose(0, 1)
+        v = v.view(S, KV, d).transpose(0, 1)
+        q, k = _apply_rope(q, cos[None], sin[None], emu), _apply_rope(k, cos[None], sin[None], emu)
+        if cache is not None:
+            if cache[li] is None:
+                cache[li] = [k, v]
+            else:
+                cache[li] = [torch.cat([cache[li][0], k], dim=1), torch.cat([cache[li][1], v], dim=1)]
+            k, v = cache[li]
+        Sk = k.shape[1]
+        kk = k.repeat_interleave(H // KV, dim=0)          # repeat_kv modeling_llama.py:241-250
+        vv = v.repeat_interleave(H // KV, dim=0)
+        s = (q @ kk.transpose(-1, -2)) / math.sqrt(d)
+        qi = torch.arange(Sk - S, Sk)[:, None]
+        ki = torch.arange(Sk)[None, :]
+        s = s.masked_fill((ki > qi)[None], float("-inf"))
+        o = _r(_r(torch.softmax(s.float(), dim=-1), emu) @ vv, emu)
+        o = o.transpose(0, 1).reshape(S, H * d)
+        x = _r(x + _lin(o, W[p + "self_attn.o_proj.weight"], None, emu), emu)
+        h = _rmsnorm(x, W[p + "post_attention_layernorm.weight"], cfg.rms_eps, emu)
+        x = _r(x + _mlp(cfg, W, p, h, emu), emu)
+    if last_only:
+        x = x[-1:]
+    h = _rmsnorm(x, W["model.norm.weight"], cfg.rms_eps, emu)
+    logits = _lin(h, W["lm_head.weight"], W.get("lm_head.bias"), emu)       # bias: SURVEY App. C #3
+    return logits.float()
+
+
+def greedy_generate(cfg: LLMConfig, W, inputs_embeds: torch.Tensor, max_new_tokens: int, eos_token_id: Optional[int],
+                    emu=False, use_cache=True, return_margins=False):
+    """language_model.generate(inputs_embeds=..., do_sample=False, num_beams=1) semantics
+    (models/llava_next_video.py:655-661; transformers GenerationMixin [ext]): only NEW ids are
+    returned, the step that emits eos is included, generation stops after it.
+
+    use_cache=False is the O(n^2) definition (SURVEY §8c 'Greedy-decode oracle'); use_cache=True is
+    the mathematically identical KV-cached loop used for the CPU baseline."""
+    e = _r(W["model.embed_tokens.weight"], emu)
+    out: List[int] = []
+    margins: List[float] = []
+    if use_cache:
+        cache = [None] * cfg.layers
+        logits = llm_forward(cfg, W, inputs_embeds, emu, cache, 0, last_only=True)
+        n = inputs_embeds.shape[0]
+    else:
+        seq = inputs_embeds
+        logits = llm_forward(cfg, W, seq, emu, None, 0, last_only=True)
+    for _ in range(max_new_tokens):
+        top2 = torch.topk(logits[-1], 2)
+        tok = int(top2.indices[0])
+        margins.append(float(top2.values[0] - top2.values[1]))
+        out.append(tok)
+        if eos_token_id is not None and tok == eos_token_id:
+            break
+        if len(out) == max_new_tokens:
+            break
+        if use_cache:
+            logits = llm_forward(cfg, W, e[tok][None], emu, cache, n, last_only=True)
+            n += 1
+        else:
+            seq = torch.cat([seq, e[tok][None]], dim=0)
+            logits = llm_forward(cfg, W, seq, emu, None, 0, last_only=True)
+    return (out, margins) if return_margins else out
+
+
+def lora_merge(w: torch.Tensor, A: torch.Tensor, B: torch.Tensor, alpha: float = 256.0, r: int = 128) -> torch.Tensor:
+    """peft 0.3.0 LoRA linear [ext, parity unpinned]: y = W x + (alpha/r) B(A x)  ==  (W + (alpha/r) B A) x.
+    models/llava_next_video.py:212-224 (r=128, alpha=256 -> x2.0)."""
+    return w.float() + (alpha / r) * (B.float() @ A.float())
+
+
+# --------------------------------------------------------------------------------------
+# synthetic weights (shared by tests / bench so HIP path and oracle see identical tensors)
+# --------------------------------------------------------------------------------------
+def frame_normalize(frames_u8: torch.Tensor, mean, std) -> torch.Tensor:
+    """ToTensor + Normalize tail of frame_transform (mm_utils/utils.py:177-181) for already-sized frames."""
+    x = frames_u8.float() / 255.0
+    m = torch.tensor(mean).view(1, 3, 1, 1)
+    s = torch.tensor(std).view(1, 3, 1, 1)
+    return (x - m) / s

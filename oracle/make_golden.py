@@ -1,0 +1,271 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (imported in place from
+/root/reference via oracle/ref_shims.py) on seeded synthetic weights/inputs.
+
+Run in the build container only:  python oracle/make_golden.py
+Fixtures are data (inputs are regenerated from seeds by grounded_video_llm_amd.synth.det_tensor;
+outputs are stored, strided where large).  Nothing from the reference's source text is stored.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import _gvl_bootstrap  # noqa: E402,F401
+from grounded_video_llm_amd import synth  # noqa: E402
+import ref_shims  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def save(name, meta, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=np.array(json.dumps(meta)),
+                        **{k: (v.detach().float().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    print("wrote", name, {k: tuple(np.asarray(v).shape) for k, v in arrays.items()})
+
+
+def load_into(module, W, allow_missing_prefixes=()):
+    sd = module.state_dict()
+    missing = [k for k in sd if k not in W and not k.startswith(tuple(allow_missing_prefixes))]
+    assert not missing, missing[:10]
+    unexpected = [k for k in W if k not in sd]
+    assert not unexpected, unexpected[:10]
+    module.load_state_dict({k: W[k].reshape(sd[k].shape) for k in W}, strict=False)
+    return module.eval()
+
+
+# ---------------------------------------------------------------------------------------------
+def g_clip(ns):
+    from transformers import CLIPVisionConfig
+    # tiny, all layers
+    cfg = dict(hidden=64, inter=128, layers=3, heads=4, image=28, patch=14)
+    c = CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4, image_size=28,
+                         patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5, projection_dim=32)
+    c._attn_implementation = "eager"
+    m = load_into(ns.clip.CLIPVisionModel(c), synth.clip_weights(64, 128, 3, 28, 14, seed="g.clip.tiny"))
+    px = synth.det_tensor("g.clip.tiny.px", (2, 3, 28, 28))
+    hs = m(px, output_hidden_states=True).hidden_states
+    save("clip_tiny", dict(cfg=cfg, seed="g.clip.tiny", px="g.clip.tiny.px", px_shape=[2, 3, 28, 28]),
+         penultimate=hs[-2][:, 1:], embed=hs[0])
+    # full-width, 2 layers => hidden_states[-2] is the output of ONE full-width layer at S=577
+    cfg = dict(hidden=1024, inter=4096, layers=2, heads=16, image=336, patch=14)
+    c = ns.llava.CLIP_VIT_LARGE_PATCH14_336_CONFIG
+    import copy
+    c = copy.deepcopy(c)
+    c.num_hidden_layers = 2
+    c._attn_implementation = "eager"
+    m = load_into(ns.clip.CLIPVisionModel(c), synth.clip_weights(1024, 4096, 2, 336, 14, seed="g.clip.full"))
+    px = synth.det_tensor("g.clip.full.px", (1, 3, 336, 336))
+    hs = m(px, output_hidden_states=True).hidden_states
+    save("clip_full_layer", dict(cfg=cfg, seed="g.clip.full", px="g.clip.full.px", px_shape=[1, 3, 336, 336], stride=[5, 7]),
+         penultimate=hs[-2][:, 1:][:, ::5, ::7])
+
+
+def _iv2(ns, dim, depth, heads, ratio, image, frames):
+    return ns.iv2.PretrainInternVideo2(
+        in_chans=3, img_size=image, patch_size=14, embed_dim=dim, depth=depth, num_heads=heads, mlp_ratio=ratio,
+        clip_embed_dim=32, attn_pool_num_heads=4, qkv_bias=False, drop_path_rate=0.25, init_values=0.00001,
+        qk_normalization=True, use_flash_attn=False, use_fused_rmsnorm=False, use_fused_mlp=False, fused_mlp_heuristic=1,
+        layerscale_no_force_fp32=False, num_frames=frames, tubelet_size=1, sep_pos_embed=False,
+        sep_image_video_pos_embed=True, use_checkpoint=False, checkpoint_num=0, clip_teacher_embed_dim=16,
+        clip_teacher_final_dim=16, clip_norm_type="l2", clip_return_layer=1, clip_student_return_interval=1)
+
+
+_IV2_EXTRA = ("img_pos_embed", "clip_pos_embed", "clip_img_pos_embed", "clip_projector", "clip_decoder", "final_clip_decoder")
+
+
+def g_iv2(ns):
+    cfg = dict(dim=64, inter=128, depth=4, heads=4, image=28, frames=2)
+    m = load_into(_iv2(ns, 64, 4, 4, 2.0, 28, 2), synth.iv2_weights(64, 128, 4, 2, 28, 14, seed="g.iv2.tiny"), _IV2_EXTRA)
+    px = synth.det_tensor("g.iv2.tiny.px", (2, 3, 2, 28, 28))
+    y = m(px, None, False, x_vis_return_idx=-2, x_vis_only=True)[:, 1:, :]
+    mb = m.to(torch.bfloat16)
+    yb = mb(px, None, False, x_vis_return_idx=-2, x_vis_only=True)[:, 1:, :].float()
+    save("iv2_tiny", dict(cfg=cfg, seed="g.iv2.tiny", px="g.iv2.tiny.px", px_shape=[2, 3, 2, 28, 28]), out=y, out_bf16=yb)
+    # full-width: depth=2 -> exactly ONE 1408/6144/16-head block runs (break at idx == depth-2 == 0), S = 2*256+1
+    cfg = dict(dim=1408, inter=6144, depth=2, heads=16, image=224, frames=2)
+    m = load_into(_iv2(ns, 1408, 2, 16, 48 / 11, 224, 2), synth.iv2_weights(1408, 6144, 2, 2, 224, 14, seed="g.iv2.full"), _IV2_EXTRA)
+    assert m.blocks[0].mlp.fc1.weight.shape[0] == 6144
+    px = synth.det_tensor("g.iv2.full.px", (1, 3, 2, 224, 224))
+    y = m(px, None, False, x_vis_return_idx=-2, x_vis_only=True)[:, 1:, :]
+    save("iv2_full_block", dict(cfg=cfg, seed="g.iv2.full", px="g.iv2.full.px", px_shape=[1, 3, 2, 224, 224], stride=[3, 11]),
+         out=y[:, ::3, ::11])
+    # load-time temporal pos-embed interpolation 4 -> 8 (interpolate_pos_embed_internvideo2_new)
+    mm = _iv2(ns, 64, 2, 4, 2.0, 28, 8)
+    pos4 = synth.det_tensor("g.iv2.pos4", (1, 1 + 4 * 4, 64))
+    sd = {"pos_embed": pos4.clone(), "clip_pos_embed": pos4.clone()}
+    ns.iv2.interpolate_pos_embed_internvideo2_new(sd, mm, orig_t_size=4)
+    save("iv2_pos_interp", dict(src="g.iv2.pos4", src_shape=[1, 17, 64], orig_t=4, new_t=8), pos=sd["pos_embed"])
+
+
+def _phi_cfg(ns, hidden, inter, layers, heads, kv, vocab, short, long):
+    c = ns.phi3.Phi3Config(vocab_size=vocab, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
+                           num_attention_heads=heads, num_key_value_heads=kv, rms_norm_eps=1e-5, rope_theta=10000.0,
+                           max_position_embeddings=131072, original_max_position_embeddings=4096, pad_token_id=0,
+                           bos_token_id=1, eos_token_id=2)
+    c.rope_scaling = {"type": "longrope", "short_factor": short, "long_factor": long}
+    c.rope_theta = 10000.0
+    c.max_position_embeddings = 131072
+    c.original_max_position_embeddings = 4096
+    c._attn_implementation = "eager"
+    return c
+
+
+def _phi(ns, hidden, inter, layers, heads, kv, vocab, seed):
+    short, long = synth.longrope_factors(hidden // heads)
+    m = ns.phi3.Phi3ForCausalLM(_phi_cfg(ns, hidden, inter, layers, heads, kv, vocab, short, long))
+    m.lm_head = torch.nn.Linear(hidden, vocab, bias=True)     # what reset_embeddings does (llava_next_video.py:263)
+    W = synth.llm_weights("phi3", hidden, inter, layers, heads, kv, vocab, True, seed=seed)
+    return load_into(m, W), W
+
+
+def g_phi3(ns):
+    cfg = dict(kind="phi3", hidden=64, inter=128, layers=2, heads=4, kv_heads=4, vocab=100)
+    m, W = _phi(ns, 64, 128, 2, 4, 4, 100, "g.phi.tiny")
+    x = synth.det_tensor("g.phi.tiny.x", (1, 10, 64), 0.5)
+    logits = m(inputs_embeds=x, use_cache=False).logits
+    xl = synth.det_tensor("g.phi.tiny.xl", (1, 4100, 64), 0.5)
+    logits_long = m(inputs_embeds=xl, use_cache=False).logits[:, -4:]
+    # greedy by the O(n^2) definition with the reference forward
+    e = m.get_input_embeddings().weight
+    seq = x.clone()
+    ids, margins = [], []
+    for _ in range(16):
+        lg = m(inputs_embeds=seq, use_cache=False).logits[0, -1]
+        t2 = torch.topk(lg, 2)
+        ids.append(int(t2.indices[0]))
+        margins.append(float(t2.values[0] - t2.values[1]))
+        seq = torch.cat([seq, e[ids[-1]][None, None]], dim=1)
+    save("phi3_tiny", dict(cfg=cfg, seed="g.phi.tiny", x="g.phi.tiny.x", x_shape=[1, 10, 64], xl="g.phi.tiny.xl", xl_shape=[1, 4100, 64]),
+         logits=logits, logits_long=logits_long, greedy_ids=np.array(ids), greedy_margins=np.array(margins))
+    # full-width single layer (3072 / 8192 / 32 heads x 96), S = 64
+    cfg = dict(kind="phi3", hidden=3072, inter=8192, layers=1, heads=32, kv_heads=32, vocab=64)
+    m, W = _phi(ns, 3072, 8192, 1, 32, 32, 64, "g.phi.full")
+    x = synth.det_tensor("g.phi.full.x", (1, 64, 3072), 0.5)
+    logits = m(inputs_embeds=x, use_cache=False).logits
+    save("phi3_full_layer", dict(cfg=cfg, seed="g.phi.full", x="g.phi.full.x", x_shape=[1, 64, 3072]), logits=logits)
+
+
+def g_llama(ns):
+    from transformers import LlamaConfig
+    cfg = dict(kind="llama", hidden=64, inter=128, layers=2, heads=4, kv_heads=2, vocab=100, rope_theta=500000.0)
+    c = LlamaConfig(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                    num_key_value_heads=2, rms_norm_eps=1e-5, max_position_embeddings=8192, pad_token_id=0, bos_token_id=1,
+                    eos_token_id=2, attention_bias=False)
+    c.rope_theta = 500000.0
+    c.rope_scaling = None
+    c.pretraining_tp = 1
+    c.attention_dropout = 0.0
+    c.mlp_bias = False
+    c._attn_implementation = "eager"
+    m = ns.llama.LlamaForCausalLM(c)
+    m.lm_head = torch.nn.Linear(64, 100, bias=True)
+    load_into(m, synth.llm_weights("llama", 64, 128, 2, 4, 2, 100, True, seed="g.llama.tiny"))
+    x = synth.det_tensor("g.llama.tiny.x", (1, 12, 64), 0.5)
+    logits = m(inputs_embeds=x, use_cache=False).logits
+    save("llama_tiny", dict(cfg=cfg, seed="g.llama.tiny", x="g.llama.tiny.x", x_shape=[1, 12, 64]), logits=logits)
+
+
+def g_glue(ns):
+    """encode_images + prepare_multimodal_inputs on a skeleton LLAVA_NEXT_VIDEO."""
+    import copy
+    L = ns.llava
+
+    class Skel(L.LLAVA_NEXT_VIDEO):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+
+        def get_input_embeddings(self):
+            return self.embed
+
+    for llm, hid in (("phi3.5", 3072), ("llama3", 4096)):
+        sk = Skel()
+        sk.llm, sk.dtype = llm, torch.float32
+        c = copy.deepcopy(L.CLIP_VIT_LARGE_PATCH14_336_CONFIG)
+        c.num_hidden_layers = 2
+        c.intermediate_size = 256
+        c._attn_implementation = "eager"
+        Wc = synth.clip_weights(1024, 256, 2, 336, 14, seed="g.glue.clip")
+        sk.vision_tower = load_into(ns.clip.CLIPVisionModel(c), Wc)
+        Wv = synth.iv2_weights(1408, 352, 3, 2, 224, 14, seed="g.glue.iv2")
+        sk.video_encoder = load_into(_iv2(ns, 1408, 3, 16, 0.25, 224, 2), Wv, _IV2_EXTRA)
+        Wp = synth.projector_weights(llm, hid, 1024, 1408, seed="g.glue.proj." + llm)
+        sk.video_projecter = load_into(L.Video_Projecter(1408, hid), {k[len("video_projecter."):]: v for k, v in Wp.items() if k.startswith("video_projecter.")})
+        mm = {k[len("multi_modal_projector."):]: v for k, v in Wp.items() if k.startswith("multi_modal_projector.")}
+        if llm == "phi3.5":
+            sk.multi_modal_projector = load_into(L.Phi3_5_Projecter(), mm)
+            sk.glb_GN, sk.sub_GN = Wp["glb_GN"], Wp["sub_GN"]
+        else:
+            from transformers import LlavaConfig, CLIPVisionConfig, LlamaConfig
+            lc = LlavaConfig(vision_config=CLIPVisionConfig(hidden_size=1024, num_attention_heads=16), text_config=LlamaConfig(hidden_size=hid, num_hidden_layers=1, intermediate_size=64, num_attention_heads=4, vocab_size=32),
+                             projector_hidden_act="gelu", vision_feature_layer=-2)
+            sk.multi_modal_projector = load_into(L.LlavaMultiModalProjector(lc), mm)
+            sk.image_newline = Wp["image_newline"]
+        sk.config = type("C", (), {"hidden_size": hid})()
+        sk.embed = torch.nn.Embedding(50, hid)
+        sk.embed.weight.data.copy_(synth.det_tensor("g.glue.embed." + llm, (50, hid), 0.5))
+        sp = synth.det_tensor("g.glue.sp", (1, 2, 3, 336, 336))
+        tp = synth.det_tensor("g.glue.tp", (1, 4, 3, 224, 224))
+        feats = sk.encode_images({"spatial_pixel_values": sp, "temporal_pixel_values": tp})
+        ids = torch.tensor([[1, 5, 9, -200, 7, 3, 2]])
+        emb, _, mask = sk.prepare_multimodal_inputs(ids, ids.clone(), torch.ones_like(ids), feats, ["vid"])
+        st = [3, 16]
+        save("glue_" + llm.replace(".", "_"), dict(llm=llm, hidden=hid, clip=dict(hidden=1024, inter=256, layers=2, heads=16),
+                                                   iv2=dict(dim=1408, inter=352, depth=3, heads=16, frames=2), ids=ids[0].tolist(),
+                                                   stride=st, feats_shape=list(feats.shape), emb_shape=list(emb.shape)),
+             feats=feats[:, ::st[0], ::st[1]], emb=emb[:, ::st[0], ::st[1]], mask=mask)
+
+
+def g_int(ns):
+    fi = {f"{n}_{v}": np.array([int(x) for x in ns.video_utils.get_frame_indices(n, v, "middle")])
+          for n, v in ((96, 2880), (8, 5), (96, 97), (96, 3000), (8, 240), (256, 7211), (96, 96), (12, 1))}
+    T = ns.template
+    tm = {"phi3.5": T.Phi_3_5_Template(), "llama3": T.LLaMA3_Template(), "vicuna": T.Vicuna_Template()}
+    prompts = {}
+    text = "Give you a textual query: 'a person opens the door'. When does the described content occur in the video?"
+    for llm, t in tm.items():
+        sep, eos = t.separator.apply()
+        for mode, val in (("grounding", T.DEFAULT_IMAGE_TOKEN + " " + T.GROUNDING_TOKEN + "\n" + text),
+                          ("qa", T.DEFAULT_IMAGE_TOKEN + "\n" + text)):
+            conv = [{"from": "human", "value": val}, {"from": "gpt", "value": ""}]
+            prompts[f"{llm}|{mode}"] = t.encode(conv).replace(eos, "")
+    pti = {}
+    for llm in ("phi3.5", "llama3"):
+        for txt, dur in (("From <36> to <64>.", 118.3), ("<0> <300> <150>", 77.77), ("no tokens here", 10.0)):
+            pti[f"{llm}|{txt}|{dur}"] = ns.inference.parse_time_interval(txt, dur, 300, llm)
+    # tokenizer_image_token with a toy whitespace tokenizer (BOS=1)
+    class Tok:
+        bos_token_id = 1
+
+        def __call__(self, s):
+            return type("O", (), {"input_ids": [1] + [3 + (sum(map(ord, w)) % 90) for w in s.split()]})()
+
+    class TokNoBos(Tok):
+        def __call__(self, s):
+            return type("O", (), {"input_ids": [3 + (sum(map(ord, w)) % 90) for w in s.split()]})()
+
+    tit = {}
+    for name, tk in (("bos", Tok()), ("nobos", TokNoBos())):
+        for pr in ("hello <image> world again", "<image>\nwhat is this", "a b c", "x <image> y <image> z"):
+            tit[f"{name}|{pr}"] = ns.llava.LLAVA_NEXT_VIDEO.tokenizer_image_token(None, pr, tk)
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "integer_paths.json"), "w") as f:
+        json.dump(dict(frame_indices={k: v.tolist() for k, v in fi.items()}, prompts=prompts, parse_time_interval=pti,
+                       tokenizer_image_token=tit, prompt_text=text), f, indent=1)
+    print("wrote integer_paths.json")
+
+
+if __name__ == "__main__":
+    ns = ref_shims.load_reference()
+    which = sys.argv[1:] or ["int", "clip", "iv2", "phi3", "llama", "glue"]
+    for w in which:
+        {"int": g_int, "clip": g_clip, "iv2": g_iv2, "phi3": g_phi3, "llama": g_llama, "glue": g_glue}[w](ns)

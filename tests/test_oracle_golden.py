@@ -1,0 +1,164 @@
+"""Pins oracle/gvl_oracle.py (the CPU restatement) against outputs of the reference's own modules
+(tests/golden/*, produced by oracle/make_golden.py in the build container)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import gvl_oracle as O
+from grounded_video_llm_amd import synth
+from conftest import load_golden, GOLDEN
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max()
+    ref = np.abs(b).max() + 1e-12
+    assert err <= tol * ref, f"max err {err:.3e} vs scale {ref:.3e}"
+
+
+def test_integer_paths():
+    g = json.load(open(os.path.join(GOLDEN, "integer_paths.json")))
+    for k, v in g["frame_indices"].items():
+        n, vlen = map(int, k.split("_"))
+        assert O.get_frame_indices(n, vlen, "middle") == v, k
+    assert O.get_frame_indices(96, 2880)[:2] == [14, 44] and O.get_frame_indices(96, 2880)[-1] == 2864
+    for k, v in g["prompts"].items():
+        llm, mode = k.split("|")
+        assert O.build_prompt(llm, mode, g["prompt_text"]) == v, k
+    for k, v in g["parse_time_interval"].items():
+        llm, txt, dur = k.split("|")
+        assert O.parse_time_interval(txt, float(dur), 300, llm) == v, k
+    for k, v in g["tokenizer_image_token"].items():
+        name, pr = k.split("|", 1)
+        def tok(s, nb=(name == "nobos")):
+            ids = [3 + (sum(map(ord, w)) % 90) for w in s.split()]
+            return ids if nb else [1] + ids
+        assert O.tokenizer_image_token(pr, tok, 1) == v, k
+    # SURVEY §8 a14 goldens
+    assert O.parse_time_interval("From <36> to <64>.", 118.3, 300, "phi3.5") == "From  14.20 seconds to  25.24 seconds."
+    assert O.seconds_to_temporal_tokens("What is happening from 70 seconds to 80 seconds?", 118.3) == "What is happening from <177> to <202>?"
+    assert O.spatial_frame_indices(96, 12) == [4 + 8 * i for i in range(12)]
+    rng = np.random.default_rng(0)
+    for t, d in zip(rng.uniform(0, 500, 2000), rng.uniform(1, 500, 2000)):
+        t = min(t, d)
+        assert O.quantize_timestamp(float(t), float(d)) == min(int(300 * float(t) / float(d)), 300)
+
+
+def test_left_pad_truncate():
+    ids, mask = O.left_pad_truncate([[1, 2, 3], [4, 5, 6, 7, 8]], pad_id=0, max_txt_len=4)
+    assert ids.tolist() == [[0, 1, 2, 3], [5, 6, 7, 8]] and mask.tolist() == [[0, 1, 1, 1], [1, 1, 1, 1]]
+
+
+def test_clip_tiny():
+    meta, g = load_golden("clip_tiny")
+    c = meta["cfg"]
+    W = synth.clip_weights(c["hidden"], c["inter"], c["layers"], c["image"], c["patch"], seed=meta["seed"])
+    px = synth.det_tensor(meta["px"], meta["px_shape"])
+    _close(O.clip_embeddings(px, W), g["embed"], 1e-5)
+    _close(O.clip_penultimate(px, W, c["layers"], c["heads"]), g["penultimate"], 2e-5)
+
+
+def test_clip_full_layer():
+    meta, g = load_golden("clip_full_layer")
+    c = meta["cfg"]
+    W = synth.clip_weights(c["hidden"], c["inter"], c["layers"], c["image"], c["patch"], seed=meta["seed"])
+    px = synth.det_tensor(meta["px"], meta["px_shape"])
+    y = O.clip_penultimate(px, W, c["layers"], c["heads"])
+    s = meta["stride"]
+    _close(y[:, ::s[0], ::s[1]], g["penultimate"], 5e-5)
+    ye = O.clip_penultimate(px, W, c["layers"], c["heads"], emu=True)
+    _close(ye[:, ::s[0], ::s[1]], g["penultimate"], 3e-2)      # bf16-emulated path stays within bf16 noise of fp32
+
+
+def test_iv2_tiny_and_pos_interp():
+    meta, g = load_golden("iv2_tiny")
+    c = meta["cfg"]
+    W = synth.iv2_weights(c["dim"], c["inter"], c["depth"], c["frames"], c["image"], 14, seed=meta["seed"])
+    px = synth.det_tensor(meta["px"], meta["px_shape"])
+    _close(O.iv2_encode(px, W, c["depth"], c["heads"]), g["out"], 2e-5)
+    _close(O.iv2_encode(px, W, c["depth"], c["heads"], emu=True), g["out_bf16"], 3e-2)   # vs the reference run in bf16 on CPU
+    meta, g = load_golden("iv2_pos_interp")
+    src = synth.det_tensor(meta["src"], meta["src_shape"])
+    _close(O.interpolate_pos_embed_t(src, meta["orig_t"], meta["new_t"]), g["pos"], 1e-6)
+
+
+def test_iv2_full_block():
+    meta, g = load_golden("iv2_full_block")
+    c = meta["cfg"]
+    W = synth.iv2_weights(c["dim"], c["inter"], c["depth"], c["frames"], c["image"], 14, seed=meta["seed"])
+    px = synth.det_tensor(meta["px"], meta["px_shape"])
+    y = O.iv2_encode(px, W, c["depth"], c["heads"])
+    s = meta["stride"]
+    _close(y[:, ::s[0], ::s[1]], g["out"], 5e-5)
+
+
+def _cfg(c, long=True):
+    short, lng = synth.longrope_factors(c["hidden"] // c["heads"])
+    if c["kind"] == "phi3":
+        return O.LLMConfig("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], 1e-5, 10000.0,
+                           131072, 4096, short, lng)
+    return O.LLMConfig("llama", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], 1e-5,
+                       c.get("rope_theta", 500000.0))
+
+
+def test_phi3_tiny_logits_long_and_greedy():
+    meta, g = load_golden("phi3_tiny")
+    c = meta["cfg"]
+    cfg = _cfg(c)
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
+    x = synth.det_tensor(meta["x"], meta["x_shape"], 0.5)[0]
+    _close(O.llm_forward(cfg, W, x), g["logits"][0], 2e-5)
+    xl = synth.det_tensor(meta["xl"], meta["xl_shape"], 0.5)[0]
+    _close(O.llm_forward(cfg, W, xl)[-4:], g["logits_long"][0], 1e-4)      # S=4100 > 4096 -> long factors
+    ids_full = O.greedy_generate(cfg, W, x, 16, None, use_cache=False)
+    ids_kv, margins = O.greedy_generate(cfg, W, x, 16, None, use_cache=True, return_margins=True)
+    assert ids_full == g["greedy_ids"].tolist()
+    assert ids_kv == g["greedy_ids"].tolist()
+    np.testing.assert_allclose(margins, g["greedy_margins"], rtol=0, atol=1e-4)
+
+
+def test_phi3_full_layer():
+    meta, g = load_golden("phi3_full_layer")
+    c = meta["cfg"]
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
+    x = synth.det_tensor(meta["x"], meta["x_shape"], 0.5)[0]
+    _close(O.llm_forward(_cfg(c), W, x), g["logits"][0], 5e-5)
+
+
+def test_llama_tiny():
+    meta, g = load_golden("llama_tiny")
+    c = meta["cfg"]
+    W = synth.llm_weights("llama", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
+    x = synth.det_tensor(meta["x"], meta["x_shape"], 0.5)[0]
+    _close(O.llm_forward(_cfg(c), W, x), g["logits"][0], 2e-5)
+
+
+def _glue(name):
+    meta, g = load_golden(name)
+    llm, hid = meta["llm"], meta["hidden"]
+    cc, vc = meta["clip"], meta["iv2"]
+    Wc = synth.clip_weights(cc["hidden"], cc["inter"], cc["layers"], 336, 14, seed="g.glue.clip")
+    Wv = synth.iv2_weights(vc["dim"], vc["inter"], vc["depth"], vc["frames"], 224, 14, seed="g.glue.iv2")
+    Wp = synth.projector_weights(llm, hid, 1024, 1408, seed="g.glue.proj." + llm)
+    sp = synth.det_tensor("g.glue.sp", (1, 2, 3, 336, 336))
+    tp = synth.det_tensor("g.glue.tp", (1, 4, 3, 224, 224))
+    feats = O.encode_images(sp, tp, Wc, Wv, Wp, llm, clip_layers=cc["layers"], clip_heads=cc["heads"], iv2_depth=vc["depth"], iv2_heads=vc["heads"])
+    assert list(feats.shape) == meta["feats_shape"]
+    s = meta["stride"]
+    _close(feats[:, ::s[0], ::s[1]], g["feats"], 1e-4)
+    emb_w = synth.det_tensor("g.glue.embed." + llm, (50, hid), 0.5)
+    emb = O.splice(torch.tensor(meta["ids"]), feats[0], emb_w)[None]
+    assert list(emb.shape) == meta["emb_shape"]
+    _close(emb[:, ::s[0], ::s[1]], g["emb"], 1e-4)
+    assert g["mask"].shape[1] == emb.shape[1] and g["mask"].min() == 1
+
+
+def test_glue_phi35():
+    _glue("glue_phi3_5")        # 2 segments x 285 tokens (SURVEY §3.2 [probe])
+
+
+def test_glue_llama3():
+    _glue("glue_llama3")        # 2 segments x 193 tokens

@@ -1,0 +1,374 @@
+// gvl_attn.hip -- LDS-staged flash attention (vision + LLM prefill) and paged-KV decode attention, gfx950.
+//
+// Replaces: eager bmm/softmax/bmm in CLIPAttention (models/modeling_clip.py:274-314),
+// flash_attn_varlen_qkvpacked_func in InternVideo2 (models/internvideo2.py:514-517, naive :575-580),
+// flash_attn_func(causal=True) / eager attention in Phi-3 / Llama (models/modeling_phi3.py:575-594,857-864;
+// models/modeling_llama.py:316-399) and the per-token cached attention of generate().
+//
+// Operand layouts (written by qkv_post in gvl_elem.hip):
+//   Q  [B][H][S][D]                      D = head dim padded to a multiple of 32 (88 -> 96, pad = 0)
+//   K  pages [page][KV][64][D]           one page = 64 consecutive tokens = one key tile
+//   V^T pages [page][KV][D][64]          transposed inside the page: the P.V contraction (over keys)
+//                                        then reads K-contiguous rows exactly like a GEMM operand.
+// The same page layout is the KV cache of the LLM (block_table != null) and the scratch K/V of the
+// vision towers (block_table == null, page(b,t) = b*n_tiles + t).
+//
+// Math per 64-key tile and 32-query wave (v_mfma_f32_32x32x16_bf16):
+//   S^T[key,q] = K . Q^T     (A = K rows from LDS, B = Q from registers)
+//   online softmax on the lane's 32 scores (the lane owns ONE query: max/sum are lane-local plus one
+//   exchange with lane^32)
+//   O^T[d,q] += V^T[d,keys] . P^T[keys,q]   (A = V^T rows from LDS, B = P straight from the score
+//   registers: K rows are read in a permuted order so that the 8 scores a lane holds per 16-key step
+//   are exactly the 8 k-slots the MFMA B operand wants -- no cross-lane movement of P at all).
+#include "gvl_internal.h"
+
+template <int D> struct KSwz;
+template <> struct KSwz<64> {   // 128-byte rows: phys = chunk ^ ((row>>1)&7)
+  static __device__ __forceinline__ int phys(int row, int lc) { return lc ^ ((row >> 1) & 7); }
+  static __device__ __forceinline__ int logical(int row, int pc) { return pc ^ ((row >> 1) & 7); }
+};
+template <> struct KSwz<96> {   // 192-byte rows (12 chunks): rotate by 3*((row>>2)&3) -- conflict-free, see DESIGN.md
+  static __device__ __forceinline__ int phys(int row, int lc) { int p = lc + 3 * ((row >> 2) & 3); return p >= 12 ? p - 12 : p; }
+  static __device__ __forceinline__ int logical(int row, int pc) { int l = pc - 3 * ((row >> 2) & 3); return l < 0 ? l + 12 : l; }
+};
+template <> struct KSwz<128> {  // 256-byte rows: phys = chunk ^ (row&15)
+  static __device__ __forceinline__ int phys(int row, int lc) { return lc ^ (row & 15); }
+  static __device__ __forceinline__ int logical(int row, int pc) { return pc ^ (row & 15); }
+};
+
+// row i of the S^T MFMA reads key kperm(i) of the 32-key block, so that accumulator register r of
+// lane (q, h) holds key (r>>3)*16 + 8*h + (r&7).
+__device__ __forceinline__ int kperm(int i) {
+  const int c = i & 3, hh = (i >> 2) & 1, b = i >> 3;
+  return (b >> 1) * 16 + 8 * hh + 4 * (b & 1) + c;
+}
+
+template <int D, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int NT = NWAVES * 64;
+  constexpr int DK = D / 16;          // k-steps of the QK^T contraction
+  constexpr int DB = D / 32;          // 32-row d blocks of O^T
+  constexpr int CPR = D / 8;          // 16-byte chunks per K row
+  constexpr int KCH = 64 * CPR;       // chunks in a K tile (== chunks in a V^T tile)
+  constexpr int NIK = KCH / NT;       // DMA instructions per thread for K (and for V^T)
+  constexpr int TILE_BYTES = 64 * D * 2;
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  static_assert(KCH % NT == 0, "tile/threads mismatch");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int hkv = head / (a.H / a.KV);
+  const int q0 = blockIdx.x * (NWAVES * 32);
+  const int qw = q0 + wave * 32;
+  const int n_tiles_all = (a.S + 63) >> 6;
+  int last_q = q0 + NWAVES * 32 - 1; if (last_q > a.S - 1) last_q = a.S - 1;
+  const int n_tiles = a.causal ? (last_q >> 6) + 1 : n_tiles_all;
+
+  // ---- DMA source offsets inside a page (elements), loop invariant --------------------------------
+  int koff[NIK], voff[NIK];
+#pragma unroll
+  for (int i = 0; i < NIK; ++i) {
+    const int pos = i * NT + tid;
+    const int kr = pos / CPR, kpc = pos - kr * CPR;
+    koff[i] = kr * D + KSwz<D>::logical(kr, kpc) * 8;
+    const int vr = pos >> 3, vpc = pos & 7;
+    voff[i] = vr * 64 + (vpc ^ ((vr >> 1) & 7)) * 8;
+  }
+  auto page_of = [&](int t) -> size_t {
+    const int pg = a.block_table ? a.block_table[b * a.max_pages + t] : b * n_tiles_all + t;
+    return ((size_t)pg * a.KV + hkv) * (size_t)(64 * D);
+  };
+  auto stage = [&](int buf, int t) {
+    const size_t pb = page_of(t);
+    const bf16_t* kp = a.Kt + pb;
+    const bf16_t* vp = a.Vt + pb;
+    char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NIK; ++i) {
+      char* dst = base + (i * NT + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + koff[i]),
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NIK; ++i) {
+      char* dst = base + TILE_BYTES + (i * NT + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + voff[i]),
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  // ---- Q fragments (MFMA B operand): lane (q = qw + l31, h) holds d = kk*16 + 8h + 0..7 ----------
+  bf16x8_t qf[DK];
+  {
+    int qi = qw + l31; if (qi > a.S - 1) qi = a.S - 1;
+    const bf16_t* qp = a.Q + (((size_t)b * a.H + head) * a.S + qi) * D + 8 * h;
+#pragma unroll
+    for (int kk = 0; kk < DK; ++kk) qf[kk] = *(const bf16x8_t*)(qp + kk * 16);
+  }
+
+  f32x16_t o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float sc = a.scale * 1.4426950408889634f;  // scores in log2 units
+
+  // K fragment rows (permuted) and their swizzled chunk offsets; V^T fragment rows
+  const int krow0 = kperm(l31);
+  const int vswz = (l31 >> 1) & 7;
+  const int my_q = qw + l31;
+
+  stage(0, 0);
+  for (int t = 0; t < n_tiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < n_tiles) stage((t + 1) & 1, t + 1);
+    if (a.causal && t * 64 > qw + 31) continue;   // wave-uniform: every key of this tile is in the future
+    const char* kb_ = smem + (t & 1) * STAGE_BYTES;
+    const char* vb_ = kb_ + TILE_BYTES;
+
+    // ---- S^T = K . Q^T ---------------------------------------------------------------------------
+    f32x16_t s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+      const int row = kb * 32 + krow0;
+#pragma unroll
+      for (int kk = 0; kk < DK; ++kk) {
+        const bf16x8_t kf = *(const bf16x8_t*)(kb_ + row * (D * 2) + (KSwz<D>::phys(row, kk * 2 + h) << 4));
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (lane-local) ----------------------------------------------------------------
+    const bool need_mask = (t == n_tiles_all - 1 && (a.S & 63)) || (a.causal && t * 64 + 63 > qw);
+    float mx = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = s[kb][r] * sc;
+        if (need_mask) {
+          const int key = t * 64 + kb * 32 + (r >> 3) * 16 + 8 * h + (r & 7);
+          const bool dead = key >= a.S || (a.causal && key > my_q);
+          v = dead ? -1e30f : v;
+        }
+        s[kb][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+        s[kb][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+    // ---- O^T += V^T . P^T ---------------------------------------------------------------------------
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int kb = st >> 1, r0 = (st & 1) * 8;
+      union { bf16x8_t v; unsigned u[4]; } pf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pf.u[e] = pack2bf(s[kb][r0 + 2 * e], s[kb][r0 + 2 * e + 1]);
+      const int coff = ((st * 2 + h) ^ vswz) << 4;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const bf16x8_t vf = *(const bf16x8_t*)(vb_ + (db * 32 + l31) * 128 + coff);
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o[db], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (my_q < a.S) {
+    bf16_t* op = a.O + ((size_t)b * a.S + my_q) * (size_t)(a.H * a.Dout) + head * a.Dout;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * h;
+        if (d < a.Dout) {
+          u32x2_t w = {pack2bf(o[db][4 * g] * inv, o[db][4 * g + 1] * inv), pack2bf(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv)};
+          *(u32x2_t*)(op + d) = w;
+        }
+      }
+  }
+}
+
+template <int D, int NWAVES>
+static int launch_attn(const AttnArgs& a, hipStream_t st) {
+  constexpr int LDS = 2 * 2 * 64 * D * 2;
+  static bool attr_set = false;
+  auto kern = attn_fwd_kernel<D, NWAVES>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+    attr_set = true;
+  }
+  dim3 grid((a.S + NWAVES * 32 - 1) / (NWAVES * 32), a.H, a.B);
+  hipLaunchKernelGGL(kern, grid, dim3(NWAVES * 64), LDS, st, a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+double gvl_attn_flops(const AttnArgs& a) {
+  // algorithmic: 4*S^2*d*H non-causal, half that causal, d = real head dim
+  const double f = 4.0 * (double)a.S * a.S * a.Dout * a.H * a.B;
+  return a.causal ? 0.5 * f : f;
+}
+
+int gvl_launch_attention(const AttnArgs& a, hipStream_t st) {
+  if (a.B <= 0 || a.S <= 0 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 3)) return -1;
+  switch (a.D) {
+    case 64: return launch_attn<64, 4>(a, st);
+    case 96: return launch_attn<96, 4>(a, st);
+    case 128: return launch_attn<128, 4>(a, st);
+    default: return -1;
+  }
+}
+
+// =====================================================================================================
+// decode attention: one new query per head against the paged cache, split over the context
+// =====================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a) {
+  constexpr int CPR = D / 8;       // 16-byte chunks per key row
+  constexpr int NIT = D / 8;       // 64*CPR chunks per page / 64 lanes
+  __shared__ __attribute__((aligned(16))) float q_s[D];
+  __shared__ __attribute__((aligned(16))) float part_s[4][64 * CPR];
+  __shared__ __attribute__((aligned(16))) float p_s[4][64];
+  __shared__ float red_s[4][D + 2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int head = blockIdx.x, split = blockIdx.y;
+  const int hkv = head / (a.H / a.KV);
+  const int pos = *a.pos_ptr + 1;                   // tokens in the cache, new one included
+  const int npages = (pos + 63) >> 6;
+  const int pps = (npages + a.nsplit - 1) / a.nsplit;
+  const int p_begin = split * pps;
+  int p_end = p_begin + pps; if (p_end > npages) p_end = npages;
+
+  for (int i = tid; i < D; i += 256) q_s[i] = bf2f(a.q[head * D + i]);
+  __syncthreads();
+
+  const float sc = a.scale * 1.4426950408889634f;
+  float m_run = -1e30f, l_run = 0.f;
+  float oacc[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) oacc[i] = 0.f;
+
+  for (int pg = p_begin + wave; pg < p_end; pg += 4) {
+    const size_t pb = ((size_t)a.block_table[pg] * a.KV + hkv) * (size_t)(64 * D);
+    const bf16_t* kp = a.Kt + pb;
+    const bf16_t* vp = a.Vt + pb;
+    // partial dots, fully coalesced 16-byte loads
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 64 + lane;
+      const int dch = c % CPR;
+      const u32x4_t kv = *(const u32x4_t*)(kp + c * 8);
+      const float* qq = q_s + dch * 8;
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc += lo_bf(kv[e]) * qq[2 * e] + hi_bf(kv[e]) * qq[2 * e + 1];
+      part_s[wave][c] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float sv = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPR; ++i) sv += part_s[wave][lane * CPR + i];
+    sv *= sc;
+    if (pg * 64 + lane >= pos) sv = -1e30f;
+    const float mx = wave_max(sv);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    const float p = __builtin_amdgcn_exp2f(sv - m_new);
+    l_run = l_run * alpha + wave_sum(p);
+    // the reference multiplies bf16 probabilities into V (flash-attn / eager .to(v.dtype))
+    p_s[wave][lane] = rbf(p);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 64 + lane;                 // chunk of V^T: d = c/8, keys 8*(c%8)..+7
+      const u32x4_t vv = *(const u32x4_t*)(vp + c * 8);
+      const float* pp = p_s[wave] + (c & 7) * 8;
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc += lo_bf(vv[e]) * pp[2 * e] + hi_bf(vv[e]) * pp[2 * e + 1];
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      oacc[it] = oacc[it] * alpha + acc;            // d = it*8 + lane/8 (same value in the 8 lanes)
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // combine the 4 waves
+  if ((lane & 7) == 0) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) red_s[wave][it * 8 + (lane >> 3)] = oacc[it];
+  }
+  if (lane == 0) { red_s[wave][D] = m_run; red_s[wave][D + 1] = l_run; }
+  __syncthreads();
+  float* outp = a.part + ((size_t)head * a.nsplit + split) * (D + 2);
+  const float mm = fmaxf(fmaxf(red_s[0][D], red_s[1][D]), fmaxf(red_s[2][D], red_s[3][D]));
+  if (tid < D) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc += red_s[w][tid] * __builtin_amdgcn_exp2f(red_s[w][D] - mm);
+    outp[tid] = acc;
+  }
+  if (tid == 0) {
+    float l = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) l += red_s[w][D + 1] * __builtin_amdgcn_exp2f(red_s[w][D] - mm);
+    outp[D] = mm; outp[D + 1] = l;
+  }
+}
+
+template <int D>
+__global__ void decode_attn_combine_kernel(const float* part, bf16_t* out, int nsplit, int Dout) {
+  const int head = blockIdx.x, d = threadIdx.x;
+  const float* pp = part + (size_t)head * nsplit * (D + 2);
+  float mm = -1e30f;
+  for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, pp[s * (D + 2) + D]);
+  float l = 0.f, acc = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float w = __builtin_amdgcn_exp2f(pp[s * (D + 2) + D] - mm);
+    l += pp[s * (D + 2) + D + 1] * w;
+    if (d < D) acc += pp[s * (D + 2) + d] * w;
+  }
+  if (d < Dout) out[head * Dout + d] = f2bf(acc / l);
+}
+
+template <int D>
+static int launch_decode(const DecodeAttnArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(decode_attn_kernel<D>, dim3(a.H, a.nsplit), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(decode_attn_combine_kernel<D>, dim3(a.H), dim3(D), 0, st, a.part, a.out, a.nsplit, a.Dout);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int gvl_launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st) {
+  switch (a.D) {
+    case 64: return launch_decode<64>(a, st);
+    case 96: return launch_decode<96>(a, st);
+    case 128: return launch_decode<128>(a, st);
+    default: return -1;
+  }
+}

@@ -1,0 +1,613 @@
+// gvl_elem.hip -- HBM-bound kernels of the hot path: norms, patch im2col, embeddings, qkv re-tiling
+// (+ qk-RMSNorm / RoPE), HD-merge / pooling glue, decode GEMV, argmax.   gfx950 only.
+// Every kernel moves 8/16 bytes per lane (guide G13) and keeps statistics in fp32.
+#include "gvl_internal.h"
+
+#define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -3)
+
+// =====================================================================================================
+// LayerNorm (CLIP: models/modeling_clip.py:351,353,851; fp32 in, bf16 out -- the next op is an autocast
+// linear) and RMSNorm (models/internvideo2.py:443-448, models/modeling_phi3.py:319-324).
+// one wave per row, 4 rows per block.
+// =====================================================================================================
+template <int MAXV>  // MAXV float4 per lane: cols <= MAXV*256
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, bf16_t* __restrict__ y, int rows, int cols, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * cols;
+  f32x4_t v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < cols) { v[i] = *(const f32x4_t*)(xr + c); s += v[i][0] + v[i][1] + v[i][2] + v[i][3]; }
+  }
+  const float mean = wave_sum(s) / cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < cols) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < cols) {
+      const f32x4_t wv = *(const f32x4_t*)(w + c), bv = *(const f32x4_t*)(b + c);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e] + bv[e];
+      u32x2_t pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+      *(u32x2_t*)(y + (size_t)row * cols + c) = pk;
+    }
+  }
+}
+
+int gvl_launch_layernorm_f32(const float* x, const float* w, const float* b, bf16_t* y, int rows, int cols, float eps, hipStream_t st) {
+  if (cols % 4 || cols > 4096) return -1;
+  dim3 g((rows + 3) / 4), t(256);
+  if (cols <= 1024) hipLaunchKernelGGL(layernorm_f32_kernel<4>, g, t, 0, st, x, w, b, y, rows, cols, eps);
+  else hipLaunchKernelGGL(layernorm_f32_kernel<16>, g, t, 0, st, x, w, b, y, rows, cols, eps);
+  return CHECK_LAUNCH();
+}
+
+template <int MAXV>  // MAXV 16-byte vectors per lane: cols <= MAXV*512
+__global__ __launch_bounds__(256) void rmsnorm_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                           bf16_t* __restrict__ y, int rows, int cols, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const bf16_t* xr = x + (size_t)row * cols;
+  u32x4_t v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < cols) {
+      v[i] = *(const u32x4_t*)(xr + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float a = lo_bf(v[i][e]), bb = hi_bf(v[i][e]); s += a * a + bb * bb; }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(s) / cols + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < cols) {
+      const u32x4_t wv = *(const u32x4_t*)(w + c);
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)   // weight * bf16(x * rsqrt) , both factors bf16, product rounded to bf16
+        o[e] = pack2bf(lo_bf(wv[e]) * rbf(lo_bf(v[i][e]) * rs), hi_bf(wv[e]) * rbf(hi_bf(v[i][e]) * rs));
+      *(u32x4_t*)(y + (size_t)row * cols + c) = o;
+    }
+  }
+}
+
+int gvl_launch_rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, float eps, hipStream_t st) {
+  if (cols % 8 || cols > 8192) return -1;
+  dim3 g((rows + 3) / 4), t(256);
+  if (cols <= 2048) hipLaunchKernelGGL(rmsnorm_bf16_kernel<4>, g, t, 0, st, x, w, y, rows, cols, eps);
+  else hipLaunchKernelGGL(rmsnorm_bf16_kernel<16>, g, t, 0, st, x, w, y, rows, cols, eps);
+  return CHECK_LAUNCH();
+}
+
+// =====================================================================================================
+// patch im2col for conv with stride == kernel (models/modeling_clip.py:185, models/internvideo2.py:714-722)
+// px f32 [n][3][T][HW][HW] -> A bf16 [n*T*g*g][Kp], k = c*p*p + py*p + px, zero padded to Kp
+// =====================================================================================================
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ px, bf16_t* __restrict__ A, int n_img, int T, int image,
+                                                       int patch, int Kp) {
+  const int g = image / patch, K = 3 * patch * patch, kv = Kp / 8;
+  const long total = (long)n_img * T * g * g * kv;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int kc = (int)(idx % kv);
+    const long row = idx / kv;
+    const int gx = (int)(row % g), gy = (int)((row / g) % g), t = (int)((row / ((long)g * g)) % T), img = (int)(row / ((long)g * g * T));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = kc * 8 + e;
+      if (k < K) {
+        const int c = k / (patch * patch), rem = k - c * patch * patch, py = rem / patch, pxx = rem - py * patch;
+        v[e] = px[((((size_t)img * 3 + c) * T + t) * image + (gy * patch + py)) * image + gx * patch + pxx];
+      } else v[e] = 0.f;
+    }
+    u32x4_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+    *(u32x4_t*)(A + row * Kp + kc * 8) = o;
+  }
+}
+int gvl_launch_patchify(const float* px, bf16_t* A, int n_img, int T, int image, int patch, int Kp, hipStream_t st) {
+  if (Kp % 8 || Kp < 3 * patch * patch || image % patch) return -1;
+  const int g = image / patch;
+  const long total = (long)n_img * T * g * g * (Kp / 8);
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(patchify_kernel, dim3(blocks), dim3(256), 0, st, px, A, n_img, T, image, patch, Kp);
+  return CHECK_LAUNCH();
+}
+
+// =====================================================================================================
+// CLIP embeddings + pre_layrnorm (models/modeling_clip.py:182-191, :851): one wave per token row
+// =====================================================================================================
+template <int MAXV>
+__global__ __launch_bounds__(256) void clip_embed_ln_kernel(const bf16_t* __restrict__ patch, const float* __restrict__ cls,
+                                                            const float* __restrict__ pos, const float* __restrict__ lnw,
+                                                            const float* __restrict__ lnb, float* __restrict__ x, int n_img, int P, int C, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int S = P + 1;
+  if (row >= n_img * S) return;
+  const int img = row / S, s = row - img * S;
+  f32x4_t v[MAXV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < C) {
+      const f32x4_t pv = *(const f32x4_t*)(pos + (size_t)s * C + c);
+      if (s == 0) {
+        const f32x4_t cv = *(const f32x4_t*)(cls + c);
+        v[i] = cv + pv;
+      } else {
+        const u32x2_t pk = *(const u32x2_t*)(patch + ((size_t)img * P + (s - 1)) * C + c);
+        f32x4_t e = {lo_bf(pk[0]), hi_bf(pk[0]), lo_bf(pk[1]), hi_bf(pk[1])};
+        v[i] = e + pv;
+      }
+      sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+  }
+  const float mean = wave_sum(sum) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < C) {
+      const f32x4_t wv = *(const f32x4_t*)(lnw + c), bv = *(const f32x4_t*)(lnb + c);
+      f32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e] + bv[e];
+      *(f32x4_t*)(x + (size_t)row * C + c) = o;
+    }
+  }
+}
+int gvl_launch_clip_embed_ln(const bf16_t* patch, const float* cls, const float* pos, const float* lnw, const float* lnb, float* x,
+                             int n_img, int P, int C, float eps, hipStream_t st) {
+  if (C % 4 || C > 4096) return -1;
+  const int rows = n_img * (P + 1);
+  dim3 g((rows + 3) / 4), t(256);
+  if (C <= 1024) hipLaunchKernelGGL(clip_embed_ln_kernel<4>, g, t, 0, st, patch, cls, pos, lnw, lnb, x, n_img, P, C, eps);
+  else hipLaunchKernelGGL(clip_embed_ln_kernel<16>, g, t, 0, st, patch, cls, pos, lnw, lnb, x, n_img, P, C, eps);
+  return CHECK_LAUNCH();
+}
+
+// =====================================================================================================
+// InternVideo2 embeddings (models/internvideo2.py:972-1011): cat(cls, patches) + pos_embed, all bf16
+// =====================================================================================================
+__global__ __launch_bounds__(256) void iv2_embed_kernel(const bf16_t* __restrict__ patch, const bf16_t* __restrict__ cls,
+                                                        const bf16_t* __restrict__ pos, bf16_t* __restrict__ x, int B, int TL, int C) {
+  const int cv = C / 8;
+  const long total = (long)B * (TL + 1) * cv;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv) * 8;
+    const long row = idx / cv;
+    const int s = (int)(row % (TL + 1)), b = (int)(row / (TL + 1));
+    const u32x4_t pv = *(const u32x4_t*)(pos + (size_t)s * C + c);
+    const u32x4_t sv = s == 0 ? *(const u32x4_t*)(cls + c) : *(const u32x4_t*)(patch + ((size_t)b * TL + (s - 1)) * C + c);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2bf(lo_bf(sv[e]) + lo_bf(pv[e]), hi_bf(sv[e]) + hi_bf(pv[e]));
+    *(u32x4_t*)(x + row * C + c) = o;
+  }
+}
+int gvl_launch_iv2_embed(const bf16_t* patch, const bf16_t* cls, const bf16_t* pos, bf16_t* x, int B, int TL, int C, hipStream_t st) {
+  if (C % 8) return -1;
+  const long total = (long)B * (TL + 1) * (C / 8);
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(iv2_embed_kernel, dim3(blocks), dim3(256), 0, st, patch, cls, pos, x, B, TL, C);
+  return CHECK_LAUNCH();
+}
+
+// =====================================================================================================
+// qkv_post: fused-qkv row -> Q [B][H][S][D], K pages [page][KV][64][D] (+ V^T column for the decode row)
+//   mode 1: IV2 q/k RMSNorm over the full width (models/internvideo2.py:560-561,590-598)
+//   mode 2: RoPE (models/modeling_phi3.py:413-445; cos/sin tables hold the bf16-rounded values of :397-409)
+// one block per token row.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
+  __shared__ float red[8];
+  const int row = blockIdx.x;
+  const int b = row / a.S, s_in = row - b * a.S;
+  const int tid = threadIdx.x;
+  const bf16_t* qr = a.qkv + (size_t)row * a.ld;
+  const bf16_t* kr = qr + a.H * a.Dr;
+  const bf16_t* vr = kr + a.KV * a.Dr;
+  const int half = a.Dr >> 1;
+
+  float q_rs = 1.f, k_rs = 1.f;
+  if (a.mode == 1) {
+    float sq = 0.f, sk = 0.f;
+    for (int i = tid; i < a.H * a.Dr; i += 256) { const float v = bf2f(qr[i]); sq += v * v; }
+    for (int i = tid; i < a.KV * a.Dr; i += 256) { const float v = bf2f(kr[i]); sk += v * v; }
+    sq = wave_sum(sq); sk = wave_sum(sk);
+    if ((tid & 63) == 0) { red[tid >> 6] = sq; red[4 + (tid >> 6)] = sk; }
+    __syncthreads();
+    q_rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (a.H * a.Dr) + a.eps);
+    k_rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (a.KV * a.Dr) + a.eps);
+  }
+  int pos = a.pos0 + s_in;                     // token position (RoPE, cache slot)
+  if (a.pos_ptr) pos = *a.pos_ptr;
+  const float* cosp = a.cos; const float* sinp = a.sin;
+  if (a.mode == 2 && a.rope_switch > 0 && pos + 1 > a.rope_switch) { cosp = a.cos_l; sinp = a.sin_l; }
+  const int s_tok = a.pos_ptr ? pos : a.pos0 + s_in;   // index in the sequence's KV space
+  const int n_tiles = (a.S + 63) >> 6;
+  const int tile = s_tok >> 6, slot = s_tok & 63;
+  const int page = a.block_table ? a.block_table[b * a.max_pages + tile] : b * n_tiles + tile;
+
+  auto xform = [&](const bf16_t* src, int hd, int d, float rs, const bf16_t* nw) -> float {
+    const float v = bf2f(src[hd * a.Dr + d]);
+    if (a.mode == 1) return bf2f(nw[hd * a.Dr + d]) * rbf(v * rs);
+    if (a.mode == 2) {
+      const int j = d < half ? d : d - half;
+      const float c = cosp[(size_t)pos * half + j], sn = sinp[(size_t)pos * half + j];
+      const float other = d < half ? -bf2f(src[hd * a.Dr + d + half]) : bf2f(src[hd * a.Dr + d - half]);
+      return rbf(v * c) + rbf(other * sn);
+    }
+    return v;
+  };
+  // Q
+  const int dq = a.D >> 1;
+  bf16_t* Qrow_base = a.Q + ((size_t)b * a.H * a.S + s_in) * a.D;     // + head*S*D
+  for (int i = tid; i < a.H * dq; i += 256) {
+    const int hd = i / dq, d = (i - hd * dq) * 2;
+    unsigned o = 0;
+    if (d < a.Dr) o = pack2bf(xform(qr, hd, d, q_rs, a.qn), xform(qr, hd, d + 1, q_rs, a.qn));
+    *(unsigned*)(Qrow_base + (size_t)hd * a.S * a.D + d) = o;
+  }
+  // K
+  bf16_t* Kbase = a.Kt + ((size_t)page * a.KV) * (64 * a.D) + (size_t)slot * a.D;
+  for (int i = tid; i < a.KV * dq; i += 256) {
+    const int hd = i / dq, d = (i - hd * dq) * 2;
+    unsigned o = 0;
+    if (d < a.Dr) o = pack2bf(xform(kr, hd, d, k_rs, a.kn), xform(kr, hd, d + 1, k_rs, a.kn));
+    *(unsigned*)(Kbase + (size_t)hd * (64 * a.D) + d) = o;
+  }
+  // V^T column of this single row (decode).  Bulk rows go through v_transpose_kernel.
+  if (a.pos_ptr) {
+    bf16_t* Vbase = a.Vt + ((size_t)page * a.KV) * (64 * a.D) + slot;
+    for (int i = tid; i < a.KV * a.Dr; i += 256) {
+      const int hd = i / a.Dr, d = i - hd * a.Dr;
+      Vbase[(size_t)hd * (64 * a.D) + d * 64] = vr[i];
+    }
+  }
+}
+
+// V rows of one 64-token tile -> V^T page [KV][D][64] through LDS (tokens >= S and d >= Dr are zero filled)
+__global__ __launch_bounds__(256) void v_transpose_kernel(const QkvPostArgs a) {
+  __shared__ bf16_t tile[64][130];
+  const int t = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int s0 = a.pos0 + t * 64;                       // first token (sequence space) of this tile; pos0 is a multiple of 64
+  const int n_tiles = (a.S + 63) >> 6;
+  const int tile_idx = s0 >> 6;
+  const int page = a.block_table ? a.block_table[b * a.max_pages + tile_idx] : b * n_tiles + tile_idx;
+  const int voff = (a.H + a.KV) * a.Dr + hkv * a.Dr;
+  const int dq = a.Dr >> 1;
+  for (int i = tid; i < 64 * dq; i += 256) {
+    const int r = i / dq, d = (i - r * dq) * 2;
+    const int s_in = t * 64 + r;
+    unsigned v = 0;
+    if (s_in < a.S) v = *(const unsigned*)(a.qkv + ((size_t)b * a.S + s_in) * a.ld + voff + d);
+    tile[r][d] = (bf16_t)(v & 0xffff); tile[r][d + 1] = (bf16_t)(v >> 16);
+  }
+  __syncthreads();
+  bf16_t* dst = a.Vt + ((size_t)page * a.KV + hkv) * (64 * a.D);
+  for (int i = tid; i < a.D * 32; i += 256) {
+    const int d = i >> 5, kp = (i & 31) * 2;
+    unsigned o = 0;
+    if (d < a.Dr) o = (unsigned)tile[kp][d] | ((unsigned)tile[kp + 1][d] << 16);
+    *(unsigned*)(dst + d * 64 + kp) = o;
+  }
+}
+
+int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st) {
+  if (a.Dr & 1 || a.D < a.Dr || a.Dr > 128) return -1;
+  const int rows = a.B * a.S;
+  hipLaunchKernelGGL(qkv_post_kernel, dim3(rows), dim3(256), 0, st, a);
+  if (!a.pos_ptr) {
+    const int n_tiles = (a.S + 63) >> 6;
+    hipLaunchKernelGGL(v_transpose_kernel, dim3(n_tiles, a.KV, a.B), dim3(256), 0, st, a);
+  }
+  return CHECK_LAUNCH();
+}
+
+// =====================================================================================================
+// glue: HD 2x2 merge + sub_GN (models/llava_next_video.py:454-489), Llama 3x3 pool (:509-517),
+// temporal 4x4 pool (:543-549)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void hd_merge_kernel(const float* __restrict__ f, const float* __restrict__ sub_gn, bf16_t* __restrict__ out, int n, int C) {
+  const int c4 = 4 * C, cv = c4 / 4;
+  const long total = (long)n * 156 * cv;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv) * 4;
+    const long row = idx / cv;
+    const int r = (int)(row % 156), img = (int)(row / 156);
+    const int hh = r / 13, ww = r - hh * 13;
+    f32x4_t v;
+    if (ww == 12) v = *(const f32x4_t*)(sub_gn + c);
+    else {
+      const int chunk = c / C, cc = c - chunk * C, dy = chunk >> 1, dx = chunk & 1;
+      v = *(const f32x4_t*)(f + ((size_t)img * 576 + (2 * hh + dy) * 24 + 2 * ww + dx) * C + cc);
+    }
+    u32x2_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *(u32x2_t*)(out + row * c4 + c) = o;
+  }
+}
+int gvl_launch_hd_merge(const float* f, const float* sub_gn, bf16_t* out, int n, int C, hipStream_t st) {
+  if (C % 4) return -1;
+  const long total = (long)n * 156 * C;
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(hd_merge_kernel, dim3(blocks), dim3(256), 0, st, f, sub_gn, out, n, C);
+  return CHECK_LAUNCH();
+}
+
+__global__ __launch_bounds__(256) void pool_spatial_kernel(const float* __restrict__ f, bf16_t* __restrict__ out, int n, int C) {
+  const int cv = C / 4;
+  const long total = (long)n * 64 * cv;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv) * 4;
+    const long row = idx / cv;
+    const int r = (int)(row % 64), img = (int)(row / 64);
+    const int ph = r >> 3, pw = r & 7;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int dy = 0; dy < 3; ++dy)
+      for (int dx = 0; dx < 3; ++dx) acc += *(const f32x4_t*)(f + ((size_t)img * 576 + (3 * ph + dy) * 24 + 3 * pw + dx) * C + c);
+    u32x2_t o = {pack2bf(acc[0] / 9.f, acc[1] / 9.f), pack2bf(acc[2] / 9.f, acc[3] / 9.f)};
+    *(u32x2_t*)(out + row * C + c) = o;
+  }
+}
+int gvl_launch_pool_spatial(const float* f, bf16_t* out, int n, int C, hipStream_t st) {
+  if (C % 4) return -1;
+  const long total = (long)n * 64 * (C / 4);
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pool_spatial_kernel, dim3(blocks), dim3(256), 0, st, f, out, n, C);
+  return CHECK_LAUNCH();
+}
+
+__global__ __launch_bounds__(256) void pool_temporal_kernel(const bf16_t* __restrict__ f, bf16_t* __restrict__ out, int n, int T, int C) {
+  const int cv = C / 8;
+  const long total = (long)n * T * 16 * cv;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv) * 8;
+    const long row = idx / cv;
+    const int r = (int)(row % 16), t = (int)((row / 16) % T), seg = (int)(row / (16L * T));
+    const int ph = r >> 2, pw = r & 3;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int dy = 0; dy < 4; ++dy)
+      for (int dx = 0; dx < 4; ++dx) {
+        const u32x4_t v = *(const u32x4_t*)(f + ((size_t)seg * T * 256 + t * 256 + (4 * ph + dy) * 16 + 4 * pw + dx) * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += lo_bf(v[e]); acc[2 * e + 1] += hi_bf(v[e]); }
+      }
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2bf(acc[2 * e] * 0.0625f, acc[2 * e + 1] * 0.0625f);
+    *(u32x4_t*)(out + row * C + c) = o;
+  }
+}
+int gvl_launch_pool_temporal(const bf16_t* f, bf16_t* out, int n, int T, int C, hipStream_t st) {
+  if (C % 8) return -1;
+  const long total = (long)n * T * 16 * (C / 8);
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pool_temporal_kernel, dim3(blocks), dim3(256), 0, st, f, out, n, T, C);
+  return CHECK_LAUNCH();
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
+}
+int gvl_launch_f32_to_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t st) {
+  int blocks = (int)((n + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, st, x, y, (long)n);
+  return CHECK_LAUNCH();
+}
+
+__global__ void bcast_row_kernel(const bf16_t* __restrict__ row, bf16_t* __restrict__ dst, int n, int stride_rows, int row_off, int cols) {
+  const long total = (long)n * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cols), s = (int)(i / cols);
+    dst[((size_t)s * stride_rows + row_off) * cols + c] = row[c];
+  }
+}
+int gvl_launch_bcast_row(const bf16_t* row, bf16_t* dst, int n, int stride_rows, int row_off, int cols, hipStream_t st) {
+  const long total = (long)n * cols;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(bcast_row_kernel, dim3(blocks), dim3(256), 0, st, row, dst, n, stride_rows, row_off, cols);
+  return CHECK_LAUNCH();
+}
+
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ table, const int* __restrict__ ids, bf16_t* __restrict__ dst, int n, int cols) {
+  const int cv = cols / 8;
+  const long total = (long)n * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * 8, r = (int)(i / cv);
+    *(u32x4_t*)(dst + (size_t)r * cols + c) = *(const u32x4_t*)(table + (size_t)ids[r] * cols + c);
+  }
+}
+int gvl_launch_gather_rows(const bf16_t* table, const int* ids, bf16_t* dst, int n, int cols, hipStream_t st) {
+  if (cols % 8) return -1;
+  if (n <= 0) return 0;
+  const long total = (long)n * (cols / 8);
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, st, table, ids, dst, n, cols);
+  return CHECK_LAUNCH();
+}
+
+// y[n][s][:] = x[n][s+1][:]   (drop the CLS row: hidden_states[-2][:, 1:], x_vis[:, 1:, :])
+__global__ void strip_cls_kernel(const uint32_t* __restrict__ x, uint32_t* __restrict__ y, int n, int S, int Cw) {
+  const long total = (long)n * (S - 1) * Cw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cw);
+    const long row = i / Cw;
+    const int s = (int)(row % (S - 1)), b = (int)(row / (S - 1));
+    y[i] = x[((size_t)b * S + s + 1) * Cw + c];
+  }
+}
+int gvl_launch_strip_cls(const void* x, void* y, int n, int S, int C, int elem_bytes, hipStream_t st) {
+  if ((C * elem_bytes) % 4) return -1;
+  const int Cw = C * elem_bytes / 4;
+  const long total = (long)n * (S - 1) * Cw;
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(strip_cls_kernel, dim3(blocks), dim3(256), 0, st, (const uint32_t*)x, (uint32_t*)y, n, S, Cw);
+  return CHECK_LAUNCH();
+}
+
+// =====================================================================================================
+// decode GEMV: y[N] = W[N,K] x[K]; HBM-bound weight stream (SURVEY.md K16/K20/K21 at q_len = 1).
+// Weights go straight to VGPRs with 16-byte loads (no LDS round trip: each byte is used once), R rows per
+// wave in flight; x (optionally RMS-normalised on the fly) lives in LDS as bf16.
+// =====================================================================================================
+template <int R>
+__global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* xs = (bf16_t*)smem;
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K8 = a.K >> 3;
+  if (a.norm_w) {
+    float s = 0.f;
+    for (int c = tid; c < K8; c += 256) {
+      const u32x4_t v = *(const u32x4_t*)(a.x + c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float p = lo_bf(v[e]), q = hi_bf(v[e]); s += p * p + q * q; }
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / a.K + a.eps);
+    for (int c = tid; c < K8; c += 256) {
+      const u32x4_t v = *(const u32x4_t*)(a.x + c * 8);
+      const u32x4_t w = *(const u32x4_t*)(a.norm_w + c * 8);
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack2bf(lo_bf(w[e]) * rbf(lo_bf(v[e]) * rs), hi_bf(w[e]) * rbf(hi_bf(v[e]) * rs));
+      *(u32x4_t*)(xs + c * 8) = o;
+    }
+  } else {
+    for (int c = tid; c < K8; c += 256) *(u32x4_t*)(xs + c * 8) = *(const u32x4_t*)(a.x + c * 8);
+  }
+  __syncthreads();
+
+  const int n0 = (blockIdx.x * 4 + wave) * R;
+  if (n0 >= a.N) return;
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  const bf16_t* wp[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { int n = n0 + r; if (n > a.N - 1) n = a.N - 1; wp[r] = a.W + (size_t)n * a.K; }
+#pragma unroll 2
+  for (int c = lane; c < K8; c += 64) {
+    u32x4_t wv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wv[r] = __builtin_nontemporal_load((const u32x4_t*)(wp[r] + c * 8));
+    const u32x4_t xv = *(const u32x4_t*)(xs + c * 8);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[r] += lo_bf(wv[r][e]) * lo_bf(xv[e]) + hi_bf(wv[r][e]) * hi_bf(xv[e]);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+  if (lane == 0) {
+    if (a.act == GVL_ACT_SILU_MUL) {
+      if constexpr (R >= 2) {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+          const int n = n0 + r;
+          if (n + 1 < a.N) {
+            const float g = rbf(acc[r]), u = rbf(acc[r + 1]);
+            const float o = u * rbf(g / (1.f + __expf(-g)));
+            if (a.out_bf16) a.out_bf16[n >> 1] = f2bf(o);
+            if (a.out_f32) a.out_f32[n >> 1] = o;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int n = n0 + r;
+        if (n < a.N) {
+          float v = acc[r];
+          if (a.bias) v += a.bias[n];
+          if (a.resid) v = bf2f(a.resid[n]) + rbf(v);
+          if (a.out_bf16) a.out_bf16[n] = f2bf(v);
+          if (a.out_f32) a.out_f32[n] = v;
+        }
+      }
+    }
+  }
+}
+
+int gvl_launch_gemv(const GemvArgs& a, hipStream_t st) {
+  if (a.K % 8 || a.K > 32768) return -1;
+  const size_t lds = (size_t)a.K * 2;
+  int R = 4;
+  while (R > 1 && (a.N + 4 * R - 1) / (4 * R) < 512) R >>= 1;
+  if (a.act == GVL_ACT_SILU_MUL && R < 2) R = 2;
+  const int blocks = (a.N + 4 * R - 1) / (4 * R);
+  switch (R) {
+    case 4: hipLaunchKernelGGL(gemv_kernel<4>, dim3(blocks), dim3(256), lds, st, a); break;
+    case 2: hipLaunchKernelGGL(gemv_kernel<2>, dim3(blocks), dim3(256), lds, st, a); break;
+    default: hipLaunchKernelGGL(gemv_kernel<1>, dim3(blocks), dim3(256), lds, st, a); break;
+  }
+  return CHECK_LAUNCH();
+}
+
+// greedy sampling: first index of the maximum (torch.argmax tie rule) -> *out_tok and out_list[*step_ptr]
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int n, int* out_tok, int* out_list, const int* step_ptr) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  float best = -3.4e38f; int idx = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float v = logits[i];
+    if (v > best) { best = v; idx = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    *out_tok = idx;
+    if (out_list) out_list[step_ptr ? *step_ptr : 0] = idx;
+  }
+}
+int gvl_launch_argmax(const float* logits, int n, int* out_tok, int* out_list, const int* step_ptr, hipStream_t st) {
+  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, logits, n, out_tok, out_list, step_ptr);
+  return CHECK_LAUNCH();
+}
+__global__ void inc_kernel(int* p) { if (threadIdx.x == 0) (*p)++; }
+int gvl_launch_inc(int* p, hipStream_t st) {
+  hipLaunchKernelGGL(inc_kernel, dim3(1), dim3(64), 0, st, p);
+  return CHECK_LAUNCH();
+}
+__global__ void set_int_kernel(int* p, int v) { if (threadIdx.x == 0) *p = v; }
+int gvl_launch_set_int(int* p, int v, hipStream_t st) {
+  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, st, p, v);
+  return CHECK_LAUNCH();
+}

@@ -1,0 +1,223 @@
+// gvl_gemm.hip -- bf16 MFMA GEMM for gfx950 (MI355X):  C[M,N] = epilogue(A[M,K] . W[N,K]^T)
+//
+// Replaces every nn.Linear / patch-conv on the hot path (SURVEY.md §2.3 K1,K2,K4,K6,K7,K10,K13,K16,K20):
+// models/modeling_clip.py:185,264-266,326,340-342; models/internvideo2.py:587,603,631-634,722;
+// models/llava_next_video.py:36-38,51-53; models/modeling_phi3.py:459-464,659-663,770.
+//
+// Design (CDNA4-first, not a port of any CUDA tiling):
+//   * v_mfma_f32_32x32x16_bf16, operands swapped: the MFMA "A" rows are WEIGHT rows (n) and the
+//     "B" columns are activation rows (m), so each lane ends up owning 4 CONSECUTIVE output
+//     columns of one output row -> 8/16-byte epilogue stores into row-major C.
+//   * both operand tiles are K-contiguous 128-byte rows, staged global->LDS with
+//     global_load_lds (16 B/lane, no VGPR round trip), double buffered, ONE barrier per K tile.
+//   * LDS image is lane-linear (DMA constraint); the bank-conflict-free layout is obtained by
+//     permuting the 16-byte chunks on the SOURCE address and applying the same XOR on the
+//     ds_read_b128 side: phys_chunk = chunk ^ ((row >> 1) & 7)  (conflict-free for the
+//     ds_read_b128 lane groups of MI355X_MICROARCH.md §LDS).
+//   * XCD-aware block order: each of the 8 XCDs gets a contiguous range of tiles so that the
+//     A row-panel of a tile row stays in that XCD's private L2.
+#include "gvl_internal.h"
+
+#define BK 64  // K tile (bf16 elements) == one 128-byte LDS row
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+  constexpr int NWAVES = WAVES_M * WAVES_N;
+  constexpr int NT = NWAVES * 64;
+  constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;  // wave tile
+  constexpr int MB = TM / 32, NB = TN / 32;            // 32x32 blocks per wave
+  constexpr int ROWS = BM + BN;
+  constexpr int NI = ROWS * 8 / NT;                    // global_load_lds instructions / thread / stage
+  constexpr int STAGE_BYTES = ROWS * 128;
+  static_assert(ROWS * 8 % NT == 0, "tile/threads mismatch");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // ---- XCD-aware tile id (bijective for any grid size) ------------------------------------------
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tm = vid / tiles_n, tn = vid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- per-thread DMA source pointers (k0 excluded) -------------------------------------------
+  const bf16_t* src[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = i * NWAVES + wave;           // 1-KiB chunk = 8 tile rows
+    const int row = c * 8 + (lane >> 3);       // row in the combined [W ; A] tile
+    const int pc = lane & 7;
+    if (c * 8 < BN) {
+      const int lc = pc ^ ((row >> 1) & 7);
+      int gr = n0 + row; gr = gr < a.N ? gr : a.N - 1;
+      src[i] = a.W + (size_t)gr * a.K + lc * 8;
+    } else {
+      const int ra = row - BN;
+      const int lc = pc ^ ((ra >> 1) & 7);
+      int gr = m0 + ra; gr = gr < a.M ? gr : a.M - 1;
+      src[i] = a.A + (size_t)gr * a.lda + lc * 8;
+    }
+  }
+
+  auto stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = i * NWAVES + wave;
+      char* dst = smem + buf * STAGE_BYTES + c * 1024;  // wave-uniform; the DMA adds lane*16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  f32x16_t acc[NB][MB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment read offsets: row (lane&31) of a 32-row block, logical chunk kk*2 + (lane>>5)
+  const int l31 = lane & 31, h = lane >> 5;
+  const int swz = (l31 >> 1) & 7;
+  const int w_row_off = (wn * TN + l31) * 128;
+  const int a_row_off = BN * 128 + (wm * TM + l31) * 128;
+
+  const int nk = a.K / BK;
+  stage(0, 0);
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's DMA pieces of tile t have landed
+    __syncthreads();  // ... and everybody's; all waves are also done reading buf (t+1)&1
+    if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
+    const char* sb = smem + (t & 1) * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int coff = ((kk * 2 + h) ^ swz) << 4;
+      bf16x8_t wf[NB], af[MB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane owns row m = ..+(lane&31), columns n = ..+8*b+4*h+{0..3} --------------------
+#pragma unroll
+  for (int j = 0; j < MB; ++j) {
+    const int m = m0 + wm * TM + j * 32 + l31;
+    if (m >= a.M) continue;
+    const size_t orow = a.grp_rows ? (size_t)(m / a.grp_rows) * a.grp_stride + (m % a.grp_rows) + a.row_off : (size_t)m + a.row_off;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int n = n0 + wn * TN + i * 32 + 8 * b + 4 * h;
+        if (n >= a.N) continue;
+        float v[4] = {acc[i][j][4 * b + 0], acc[i][j][4 * b + 1], acc[i][j][4 * b + 2], acc[i][j][4 * b + 3]};
+        if (a.bias) {
+          const f32x4_t bv = *(const f32x4_t*)(a.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        }
+        if (a.act == GVL_ACT_SILU_MUL) {
+          // interleaved (gate, up) pairs -> 2 outputs at column n/2.  reference: up * silu(gate), each op in bf16
+          float o2[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float g = rbf(v[2 * e]), u = rbf(v[2 * e + 1]);
+            const float sg = rbf(g / (1.f + __expf(-g)));
+            o2[e] = u * sg;
+          }
+          bf16_t* cp = (bf16_t*)a.C + orow * a.ldc + (n >> 1);
+          *(unsigned*)cp = pack2bf(o2[0], o2[1]);
+          continue;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = v[e];
+          if (a.act == GVL_ACT_QUICK_GELU) {
+            x = rbf(x);
+            const float s = rbf(1.f / (1.f + __expf(-rbf(1.702f * x))));
+            x = x * s;
+          } else if (a.act == GVL_ACT_GELU) {
+            x = rbf(x);
+            x = 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+          }
+          v[e] = x;
+        }
+        if (a.gamma) {
+          const f32x4_t gv = *(const f32x4_t*)(a.gamma + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) * gv[e];
+        }
+        if (a.out_f32) {
+          float* cp = (float*)a.C + orow * a.ldc + n;
+          if (a.resid) {
+            const f32x4_t rv = *(const f32x4_t*)((const float*)a.resid + orow * a.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rv[e] + (a.round_pre_resid ? rbf(v[e]) : v[e]);
+          }
+          f32x4_t o = {v[0], v[1], v[2], v[3]};
+          *(f32x4_t*)cp = o;
+        } else {
+          bf16_t* cp = (bf16_t*)a.C + orow * a.ldc + n;
+          if (a.resid) {
+            const u32x2_t rv = *(const u32x2_t*)((const bf16_t*)a.resid + orow * a.ldr + n);
+            const float r0 = lo_bf(rv[0]), r1 = hi_bf(rv[0]), r2 = lo_bf(rv[1]), r3 = hi_bf(rv[1]);
+            v[0] = r0 + rbf(v[0]); v[1] = r1 + rbf(v[1]); v[2] = r2 + rbf(v[2]); v[3] = r3 + rbf(v[3]);
+          }
+          u32x2_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(u32x2_t*)cp = o;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_cfg(const GemmArgs& a, hipStream_t st) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+    attr_set = true;
+  }
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT), LDS, st, a, tiles_m, tiles_n);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+double gvl_gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K; }
+
+int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return -1;
+  if (a.K % BK != 0 || a.N % 4 != 0 || a.lda % 8 != 0) return -1;   // K padded to 64 by the packer; 16-byte rows
+  if (a.act == GVL_ACT_SILU_MUL && (a.out_f32 || a.resid || a.gamma)) return -1;
+  int cfg = a.tile_cfg;
+  if (cfg == 0) {
+    // 256x256 where it divides cleanly and there is enough work to fill 256 CUs; else 256x128; small -> 128x128
+    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const long t2561 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+    if (t256 >= 200 && a.N % 256 == 0) cfg = 2;
+    else if (t2561 >= 200) cfg = 3;
+    else cfg = 1;
+  }
+  switch (cfg) {
+    case 1: return launch_cfg<128, 128, 2, 2>(a, st);
+    case 2: return launch_cfg<256, 256, 4, 2>(a, st);
+    case 3: return launch_cfg<256, 128, 4, 2>(a, st);
+    default: return -1;
+  }
+}

@@ -1,0 +1,141 @@
+// gvl_internal.h -- shared declarations for the libgvl.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define GVL_KV_PAGE 64          // tokens per KV page == key tile of the attention kernels
+
+// ---- device helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even (inputs are finite)
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }  // round through bf16
+__device__ __forceinline__ float lo_bf(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi_bf(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- GEMM ---------------------------------------------------------------------------------------
+enum { GVL_ACT_NONE = 0, GVL_ACT_QUICK_GELU = 1, GVL_ACT_GELU = 2, GVL_ACT_SILU_MUL = 3 };
+
+struct GemmArgs {
+  const bf16_t* A;  int lda;     // [M,K] bf16
+  const bf16_t* W;               // [N,K] bf16 (nn.Linear layout), ld = K
+  void* C;          int ldc;     // [M,N'] f32 or bf16
+  int M, N, K;
+  const float* bias;             // [N] or null
+  const float* gamma;            // [N] LayerScale (after bf16 rounding of acc+bias) or null
+  const void* resid; int ldr;    // residual stream, same dtype as C, or null (may alias C)
+  int act;                       // GVL_ACT_*
+  int out_f32;                   // 1: C/resid f32, 0: bf16
+  int round_pre_resid;           // 1: round (acc+bias) [and the gamma product] to bf16 before adding resid
+  // output row remap: row m -> (m / grp_rows) * grp_stride + (m % grp_rows) + row_off   (grp_rows==0: identity)
+  int grp_rows, grp_stride, row_off;
+  int tile_cfg;                  // 0 auto, 1 = 128x128, 2 = 256x256, 3 = 256(M)x128(N)
+};
+int gvl_launch_gemm(const GemmArgs& a, hipStream_t st);
+double gvl_gemm_flops(const GemmArgs& a);
+
+// ---- attention (prefill / vision) -----------------------------------------------------------------
+struct AttnArgs {
+  const bf16_t* Q;      // [B][H][S][D] bf16 (D = padded head dim: 64, 96 or 128)
+  const bf16_t* Kt;     // key pages  [page][KV][64][D]
+  const bf16_t* Vt;     // value pages [page][KV][D][64]  (transposed inside the page)
+  bf16_t* O;            // [B][S][H*Dout]
+  const int* block_table;  // [B][max_pages] page ids, or null: page(b,t) = b*n_tiles + t
+  int max_pages;
+  int B, H, KV, S, D, Dout;   // S = number of queries == number of keys (self attention), q_pos0 = 0
+  float scale;
+  int causal;
+};
+int gvl_launch_attention(const AttnArgs& a, hipStream_t st);
+double gvl_attn_flops(const AttnArgs& a);
+
+// ---- decode attention -----------------------------------------------------------------------------
+struct DecodeAttnArgs {
+  const bf16_t* q;        // [H][D]
+  const bf16_t* Kt; const bf16_t* Vt;   // page pools (one layer)
+  const int* block_table; // [max_pages]
+  const int* pos_ptr;     // device: index of the new token (the cache holds *pos_ptr + 1 tokens, new one included)
+  float* part;            // workspace [H][nsplit][D+2]
+  bf16_t* out;            // [H*Dout]
+  int H, KV, D, Dout, nsplit;
+  float scale;
+};
+int gvl_launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st);
+
+// ---- elementwise / norm / glue kernels (gvl_elem.hip) ----------------------------------------------
+int gvl_launch_layernorm_f32(const float* x, const float* w, const float* b, bf16_t* y, int rows, int cols, float eps, hipStream_t st);
+int gvl_launch_rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, float eps, hipStream_t st);
+// im2col for a stride==kernel patch conv.  px f32 [n_img][3][T][HW][HW] (T==1 for CLIP) -> A bf16 [n_img*T*g*g][Kp]
+int gvl_launch_patchify(const float* px, bf16_t* A, int n_img, int T, int image, int patch, int Kp, hipStream_t st);
+// CLIP embeddings + pre-LN: x[n,0]=cls+pos0, x[n,1+p]=bf16r(patch)+pos -> LN -> f32 [n,1+P,C]
+int gvl_launch_clip_embed_ln(const bf16_t* patch, const float* cls, const float* pos, const float* lnw, const float* lnb,
+                             float* x, int n_img, int P, int C, float eps, hipStream_t st);
+// IV2 embeddings: x[b,0]=bf16(cls+pos0), x[b,1+j]=bf16(patch+pos) (all bf16) -> bf16 [B,1+TL,C]
+int gvl_launch_iv2_embed(const bf16_t* patch, const bf16_t* cls, const bf16_t* pos, bf16_t* x, int B, int TL, int C, hipStream_t st);
+// split a fused qkv row into attention operands.
+//  mode 0 (CLIP): plain.  mode 1 (IV2): RMS-normalise q and k over the full width with weights qn/kn.
+//  mode 2 (LLM): RoPE with cos/sin tables at positions pos0+s.
+struct QkvPostArgs {
+  const bf16_t* qkv; int ld;       // [B*S][(H+2KV)*Dr]
+  bf16_t* Q; bf16_t* Kt; bf16_t* Vt;
+  const int* block_table; int max_pages;   // null: page(b,t) = b*n_tiles + t
+  int B, S, H, KV, Dr, D;          // Dr = real head dim, D = padded
+  int mode;
+  const bf16_t* qn; const bf16_t* kn; float eps;     // mode 1
+  const float* cos; const float* sin; int pos0;      // mode 2: tables [max_seq][Dr/2] (already bf16-rounded values)
+  const int* pos_ptr;              // mode 2 decode: device position of the (single) row, overrides pos0 when non-null
+  const float* cos_l; const float* sin_l; int rope_switch;   // decode: long-factor tables used when pos+1 > rope_switch (>0)
+};
+int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st);
+// HD 2x2 merge + sub_GN newline (Phi): f32 [n,576,C] -> bf16 [n,156,4C]
+int gvl_launch_hd_merge(const float* f, const float* sub_gn, bf16_t* out, int n, int C, hipStream_t st);
+// 3x3 block mean (Llama): f32 [n,576,C] -> bf16 [n,64,C]
+int gvl_launch_pool_spatial(const float* f, bf16_t* out, int n, int C, hipStream_t st);
+// temporal 4x4 block mean: bf16 [n,T*256,C] -> bf16 [n,T*16,C]
+int gvl_launch_pool_temporal(const bf16_t* f, bf16_t* out, int n, int T, int C, hipStream_t st);
+int gvl_launch_f32_to_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t st);
+// broadcast one row to rows row_off + s*stride, s in [0,n)
+int gvl_launch_bcast_row(const bf16_t* row, bf16_t* dst, int n, int stride_rows, int row_off, int cols, hipStream_t st);
+// embedding gather: ids (device int32) -> rows of dst
+int gvl_launch_gather_rows(const bf16_t* table, const int* ids, bf16_t* dst, int n, int cols, hipStream_t st);
+int gvl_launch_strip_cls(const void* x, void* y, int n, int S, int C, int elem_bytes, hipStream_t st);
+// decode-side
+struct GemvArgs {
+  const bf16_t* W; int N, K;      // [N][K]
+  const bf16_t* x;                // [K] bf16
+  const bf16_t* norm_w; float eps;  // non-null: x <- rmsnorm(x)*norm_w (bf16 roundings as the reference)
+  const float* bias;              // [N] or null
+  const bf16_t* resid;            // [N'] or null: out = bf16(resid + bf16(y))
+  int act;                        // GVL_ACT_NONE or GVL_ACT_SILU_MUL (interleaved gate/up rows, N' = N/2)
+  bf16_t* out_bf16;               // [N'] or null
+  float* out_f32;                 // [N'] or null
+};
+int gvl_launch_gemv(const GemvArgs& a, hipStream_t st);
+int gvl_launch_argmax(const float* logits, int n, int* out_tok, int* out_list, const int* step_ptr, hipStream_t st);
+int gvl_launch_inc(int* p, hipStream_t st);
+int gvl_launch_set_int(int* p, int v, hipStream_t st);

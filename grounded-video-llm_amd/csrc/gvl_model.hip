@@ -1,0 +1,739 @@
+// gvl_model.hip -- host side of libgvl.so: context, packed weights, workspace arena, paged KV pool,
+// the three towers' launch sequences, prefill / greedy decode loop, and the C ABI of include/gvl.h.
+//
+// Launch sequences restate (file:line in the reference):
+//   CLIP tower      models/modeling_clip.py:182-191,355-393,626-651,851   (23 of 24 layers, hidden_states[-2])
+//   InternVideo2    models/internvideo2.py:680-684,721-725,970-1040      (39 of 40 blocks)
+//   glue/projectors models/llava_next_video.py:454-489,507-564
+//   splice          models/llava_next_video.py:568-596
+//   LLM             models/modeling_phi3.py:1034-1095,1249-1383,1512-1526 / models/modeling_llama.py:699-760
+//   generate()      models/llava_next_video.py:655-661 (greedy; transformers GenerationMixin [ext])
+#include "gvl_internal.h"
+#include "../../include/gvl.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+std::string g_create_err;
+
+struct Tensor { void* p = nullptr; int dtype = 0; int64_t numel = 0; std::vector<int64_t> shape; };
+
+struct ClipLayerW { const float *ln1w, *ln1b, *ln2w, *ln2b, *qkvb, *outb, *fc1b, *fc2b; const bf16_t *qkvw, *outw, *fc1w, *fc2w; };
+struct Iv2BlockW { const bf16_t *n1, *n2, *qkvw, *qn, *kn, *projw, *fc1w, *fc2w; const float *projb, *ls1, *ls2, *fc1b, *fc2b; };
+struct LlmLayerW { const bf16_t *ln1, *ln2, *qkvw, *ow, *guw, *downw; };
+
+struct Seq {
+  bool used = false; int max_tokens = 0, n_pages = 0; std::vector<int> pages;
+  int* d_block_table = nullptr; int* d_pos = nullptr; int pos = 0; int n_gen = 0;
+};
+
+struct ProfRec { int cat; hipEvent_t e0, e1; double work; };
+
+}  // namespace
+
+struct gvl_ctx {
+  gvl_config cfg;
+  std::string err;
+  std::unordered_map<std::string, Tensor> w;
+  bool finalized = false;
+  // derived geometry
+  int c_P = 0, c_S = 0, c_Kp = 0, c_Dr = 0, c_D = 0;
+  int v_L = 0, v_TL = 0, v_S = 0, v_Kp = 0, v_Dr = 0, v_D = 0;
+  int l_Dr = 0, l_D = 0, tok_per_seg = 0, img_tok = 0, seg_tok = 0;
+  bool has_clip = false, has_iv2 = false, has_llm = false, has_proj = false;
+  // resolved weights
+  const bf16_t* c_patchw = nullptr; const float *c_cls = nullptr, *c_pos = nullptr, *c_prelnw = nullptr, *c_prelnb = nullptr;
+  std::vector<ClipLayerW> cl;
+  const bf16_t *v_patchw = nullptr, *v_cls = nullptr, *v_pos = nullptr; const float* v_patchb = nullptr;
+  std::vector<Iv2BlockW> vb;
+  const bf16_t *mm0w = nullptr, *mm1w = nullptr, *vp0w = nullptr, *vp1w = nullptr, *glb_gn = nullptr, *newline = nullptr;
+  const float *mm0b = nullptr, *mm1b = nullptr, *vp0b = nullptr, *vp1b = nullptr, *sub_gn = nullptr;
+  const bf16_t *l_embed = nullptr, *l_norm = nullptr, *l_headw = nullptr; const float* l_headb = nullptr;
+  const float *cos_s = nullptr, *sin_s = nullptr, *cos_l = nullptr, *sin_l = nullptr;
+  std::vector<LlmLayerW> ll;
+  // arena
+  char* arena = nullptr; size_t arena_bytes = 0, arena_off = 0;
+  // KV pool
+  bf16_t *kpool = nullptr, *vpool = nullptr; size_t layer_stride = 0; std::vector<int> free_pages;
+  std::vector<Seq> seqs;
+  // decode buffers
+  bf16_t *d_x = nullptr, *d_qkv = nullptr, *d_q = nullptr, *d_attn = nullptr, *d_act = nullptr;
+  float *d_logits = nullptr, *d_part = nullptr; int *d_tok = nullptr, *d_step = nullptr, *d_outlist = nullptr, *d_ids = nullptr;
+  int nsplit = 16, outlist_cap = 8192, ids_cap = 16384;
+  // profiling
+  bool prof = false; std::vector<ProfRec> recs;
+  double prof_ms[GVL_PROF_NCAT] = {0}, prof_work[GVL_PROF_NCAT] = {0}; int64_t prof_n[GVL_PROF_NCAT] = {0};
+};
+
+namespace {
+
+int fail(gvl_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg; else g_create_err = msg;
+  return code;
+}
+int hipfail(gvl_ctx* c, hipError_t e, const char* what) {
+  return fail(c, GVL_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(c, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return hipfail(c, _e, #expr); } while (0)
+
+int pad_head(int dr) { return dr <= 64 ? 64 : (dr <= 96 ? 96 : (dr <= 128 ? 128 : -1)); }
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct ProfScope {
+  gvl_ctx* c; hipStream_t st; int idx = -1;
+  ProfScope(gvl_ctx* c_, int cat, double work, hipStream_t st_) : c(c_), st(st_) {
+    if (!c->prof) return;
+    ProfRec r; r.cat = cat; r.work = work;
+    hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, st);
+    c->recs.push_back(r); idx = (int)c->recs.size() - 1;
+  }
+  ~ProfScope() { if (idx >= 0) hipEventRecord(c->recs[idx].e1, st); }
+};
+#define RUN(cat, work, expr) do { ProfScope _ps(ctx, cat, work, st); int _rc = (expr); if (_rc) return fail(ctx, _rc == -1 ? GVL_ERR_ARG : GVL_ERR_HIP, std::string("launch failed: ") + #expr); } while (0)
+
+void* arena_alloc(gvl_ctx* c, size_t bytes) {
+  const size_t off = al256(c->arena_off);
+  if (off + bytes > c->arena_bytes) return nullptr;
+  c->arena_off = off + bytes;
+  return c->arena + off;
+}
+#define AALLOC(var, type, count) type* var = (type*)arena_alloc(ctx, (size_t)(count) * sizeof(type)); if (!var) return fail(ctx, GVL_ERR_OOM, "workspace arena too small for " #var)
+
+const Tensor* find(gvl_ctx* c, const std::string& n) { auto it = c->w.find(n); return it == c->w.end() ? nullptr : &it->second; }
+
+template <typename T>
+int need(gvl_ctx* c, const std::string& name, int dtype, int64_t numel, const T** out, bool optional = false) {
+  const Tensor* t = find(c, name);
+  if (!t) { if (optional) { *out = nullptr; return 0; } return fail(c, GVL_ERR_STATE, "missing weight: " + name); }
+  if (t->dtype != dtype) return fail(c, GVL_ERR_ARG, "wrong dtype for weight: " + name);
+  if (t->numel != numel) return fail(c, GVL_ERR_ARG, "wrong size for weight: " + name + " (have " + std::to_string(t->numel) + ", want " + std::to_string(numel) + ")");
+  *out = (const T*)t->p;
+  return 0;
+}
+#define NEED(name, dt, n, outp) do { int _r = need(ctx, name, dt, (int64_t)(n), outp); if (_r) return _r; } while (0)
+
+GemmArgs gemm(const bf16_t* A, int lda, const bf16_t* W, void* C, int ldc, int M, int N, int K) {
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.A = A; g.lda = lda; g.W = W; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  return g;
+}
+
+// ---------------------------------------------------------------------------------------------------
+size_t clip_bytes(const gvl_ctx* c, int n) {
+  const gvl_config& f = c->cfg; const size_t M = (size_t)n * c->c_S, C = f.clip_hidden;
+  const size_t tiles = (c->c_S + 63) / 64;
+  size_t b = 0;
+  b += al256(M * C * 4) + al256(M * C * 2) + al256(M * 3 * C * 2) + al256(M * C * 2) + al256(M * f.clip_inter * 2);
+  b += al256((size_t)n * c->c_P * c->c_Kp * 2) + al256((size_t)n * c->c_P * C * 2);
+  b += al256((size_t)n * f.clip_heads * c->c_S * c->c_D * 2) + 2 * al256((size_t)n * tiles * f.clip_heads * 64 * c->c_D * 2);
+  return b + 4096;
+}
+size_t iv2_bytes(const gvl_ctx* c, int n) {
+  const gvl_config& f = c->cfg; const size_t M = (size_t)n * c->v_S, C = f.iv2_dim;
+  const size_t tiles = (c->v_S + 63) / 64;
+  size_t b = 0;
+  b += 2 * al256(M * C * 2) + al256(M * 3 * C * 2) + al256(M * C * 2) + al256(M * f.iv2_inter * 2);
+  b += al256((size_t)n * c->v_TL * c->v_Kp * 2) + al256((size_t)n * c->v_TL * C * 2);
+  b += al256((size_t)n * f.iv2_heads * c->v_S * c->v_D * 2) + 2 * al256((size_t)n * tiles * f.iv2_heads * 64 * c->v_D * 2);
+  return b + 4096;
+}
+size_t visual_bytes(const gvl_ctx* c, int n) {
+  const gvl_config& f = c->cfg;
+  const size_t cin = f.llm_kind == GVL_LLM_PHI3 ? 4 * (size_t)f.clip_hidden : (size_t)f.clip_hidden;
+  size_t b = 0;
+  b += al256((size_t)n * c->img_tok * cin * 2) + al256((size_t)n * c->img_tok * f.hidden * 2);
+  b += al256((size_t)n * c->seg_tok * f.iv2_dim * 2) + al256((size_t)n * c->seg_tok * f.hidden * 2);
+  b += 4 * al256((size_t)f.hidden * 2 + cin * 2);
+  return b + 4096;
+}
+size_t prefill_bytes(const gvl_ctx* c, int S) {
+  const gvl_config& f = c->cfg;
+  const size_t qkvw = (size_t)(f.heads + 2 * f.kv_heads) * c->l_Dr;
+  size_t b = 0;
+  b += 2 * al256((size_t)S * f.hidden * 2) + al256((size_t)S * qkvw * 2) + al256((size_t)S * f.heads * c->l_Dr * 2);
+  b += al256((size_t)S * f.inter * 2) + al256((size_t)f.heads * S * c->l_D * 2);
+  return b + 4096;
+}
+size_t feats_bytes(const gvl_ctx* c, int n) {
+  return al256((size_t)n * c->c_P * c->cfg.clip_hidden * 4) + al256((size_t)n * c->v_TL * c->cfg.iv2_dim * 2) + 1024;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int clip_encode(gvl_ctx* ctx, const float* px, int n, float* out, hipStream_t st) {
+  const gvl_config& f = ctx->cfg;
+  const int C = f.clip_hidden, H = f.clip_heads, S = ctx->c_S, P = ctx->c_P, M = n * S, I = f.clip_inter, D = ctx->c_D, Dr = ctx->c_Dr;
+  const int tiles = (S + 63) / 64;
+  const size_t mark = ctx->arena_off;
+  AALLOC(x, float, (size_t)M * C); AALLOC(h, bf16_t, (size_t)M * C); AALLOC(qkv, bf16_t, (size_t)M * 3 * C);
+  AALLOC(att, bf16_t, (size_t)M * C); AALLOC(mlp, bf16_t, (size_t)M * I);
+  AALLOC(pA, bf16_t, (size_t)n * P * ctx->c_Kp); AALLOC(pO, bf16_t, (size_t)n * P * C);
+  AALLOC(Q, bf16_t, (size_t)n * H * S * D); AALLOC(Kt, bf16_t, (size_t)n * tiles * H * 64 * D); AALLOC(Vt, bf16_t, (size_t)n * tiles * H * 64 * D);
+
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_patchify(px, pA, n, 1, f.clip_image, f.clip_patch, ctx->c_Kp, st));
+  { GemmArgs g = gemm(pA, ctx->c_Kp, ctx->c_patchw, pO, C, n * P, C, ctx->c_Kp);
+    // algorithmic flops use the real K = 3*p*p, not the padded one
+    RUN(GVL_PROF_GEMM, 2.0 * n * P * (double)C * 3 * f.clip_patch * f.clip_patch, gvl_launch_gemm(g, st)); }
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_clip_embed_ln(pO, ctx->c_cls, ctx->c_pos, ctx->c_prelnw, ctx->c_prelnb, x, n, P, C, 1e-5f, st));
+  for (int l = 0; l < f.clip_layers_run; ++l) {
+    const ClipLayerW& w = ctx->cl[l];
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_layernorm_f32(x, w.ln1w, w.ln1b, h, M, C, 1e-5f, st));
+    { GemmArgs g = gemm(h, C, w.qkvw, qkv, 3 * C, M, 3 * C, C); g.bias = w.qkvb; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv; q.ld = 3 * C; q.Q = Q; q.Kt = Kt; q.Vt = Vt; q.B = n; q.S = S; q.H = H; q.KV = H; q.Dr = Dr; q.D = D; q.mode = 0;
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
+    { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; a.O = att; a.B = n; a.H = H; a.KV = H; a.S = S; a.D = D; a.Dout = Dr;
+      a.scale = 1.0f / sqrtf((float)Dr); a.causal = 0; RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
+    { GemmArgs g = gemm(att, C, w.outw, x, C, M, C, C); g.bias = w.outb; g.resid = x; g.ldr = C; g.out_f32 = 1; g.round_pre_resid = 1;
+      RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_layernorm_f32(x, w.ln2w, w.ln2b, h, M, C, 1e-5f, st));
+    { GemmArgs g = gemm(h, C, w.fc1w, mlp, I, M, I, C); g.bias = w.fc1b; g.act = GVL_ACT_QUICK_GELU; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    { GemmArgs g = gemm(mlp, I, w.fc2w, x, C, M, C, I); g.bias = w.fc2b; g.resid = x; g.ldr = C; g.out_f32 = 1; g.round_pre_resid = 1;
+      RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+  }
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_strip_cls(x, out, n, S, C, 4, st));
+  ctx->arena_off = mark;
+  return 0;
+}
+
+int iv2_encode(gvl_ctx* ctx, const float* px, int n, bf16_t* out, hipStream_t st) {
+  const gvl_config& f = ctx->cfg;
+  const int C = f.iv2_dim, H = f.iv2_heads, S = ctx->v_S, TL = ctx->v_TL, M = n * S, I = f.iv2_inter, D = ctx->v_D, Dr = ctx->v_Dr;
+  const int tiles = (S + 63) / 64;
+  const size_t mark = ctx->arena_off;
+  AALLOC(x, bf16_t, (size_t)M * C); AALLOC(h, bf16_t, (size_t)M * C); AALLOC(qkv, bf16_t, (size_t)M * 3 * C);
+  AALLOC(att, bf16_t, (size_t)M * C); AALLOC(mlp, bf16_t, (size_t)M * I);
+  AALLOC(pA, bf16_t, (size_t)n * TL * ctx->v_Kp); AALLOC(pO, bf16_t, (size_t)n * TL * C);
+  AALLOC(Q, bf16_t, (size_t)n * H * S * D); AALLOC(Kt, bf16_t, (size_t)n * tiles * H * 64 * D); AALLOC(Vt, bf16_t, (size_t)n * tiles * H * 64 * D);
+
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_patchify(px, pA, n, f.iv2_frames_per_seg, f.iv2_image, f.iv2_patch, ctx->v_Kp, st));
+  { GemmArgs g = gemm(pA, ctx->v_Kp, ctx->v_patchw, pO, C, n * TL, C, ctx->v_Kp); g.bias = ctx->v_patchb;
+    RUN(GVL_PROF_GEMM, 2.0 * n * TL * (double)C * 3 * f.iv2_patch * f.iv2_patch, gvl_launch_gemm(g, st)); }
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_iv2_embed(pO, ctx->v_cls, ctx->v_pos, x, n, TL, C, st));
+  for (int l = 0; l < f.iv2_blocks_run; ++l) {
+    const Iv2BlockW& w = ctx->vb[l];
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.n1, h, M, C, 1e-6f, st));
+    { GemmArgs g = gemm(h, C, w.qkvw, qkv, 3 * C, M, 3 * C, C); RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv; q.ld = 3 * C; q.Q = Q; q.Kt = Kt; q.Vt = Vt; q.B = n; q.S = S; q.H = H; q.KV = H; q.Dr = Dr; q.D = D;
+      q.mode = 1; q.qn = w.qn; q.kn = w.kn; q.eps = 1e-6f; RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
+    { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; a.O = att; a.B = n; a.H = H; a.KV = H; a.S = S; a.D = D; a.Dout = Dr;
+      a.scale = 1.0f / sqrtf((float)Dr); a.causal = 0; RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
+    { GemmArgs g = gemm(att, C, w.projw, x, C, M, C, C); g.bias = w.projb; g.gamma = w.ls1; g.resid = x; g.ldr = C;
+      RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.n2, h, M, C, 1e-6f, st));
+    { GemmArgs g = gemm(h, C, w.fc1w, mlp, I, M, I, C); g.bias = w.fc1b; g.act = GVL_ACT_GELU; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    { GemmArgs g = gemm(mlp, I, w.fc2w, x, C, M, C, I); g.bias = w.fc2b; g.gamma = w.ls2; g.resid = x; g.ldr = C;
+      RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+  }
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_strip_cls(x, out, n, S, C, 2, st));
+  ctx->arena_off = mark;
+  return 0;
+}
+
+int build_visual(gvl_ctx* ctx, const float* clip_feats, const bf16_t* iv2_feats, int n, bf16_t* visual, hipStream_t st) {
+  const gvl_config& f = ctx->cfg;
+  const int Hd = f.hidden, L = ctx->tok_per_seg, IT = ctx->img_tok, ST = ctx->seg_tok, T = f.iv2_frames_per_seg;
+  const bool phi = f.llm_kind == GVL_LLM_PHI3;
+  const int cin = phi ? 4 * f.clip_hidden : f.clip_hidden;
+  const size_t mark = ctx->arena_off;
+  AALLOC(A1, bf16_t, (size_t)n * IT * cin); AALLOC(T1, bf16_t, (size_t)n * IT * Hd);
+  AALLOC(A2, bf16_t, (size_t)n * ST * f.iv2_dim); AALLOC(T2, bf16_t, (size_t)n * ST * Hd);
+  AALLOC(nl1, bf16_t, Hd); AALLOC(nl2, bf16_t, Hd);
+  if (phi) RUN(GVL_PROF_OTHER, 0, gvl_launch_hd_merge(clip_feats, ctx->sub_gn, A1, n, f.clip_hidden, st));
+  else RUN(GVL_PROF_OTHER, 0, gvl_launch_pool_spatial(clip_feats, A1, n, f.clip_hidden, st));
+  { GemmArgs g = gemm(A1, cin, ctx->mm0w, T1, Hd, n * IT, Hd, cin); g.bias = ctx->mm0b; g.act = GVL_ACT_GELU; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+  { GemmArgs g = gemm(T1, Hd, ctx->mm1w, visual, Hd, n * IT, Hd, Hd); g.bias = ctx->mm1b; g.grp_rows = IT; g.grp_stride = L; g.row_off = 0;
+    RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_pool_temporal(iv2_feats, A2, n, T, f.iv2_dim, st));
+  { GemmArgs g = gemm(A2, f.iv2_dim, ctx->vp0w, T2, Hd, n * ST, Hd, f.iv2_dim); g.bias = ctx->vp0b; g.act = GVL_ACT_GELU; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+  { GemmArgs g = gemm(T2, Hd, ctx->vp1w, visual, Hd, n * ST, Hd, Hd); g.bias = ctx->vp1b; g.grp_rows = ST; g.grp_stride = L; g.row_off = IT;
+    RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+  if (phi) {   // glb_GN through the image projector (llava_next_video.py:560-561); one row, broadcast (App. C #5)
+    { GemmArgs g = gemm(ctx->glb_gn, cin, ctx->mm0w, nl1, Hd, 1, Hd, cin); g.bias = ctx->mm0b; g.act = GVL_ACT_GELU; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    { GemmArgs g = gemm(nl1, Hd, ctx->mm1w, nl2, Hd, 1, Hd, Hd); g.bias = ctx->mm1b; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_bcast_row(nl2, visual, n, L, IT + ST, Hd, st));
+  } else {
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_bcast_row(ctx->newline, visual, n, L, IT + ST, Hd, st));
+  }
+  ctx->arena_off = mark;
+  return 0;
+}
+
+// one decoder layer stack over S rows starting at position 0 (prefill)
+int llm_prefill(gvl_ctx* ctx, Seq& sq, const bf16_t* embeds, int S, hipStream_t st) {
+  const gvl_config& f = ctx->cfg;
+  const int Hd = f.hidden, H = f.heads, KV = f.kv_heads, Dr = ctx->l_Dr, D = ctx->l_D, I = f.inter;
+  const int qkvw = (H + 2 * KV) * Dr;
+  const size_t mark = ctx->arena_off;
+  AALLOC(x, bf16_t, (size_t)S * Hd); AALLOC(h, bf16_t, (size_t)S * Hd); AALLOC(qkv, bf16_t, (size_t)S * qkvw);
+  AALLOC(att, bf16_t, (size_t)S * H * Dr); AALLOC(act, bf16_t, (size_t)S * I); AALLOC(Q, bf16_t, (size_t)H * S * D);
+  HIPCHK(ctx, hipMemcpyAsync(x, embeds, (size_t)S * Hd * 2, hipMemcpyDeviceToDevice, st));
+  const bool use_long = f.rope_orig_max_pos > 0 && S > f.rope_orig_max_pos && ctx->cos_l;
+  const float* cs = use_long ? ctx->cos_l : ctx->cos_s; const float* sn = use_long ? ctx->sin_l : ctx->sin_s;
+  for (int l = 0; l < f.layers; ++l) {
+    const LlmLayerW& w = ctx->ll[l];
+    bf16_t* Kt = ctx->kpool + (size_t)l * ctx->layer_stride; bf16_t* Vt = ctx->vpool + (size_t)l * ctx->layer_stride;
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln1, h, S, Hd, f.rms_eps, st));
+    { GemmArgs g = gemm(h, Hd, w.qkvw, qkv, qkvw, S, qkvw, Hd); RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv; q.ld = qkvw; q.Q = Q; q.Kt = Kt; q.Vt = Vt; q.block_table = sq.d_block_table; q.max_pages = sq.n_pages;
+      q.B = 1; q.S = S; q.H = H; q.KV = KV; q.Dr = Dr; q.D = D; q.mode = 2; q.cos = cs; q.sin = sn; q.pos0 = 0;
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
+    { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; a.O = att; a.block_table = sq.d_block_table; a.max_pages = sq.n_pages;
+      a.B = 1; a.H = H; a.KV = KV; a.S = S; a.D = D; a.Dout = Dr; a.scale = 1.0f / sqrtf((float)Dr); a.causal = 1;
+      RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
+    { GemmArgs g = gemm(att, H * Dr, w.ow, x, Hd, S, Hd, H * Dr); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln2, h, S, Hd, f.rms_eps, st));
+    { GemmArgs g = gemm(h, Hd, w.guw, act, I, S, 2 * I, Hd); g.act = GVL_ACT_SILU_MUL; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    { GemmArgs g = gemm(act, I, w.downw, x, Hd, S, Hd, I); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+  }
+  // last-row-only lm_head: final RMSNorm fused into the GEMV
+  { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = ctx->l_headw; g.N = f.vocab; g.K = Hd; g.x = x + (size_t)(S - 1) * Hd; g.norm_w = ctx->l_norm; g.eps = f.rms_eps;
+    g.bias = ctx->l_headb; g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, gvl_launch_gemv(g, st)); }
+  ctx->arena_off = mark;
+  return 0;
+}
+
+int decode_step(gvl_ctx* ctx, Seq& sq, hipStream_t st) {
+  const gvl_config& f = ctx->cfg;
+  const int Hd = f.hidden, H = f.heads, KV = f.kv_heads, Dr = ctx->l_Dr, D = ctx->l_D, I = f.inter;
+  const int qkvw = (H + 2 * KV) * Dr;
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_rows(ctx->l_embed, ctx->d_tok, ctx->d_x, 1, Hd, st));
+  for (int l = 0; l < f.layers; ++l) {
+    const LlmLayerW& w = ctx->ll[l];
+    bf16_t* Kt = ctx->kpool + (size_t)l * ctx->layer_stride; bf16_t* Vt = ctx->vpool + (size_t)l * ctx->layer_stride;
+    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.qkvw; g.N = qkvw; g.K = Hd; g.x = ctx->d_x; g.norm_w = w.ln1; g.eps = f.rms_eps; g.out_bf16 = ctx->d_qkv;
+      RUN(GVL_PROF_GEMV, 2.0 * qkvw * Hd, gvl_launch_gemv(g, st)); }
+    { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = ctx->d_qkv; q.ld = qkvw; q.Q = ctx->d_q; q.Kt = Kt; q.Vt = Vt; q.block_table = sq.d_block_table; q.max_pages = sq.n_pages;
+      q.B = 1; q.S = 1; q.H = H; q.KV = KV; q.Dr = Dr; q.D = D; q.mode = 2; q.cos = ctx->cos_s; q.sin = ctx->sin_s; q.pos_ptr = sq.d_pos;
+      q.cos_l = ctx->cos_l; q.sin_l = ctx->sin_l; q.rope_switch = ctx->cos_l ? f.rope_orig_max_pos : 0;
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
+    { DecodeAttnArgs a; memset(&a, 0, sizeof(a)); a.q = ctx->d_q; a.Kt = Kt; a.Vt = Vt; a.block_table = sq.d_block_table; a.pos_ptr = sq.d_pos; a.part = ctx->d_part;
+      a.out = ctx->d_attn; a.H = H; a.KV = KV; a.D = D; a.Dout = Dr; a.nsplit = ctx->nsplit; a.scale = 1.0f / sqrtf((float)Dr);
+      RUN(GVL_PROF_DECODE_ATTN, 4.0 * (sq.pos + 1) * (double)KV * D, gvl_launch_decode_attention(a, st)); }
+    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.ow; g.N = Hd; g.K = H * Dr; g.x = ctx->d_attn; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
+      RUN(GVL_PROF_GEMV, 2.0 * Hd * H * Dr, gvl_launch_gemv(g, st)); }
+    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.guw; g.N = 2 * I; g.K = Hd; g.x = ctx->d_x; g.norm_w = w.ln2; g.eps = f.rms_eps; g.act = GVL_ACT_SILU_MUL; g.out_bf16 = ctx->d_act;
+      RUN(GVL_PROF_GEMV, 4.0 * I * Hd, gvl_launch_gemv(g, st)); }
+    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.downw; g.N = Hd; g.K = I; g.x = ctx->d_act; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
+      RUN(GVL_PROF_GEMV, 2.0 * Hd * I, gvl_launch_gemv(g, st)); }
+  }
+  { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = ctx->l_headw; g.N = f.vocab; g.K = Hd; g.x = ctx->d_x; g.norm_w = ctx->l_norm; g.eps = f.rms_eps; g.bias = ctx->l_headb;
+    g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, gvl_launch_gemv(g, st)); }
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(ctx->d_logits, f.vocab, ctx->d_tok, ctx->d_outlist, ctx->d_step, st));
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_inc(sq.d_pos, st));
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_inc(ctx->d_step, st));
+  sq.pos += 1; sq.n_gen += 1;
+  return 0;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* gvl_last_error(const gvl_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int gvl_device_info(char* arch_out, int arch_len, int* num_cus) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return GVL_ERR_NOGPU;
+  hipDeviceProp_t p; int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return GVL_ERR_HIP;
+  if (arch_out && arch_len > 0) { strncpy(arch_out, p.gcnArchName, arch_len - 1); arch_out[arch_len - 1] = 0; }
+  if (num_cus) *num_cus = p.multiProcessorCount;
+  return 0;
+}
+
+int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, GVL_ERR_ARG, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, GVL_ERR_NOGPU, "no HIP device: libgvl has no CPU fallback");
+  gvl_ctx* ctx = new gvl_ctx();
+  ctx->cfg = *cfg;
+  const gvl_config& f = ctx->cfg;
+  ctx->has_clip = f.clip_hidden > 0 && f.clip_layers_run >= 0 && f.clip_heads > 0;
+  ctx->has_iv2 = f.iv2_dim > 0 && f.iv2_heads > 0;
+  ctx->has_llm = f.hidden > 0 && f.layers > 0;
+  ctx->has_proj = ctx->has_clip && ctx->has_iv2 && f.hidden > 0;
+  auto bad = [&](const char* m) { std::string s = m; delete ctx; return fail(nullptr, GVL_ERR_ARG, s); };
+  if (ctx->has_clip) {
+    if (f.clip_hidden % 64 || f.clip_inter % 64 || f.clip_hidden % f.clip_heads || f.clip_image % f.clip_patch) return bad("clip geometry: hidden/inter must be multiples of 64");
+    const int g = f.clip_image / f.clip_patch;
+    ctx->c_P = g * g; ctx->c_S = ctx->c_P + 1; ctx->c_Kp = round_up(3 * f.clip_patch * f.clip_patch, 64);
+    ctx->c_Dr = f.clip_hidden / f.clip_heads; ctx->c_D = pad_head(ctx->c_Dr);
+    if (ctx->c_D < 0 || (ctx->c_Dr & 3)) return bad("clip head dim unsupported");
+  }
+  if (ctx->has_iv2) {
+    if (f.iv2_dim % 64 || f.iv2_inter % 64 || f.iv2_dim % f.iv2_heads || f.iv2_image % f.iv2_patch || f.iv2_frames_per_seg <= 0) return bad("iv2 geometry");
+    const int g = f.iv2_image / f.iv2_patch;
+    ctx->v_L = g * g; ctx->v_TL = ctx->v_L * f.iv2_frames_per_seg; ctx->v_S = ctx->v_TL + 1; ctx->v_Kp = round_up(3 * f.iv2_patch * f.iv2_patch, 64);
+    ctx->v_Dr = f.iv2_dim / f.iv2_heads; ctx->v_D = pad_head(ctx->v_Dr);
+    if (ctx->v_D < 0 || (ctx->v_Dr & 3)) return bad("iv2 head dim unsupported");
+  }
+  if (f.hidden > 0) {
+    if (f.hidden % 64) return bad("llm hidden must be a multiple of 64");
+    if (ctx->has_llm) {
+      if (f.inter % 64 || f.hidden % f.heads || f.heads % f.kv_heads || f.vocab <= 0 || f.max_seq <= 0) return bad("llm geometry");
+      ctx->l_Dr = f.hidden / f.heads; ctx->l_D = pad_head(ctx->l_Dr);
+      if (ctx->l_D < 0 || (ctx->l_Dr & 3) || ((f.heads * ctx->l_Dr) % 64)) return bad("llm head dim unsupported");
+    }
+  }
+  if (ctx->has_proj) {
+    ctx->img_tok = f.llm_kind == GVL_LLM_PHI3 ? 156 : 64;
+    ctx->seg_tok = f.iv2_frames_per_seg * 16;
+    ctx->tok_per_seg = ctx->img_tok + ctx->seg_tok + 1;
+  }
+  // workspace arena
+  const int ns = f.max_segs > 0 ? f.max_segs : 1;
+  size_t need_b = 1 << 20;
+  if (ctx->has_clip) need_b = std::max(need_b, clip_bytes(ctx, ns));
+  if (ctx->has_iv2) need_b = std::max(need_b, iv2_bytes(ctx, ns));
+  if (ctx->has_proj) need_b = std::max(need_b, visual_bytes(ctx, ns));
+  if (ctx->has_llm && f.max_prefill > 0) need_b = std::max(need_b, prefill_bytes(ctx, f.max_prefill));
+  if (ctx->has_clip && ctx->has_iv2) need_b += feats_bytes(ctx, ns);
+  need_b += 64 << 20;   // slack for the operator-level test entry points
+  ctx->arena_bytes = need_b;
+  if (hipMalloc((void**)&ctx->arena, need_b) != hipSuccess) { delete ctx; return fail(nullptr, GVL_ERR_OOM, "hipMalloc(arena) failed"); }
+  // KV pool + decode buffers
+  if (ctx->has_llm) {
+    const int pages = f.kv_pages > 0 ? f.kv_pages : 1;
+    ctx->layer_stride = (size_t)pages * f.kv_heads * 64 * ctx->l_D;
+    const size_t pool = ctx->layer_stride * f.layers * 2;
+    if (hipMalloc((void**)&ctx->kpool, pool) != hipSuccess || hipMalloc((void**)&ctx->vpool, pool) != hipSuccess) { gvl_destroy(ctx); return fail(nullptr, GVL_ERR_OOM, "hipMalloc(kv pool) failed"); }
+    hipMemset(ctx->kpool, 0, pool); hipMemset(ctx->vpool, 0, pool);   // padded keys/values must be finite
+    for (int p = pages - 1; p >= 0; --p) ctx->free_pages.push_back(p);
+    const int qkvw = (f.heads + 2 * f.kv_heads) * ctx->l_Dr;
+    bool ok = true;
+    ok &= hipMalloc((void**)&ctx->d_x, (size_t)f.hidden * 2) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_qkv, (size_t)qkvw * 2) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_q, (size_t)f.heads * ctx->l_D * 2) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_attn, (size_t)f.heads * ctx->l_Dr * 2) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_act, (size_t)f.inter * 2) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_logits, (size_t)f.vocab * 4) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_part, (size_t)f.heads * ctx->nsplit * (ctx->l_D + 2) * 4) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_tok, 4) == hipSuccess && hipMalloc((void**)&ctx->d_step, 4) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_outlist, (size_t)ctx->outlist_cap * 4) == hipSuccess;
+    if (!ok) { gvl_destroy(ctx); return fail(nullptr, GVL_ERR_OOM, "hipMalloc(decode buffers) failed"); }
+  }
+  if (hipMalloc((void**)&ctx->d_ids, (size_t)ctx->ids_cap * 4) != hipSuccess) { gvl_destroy(ctx); return fail(nullptr, GVL_ERR_OOM, "hipMalloc failed"); }
+  *out = ctx;
+  return 0;
+}
+
+int gvl_destroy(gvl_ctx* ctx) {
+  if (!ctx) return 0;
+  hipDeviceSynchronize();
+  for (auto& kv : ctx->w) if (kv.second.p) hipFree(kv.second.p);
+  for (auto& s : ctx->seqs) { if (s.d_block_table) hipFree(s.d_block_table); if (s.d_pos) hipFree(s.d_pos); }
+  void* ptrs[] = {ctx->arena, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_tok, ctx->d_step, ctx->d_outlist, ctx->d_ids};
+  for (void* p : ptrs) if (p) hipFree(p);
+  for (auto& r : ctx->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  delete ctx;
+  return 0;
+}
+
+int gvl_load_weight(gvl_ctx* ctx, const char* name, const void* data, int dtype, const int64_t* shape, int ndim, int is_device) {
+  if (!ctx || !name || !data || ndim < 0 || ndim > 8) return fail(ctx, GVL_ERR_ARG, "gvl_load_weight: bad argument");
+  if (dtype != GVL_F32 && dtype != GVL_BF16) return fail(ctx, GVL_ERR_ARG, "gvl_load_weight: dtype must be f32 or bf16");
+  Tensor t; t.dtype = dtype; t.numel = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); t.numel *= shape[i]; }
+  const size_t bytes = (size_t)t.numel * (dtype == GVL_F32 ? 4 : 2);
+  auto it = ctx->w.find(name);
+  if (it != ctx->w.end()) { hipFree(it->second.p); ctx->w.erase(it); }
+  HIPCHK(ctx, hipMalloc(&t.p, bytes ? bytes : 16));
+  HIPCHK(ctx, hipMemcpy(t.p, data, bytes, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  ctx->w[name] = t;
+  ctx->finalized = false;
+  return 0;
+}
+
+int gvl_finalize_weights(gvl_ctx* ctx) {
+  if (!ctx) return GVL_ERR_ARG;
+  const gvl_config& f = ctx->cfg;
+  char nm[128];
+  if (ctx->has_clip) {
+    const int C = f.clip_hidden, I = f.clip_inter;
+    NEED("clip.patch.w", GVL_BF16, (int64_t)C * ctx->c_Kp, &ctx->c_patchw);
+    NEED("clip.cls", GVL_F32, C, &ctx->c_cls); NEED("clip.pos", GVL_F32, (int64_t)ctx->c_S * C, &ctx->c_pos);
+    NEED("clip.preln.w", GVL_F32, C, &ctx->c_prelnw); NEED("clip.preln.b", GVL_F32, C, &ctx->c_prelnb);
+    ctx->cl.assign(f.clip_layers_run, ClipLayerW());
+    for (int l = 0; l < f.clip_layers_run; ++l) {
+      ClipLayerW& w = ctx->cl[l];
+#define CN(s) (snprintf(nm, sizeof nm, "clip.L%d." s, l), nm)
+      NEED(CN("ln1.w"), GVL_F32, C, &w.ln1w); NEED(CN("ln1.b"), GVL_F32, C, &w.ln1b); NEED(CN("ln2.w"), GVL_F32, C, &w.ln2w); NEED(CN("ln2.b"), GVL_F32, C, &w.ln2b);
+      NEED(CN("qkv.w"), GVL_BF16, (int64_t)3 * C * C, &w.qkvw); NEED(CN("qkv.b"), GVL_F32, 3 * C, &w.qkvb);
+      NEED(CN("out.w"), GVL_BF16, (int64_t)C * C, &w.outw); NEED(CN("out.b"), GVL_F32, C, &w.outb);
+      NEED(CN("fc1.w"), GVL_BF16, (int64_t)I * C, &w.fc1w); NEED(CN("fc1.b"), GVL_F32, I, &w.fc1b);
+      NEED(CN("fc2.w"), GVL_BF16, (int64_t)C * I, &w.fc2w); NEED(CN("fc2.b"), GVL_F32, C, &w.fc2b);
+#undef CN
+    }
+  }
+  if (ctx->has_iv2) {
+    const int C = f.iv2_dim, I = f.iv2_inter;
+    NEED("iv2.patch.w", GVL_BF16, (int64_t)C * ctx->v_Kp, &ctx->v_patchw); NEED("iv2.patch.b", GVL_F32, C, &ctx->v_patchb);
+    NEED("iv2.cls", GVL_BF16, C, &ctx->v_cls); NEED("iv2.pos", GVL_BF16, (int64_t)ctx->v_S * C, &ctx->v_pos);
+    ctx->vb.assign(f.iv2_blocks_run, Iv2BlockW());
+    for (int l = 0; l < f.iv2_blocks_run; ++l) {
+      Iv2BlockW& w = ctx->vb[l];
+#define VN(s) (snprintf(nm, sizeof nm, "iv2.B%d." s, l), nm)
+      NEED(VN("n1.w"), GVL_BF16, C, &w.n1); NEED(VN("n2.w"), GVL_BF16, C, &w.n2);
+      NEED(VN("qkv.w"), GVL_BF16, (int64_t)3 * C * C, &w.qkvw); NEED(VN("qn.w"), GVL_BF16, C, &w.qn); NEED(VN("kn.w"), GVL_BF16, C, &w.kn);
+      NEED(VN("proj.w"), GVL_BF16, (int64_t)C * C, &w.projw); NEED(VN("proj.b"), GVL_F32, C, &w.projb);
+      NEED(VN("ls1"), GVL_F32, C, &w.ls1); NEED(VN("ls2"), GVL_F32, C, &w.ls2);
+      NEED(VN("fc1.w"), GVL_BF16, (int64_t)I * C, &w.fc1w); NEED(VN("fc1.b"), GVL_F32, I, &w.fc1b);
+      NEED(VN("fc2.w"), GVL_BF16, (int64_t)C * I, &w.fc2w); NEED(VN("fc2.b"), GVL_F32, C, &w.fc2b);
+#undef VN
+    }
+  }
+  if (ctx->has_proj) {
+    const int Hd = f.hidden; const bool phi = f.llm_kind == GVL_LLM_PHI3; const int cin = phi ? 4 * f.clip_hidden : f.clip_hidden;
+    NEED("mm.0.w", GVL_BF16, (int64_t)Hd * cin, &ctx->mm0w); NEED("mm.0.b", GVL_F32, Hd, &ctx->mm0b);
+    NEED("mm.1.w", GVL_BF16, (int64_t)Hd * Hd, &ctx->mm1w); NEED("mm.1.b", GVL_F32, Hd, &ctx->mm1b);
+    NEED("vp.0.w", GVL_BF16, (int64_t)Hd * f.iv2_dim, &ctx->vp0w); NEED("vp.0.b", GVL_F32, Hd, &ctx->vp0b);
+    NEED("vp.1.w", GVL_BF16, (int64_t)Hd * Hd, &ctx->vp1w); NEED("vp.1.b", GVL_F32, Hd, &ctx->vp1b);
+    if (phi) { NEED("sub_gn", GVL_F32, cin, &ctx->sub_gn); NEED("glb_gn", GVL_BF16, cin, &ctx->glb_gn); }
+    else NEED("newline", GVL_BF16, Hd, &ctx->newline);
+  }
+  if (ctx->has_llm) {
+    const int Hd = f.hidden, I = f.inter, Dr = ctx->l_Dr, qkvw = (f.heads + 2 * f.kv_heads) * Dr;
+    NEED("llm.embed", GVL_BF16, (int64_t)f.vocab * Hd, &ctx->l_embed); NEED("llm.norm.w", GVL_BF16, Hd, &ctx->l_norm);
+    NEED("llm.head.w", GVL_BF16, (int64_t)f.vocab * Hd, &ctx->l_headw);
+    if (f.lm_head_bias) NEED("llm.head.b", GVL_F32, f.vocab, &ctx->l_headb); else ctx->l_headb = nullptr;
+    NEED("rope.cos_s", GVL_F32, (int64_t)f.max_seq * (Dr / 2), &ctx->cos_s); NEED("rope.sin_s", GVL_F32, (int64_t)f.max_seq * (Dr / 2), &ctx->sin_s);
+    if (f.rope_orig_max_pos > 0) { NEED("rope.cos_l", GVL_F32, (int64_t)f.max_seq * (Dr / 2), &ctx->cos_l); NEED("rope.sin_l", GVL_F32, (int64_t)f.max_seq * (Dr / 2), &ctx->sin_l); }
+    else { ctx->cos_l = ctx->sin_l = nullptr; }
+    ctx->ll.assign(f.layers, LlmLayerW());
+    for (int l = 0; l < f.layers; ++l) {
+      LlmLayerW& w = ctx->ll[l];
+#define LN(s) (snprintf(nm, sizeof nm, "llm.L%d." s, l), nm)
+      NEED(LN("ln1.w"), GVL_BF16, Hd, &w.ln1); NEED(LN("ln2.w"), GVL_BF16, Hd, &w.ln2);
+      NEED(LN("qkv.w"), GVL_BF16, (int64_t)qkvw * Hd, &w.qkvw); NEED(LN("o.w"), GVL_BF16, (int64_t)Hd * f.heads * Dr, &w.ow);
+      NEED(LN("gu.w"), GVL_BF16, (int64_t)2 * I * Hd, &w.guw); NEED(LN("down.w"), GVL_BF16, (int64_t)Hd * I, &w.downw);
+#undef LN
+    }
+  }
+  ctx->finalized = true;
+  return 0;
+}
+
+#define REQUIRE_READY(cond, what) do { if (!ctx) return GVL_ERR_ARG; if (!ctx->finalized || !(cond)) return fail(ctx, GVL_ERR_STATE, what ": weights not finalized or tower not configured"); } while (0)
+
+int gvl_clip_encode(gvl_ctx* ctx, const float* px, int n, float* out, void* stream) {
+  REQUIRE_READY(ctx->has_clip, "gvl_clip_encode");
+  if (!px || !out || n <= 0 || n > std::max(1, ctx->cfg.max_segs)) return fail(ctx, GVL_ERR_ARG, "gvl_clip_encode: bad n/pointers");
+  return clip_encode(ctx, px, n, out, (hipStream_t)stream);
+}
+int gvl_iv2_encode(gvl_ctx* ctx, const float* px, int n, uint16_t* out, void* stream) {
+  REQUIRE_READY(ctx->has_iv2, "gvl_iv2_encode");
+  if (!px || !out || n <= 0 || n > std::max(1, ctx->cfg.max_segs)) return fail(ctx, GVL_ERR_ARG, "gvl_iv2_encode: bad n/pointers");
+  return iv2_encode(ctx, px, n, out, (hipStream_t)stream);
+}
+int gvl_tokens_per_seg(const gvl_ctx* ctx) { return ctx ? ctx->tok_per_seg : 0; }
+int gvl_build_visual(gvl_ctx* ctx, const float* clip_feats, const uint16_t* iv2_feats, int n, uint16_t* visual, void* stream) {
+  REQUIRE_READY(ctx->has_proj, "gvl_build_visual");
+  if (!clip_feats || !iv2_feats || !visual || n <= 0 || n > std::max(1, ctx->cfg.max_segs)) return fail(ctx, GVL_ERR_ARG, "gvl_build_visual: bad n/pointers");
+  if (ctx->c_P != 576) return fail(ctx, GVL_ERR_ARG, "gvl_build_visual: needs the 24x24 CLIP grid (llava_next_video.py:460)");
+  if (ctx->v_L != 256) return fail(ctx, GVL_ERR_ARG, "gvl_build_visual: needs the 16x16 InternVideo2 grid");
+  return build_visual(ctx, clip_feats, iv2_feats, n, visual, (hipStream_t)stream);
+}
+int gvl_encode_segments(gvl_ctx* ctx, const float* spatial_px, const float* temporal_px, int n, uint16_t* visual, void* stream) {
+  REQUIRE_READY(ctx->has_proj, "gvl_encode_segments");
+  if (!spatial_px || !temporal_px || !visual || n <= 0 || n > std::max(1, ctx->cfg.max_segs)) return fail(ctx, GVL_ERR_ARG, "gvl_encode_segments: bad n/pointers");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t mark = ctx->arena_off;
+  AALLOC(cf, float, (size_t)n * ctx->c_P * ctx->cfg.clip_hidden);
+  AALLOC(vf, bf16_t, (size_t)n * ctx->v_TL * ctx->cfg.iv2_dim);
+  int rc = clip_encode(ctx, spatial_px, n, cf, st);
+  if (!rc) rc = iv2_encode(ctx, temporal_px, n, vf, st);
+  if (!rc) rc = gvl_build_visual(ctx, cf, vf, n, visual, stream);
+  ctx->arena_off = mark;
+  return rc;
+}
+
+int gvl_splice(gvl_ctx* ctx, const int64_t* ids, int n_ids, const uint16_t* visual, int n_visual, uint16_t* embeds, int* seq_len_out, void* stream) {
+  REQUIRE_READY(ctx->has_llm, "gvl_splice");
+  if (!ids || !visual || !embeds || n_ids <= 0 || n_visual < 0 || n_ids > ctx->ids_cap) return fail(ctx, GVL_ERR_ARG, "gvl_splice: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int idx = -1, cnt = 0;
+  std::vector<int> text; text.reserve(n_ids);
+  for (int i = 0; i < n_ids; ++i) {
+    if (ids[i] == -200) { if (idx < 0) idx = i; ++cnt; }
+    else { if (ids[i] < 0 || ids[i] >= ctx->cfg.vocab) return fail(ctx, GVL_ERR_ARG, "gvl_splice: token id out of range"); text.push_back((int)ids[i]); }
+  }
+  if (cnt != 1) return fail(ctx, GVL_ERR_ARG, "gvl_splice: exactly one IMAGE_TOKEN_INDEX (-200) expected");
+  const int Hd = ctx->cfg.hidden, n_post = n_ids - 1 - idx;
+  HIPCHK(ctx, hipMemcpy(ctx->d_ids, text.data(), text.size() * 4, hipMemcpyHostToDevice));
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_rows(ctx->l_embed, ctx->d_ids, embeds, idx, Hd, st));
+  HIPCHK(ctx, hipMemcpyAsync(embeds + (size_t)idx * Hd, visual, (size_t)n_visual * Hd * 2, hipMemcpyDeviceToDevice, st));
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_rows(ctx->l_embed, ctx->d_ids + idx, embeds + (size_t)(idx + n_visual) * Hd, n_post, Hd, st));
+  if (seq_len_out) *seq_len_out = n_ids - 1 + n_visual;
+  return 0;
+}
+
+int gvl_seq_alloc(gvl_ctx* ctx, int max_tokens, int* seq_id) {
+  REQUIRE_READY(ctx->has_llm, "gvl_seq_alloc");
+  if (max_tokens <= 0 || !seq_id) return fail(ctx, GVL_ERR_ARG, "gvl_seq_alloc: bad arguments");
+  if (max_tokens > ctx->cfg.max_seq) return fail(ctx, GVL_ERR_ARG, "gvl_seq_alloc: max_tokens exceeds cfg.max_seq (rope tables)");
+  const int np = (max_tokens + 63) / 64;
+  if ((int)ctx->free_pages.size() < np) return fail(ctx, GVL_ERR_OOM, "gvl_seq_alloc: KV pages exhausted");
+  int id = -1;
+  for (size_t i = 0; i < ctx->seqs.size(); ++i) if (!ctx->seqs[i].used) { id = (int)i; break; }
+  if (id < 0) { ctx->seqs.emplace_back(); id = (int)ctx->seqs.size() - 1; }
+  Seq& s = ctx->seqs[id];
+  s.used = true; s.max_tokens = max_tokens; s.n_pages = np; s.pos = 0; s.n_gen = 0; s.pages.clear();
+  for (int i = 0; i < np; ++i) { s.pages.push_back(ctx->free_pages.back()); ctx->free_pages.pop_back(); }
+  HIPCHK(ctx, hipMalloc((void**)&s.d_block_table, (size_t)np * 4));
+  HIPCHK(ctx, hipMalloc((void**)&s.d_pos, 4));
+  HIPCHK(ctx, hipMemcpy(s.d_block_table, s.pages.data(), (size_t)np * 4, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemset(s.d_pos, 0, 4));
+  *seq_id = id;
+  return 0;
+}
+int gvl_seq_free(gvl_ctx* ctx, int seq_id) {
+  if (!ctx || seq_id < 0 || seq_id >= (int)ctx->seqs.size() || !ctx->seqs[seq_id].used) return fail(ctx, GVL_ERR_ARG, "gvl_seq_free: bad seq");
+  Seq& s = ctx->seqs[seq_id];
+  hipDeviceSynchronize();
+  for (int p : s.pages) ctx->free_pages.push_back(p);
+  hipFree(s.d_block_table); hipFree(s.d_pos);
+  s = Seq();
+  return 0;
+}
+
+int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int S, float* last_logits, void* stream) {
+  REQUIRE_READY(ctx->has_llm, "gvl_prefill");
+  if (seq_id < 0 || seq_id >= (int)ctx->seqs.size() || !ctx->seqs[seq_id].used) return fail(ctx, GVL_ERR_ARG, "gvl_prefill: bad seq");
+  Seq& sq = ctx->seqs[seq_id];
+  if (!embeds || S <= 0 || S > sq.max_tokens || S > ctx->cfg.max_prefill) return fail(ctx, GVL_ERR_ARG, "gvl_prefill: bad length");
+  if (sq.pos != 0) return fail(ctx, GVL_ERR_STATE, "gvl_prefill: sequence already holds tokens");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = llm_prefill(ctx, sq, embeds, S, st);
+  if (rc) return rc;
+  if (last_logits) HIPCHK(ctx, hipMemcpyAsync(last_logits, ctx->d_logits, (size_t)ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(ctx->d_step, 0, st));
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(ctx->d_logits, ctx->cfg.vocab, ctx->d_tok, ctx->d_outlist, ctx->d_step, st));
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(ctx->d_step, 1, st));
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sq.d_pos, S, st));
+  sq.pos = S; sq.n_gen = 1;
+  return 0;
+}
+
+int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t* out_ids, int* n_out, void* stream) {
+  REQUIRE_READY(ctx->has_llm, "gvl_decode_greedy");
+  if (seq_id < 0 || seq_id >= (int)ctx->seqs.size() || !ctx->seqs[seq_id].used) return fail(ctx, GVL_ERR_ARG, "gvl_decode_greedy: bad seq");
+  Seq& sq = ctx->seqs[seq_id];
+  if (!out_ids || !n_out || max_new <= 0 || max_new > ctx->outlist_cap) return fail(ctx, GVL_ERR_ARG, "gvl_decode_greedy: bad arguments");
+  if (sq.n_gen < 1) return fail(ctx, GVL_ERR_STATE, "gvl_decode_greedy: call gvl_prefill first");
+  hipStream_t st = (hipStream_t)stream;
+  const int CHECK_EVERY = 16;
+  int checked = 0;   // tokens already inspected for eos
+  for (;;) {
+    const bool full = sq.n_gen >= max_new || sq.pos >= sq.max_tokens;
+    if (full || (eos_id >= 0 && sq.n_gen - checked >= CHECK_EVERY) || (eos_id >= 0 && checked == 0)) {
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      HIPCHK(ctx, hipMemcpy(out_ids + checked, ctx->d_outlist + checked, (size_t)(sq.n_gen - checked) * 4, hipMemcpyDeviceToHost));
+      if (eos_id >= 0)
+        for (int i = checked; i < sq.n_gen; ++i)
+          if (out_ids[i] == eos_id) { *n_out = i + 1; return 0; }
+      checked = sq.n_gen;
+      if (full) { *n_out = sq.n_gen < max_new ? sq.n_gen : max_new; return 0; }
+    }
+    int rc = decode_step(ctx, sq, st);
+    if (rc) return rc;
+  }
+}
+
+int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, void* stream) {
+  REQUIRE_READY(ctx->has_llm, "gvl_decode_step_logits");
+  if (seq_id < 0 || seq_id >= (int)ctx->seqs.size() || !ctx->seqs[seq_id].used) return fail(ctx, GVL_ERR_ARG, "gvl_decode_step_logits: bad seq");
+  Seq& sq = ctx->seqs[seq_id];
+  if (tok < 0 || tok >= ctx->cfg.vocab || sq.pos >= sq.max_tokens || sq.pos == 0) return fail(ctx, GVL_ERR_ARG, "gvl_decode_step_logits: bad token / sequence full / not prefilled");
+  hipStream_t st = (hipStream_t)stream;
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(ctx->d_tok, tok, st));
+  int rc = decode_step(ctx, sq, st);
+  if (rc) return rc;
+  if (logits) HIPCHK(ctx, hipMemcpyAsync(logits, ctx->d_logits, (size_t)ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int gvl_prof_enable(gvl_ctx* ctx, int on) {
+  if (!ctx) return GVL_ERR_ARG;
+  hipDeviceSynchronize();
+  for (auto& r : ctx->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  ctx->recs.clear();
+  for (int i = 0; i < GVL_PROF_NCAT; ++i) { ctx->prof_ms[i] = 0; ctx->prof_work[i] = 0; ctx->prof_n[i] = 0; }
+  ctx->prof = on != 0;
+  return 0;
+}
+int gvl_prof_read(gvl_ctx* ctx, int cat, double* total_ms, int64_t* launches, double* work) {
+  if (!ctx || cat < 0 || cat >= GVL_PROF_NCAT) return GVL_ERR_ARG;
+  hipDeviceSynchronize();
+  for (auto& r : ctx->recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { ctx->prof_ms[r.cat] += ms; ctx->prof_work[r.cat] += r.work; ctx->prof_n[r.cat] += 1; }
+    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+  }
+  ctx->recs.clear();
+  if (total_ms) *total_ms = ctx->prof_ms[cat];
+  if (launches) *launches = ctx->prof_n[cat];
+  if (work) *work = ctx->prof_work[cat];
+  return 0;
+}
+
+// ---- operator-level entry points -------------------------------------------------------------------
+int gvl_op_gemm(gvl_ctx* ctx, const uint16_t* A, const uint16_t* W, void* C, int M, int N, int K, const float* bias, const float* gamma,
+                const void* resid, int act, int out_f32, int tile_cfg, void* stream) {
+  if (!ctx) return GVL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs g = gemm(A, K, W, C, act == GVL_ACT_SILU_MUL ? N / 2 : N, M, N, K);
+  g.bias = bias; g.gamma = gamma; g.resid = resid; g.ldr = N; g.act = act; g.out_f32 = out_f32; g.round_pre_resid = 1; g.tile_cfg = tile_cfg;
+  RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
+  return 0;
+}
+int gvl_op_attention(gvl_ctx* ctx, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out, int B, int S, int H, int KV, int Dr,
+                     float scale, int causal, void* stream) {
+  // q/k/v here are column blocks of ONE fused row-major qkv tensor [B*S][(H+2KV)*Dr]: q points at column 0;
+  // k and v must equal q + H*Dr and q + (H+KV)*Dr (checked) -- the layout every tower produces.
+  if (!ctx) return GVL_ERR_ARG;
+  if (k != q + (size_t)H * Dr || v != q + (size_t)(H + KV) * Dr) return fail(ctx, GVL_ERR_ARG, "gvl_op_attention: q,k,v must be the column blocks of one fused qkv tensor");
+  const int D = pad_head(Dr);
+  if (D < 0 || (Dr & 3)) return fail(ctx, GVL_ERR_ARG, "gvl_op_attention: head dim unsupported");
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = (S + 63) / 64;
+  const size_t mark = ctx->arena_off;
+  AALLOC(Q, bf16_t, (size_t)B * H * S * D); AALLOC(Kt, bf16_t, (size_t)B * tiles * KV * 64 * D); AALLOC(Vt, bf16_t, (size_t)B * tiles * KV * 64 * D);
+  { QkvPostArgs p; memset(&p, 0, sizeof(p)); p.qkv = q; p.ld = (H + 2 * KV) * Dr; p.Q = Q; p.Kt = Kt; p.Vt = Vt; p.B = B; p.S = S; p.H = H; p.KV = KV; p.Dr = Dr; p.D = D; p.mode = 0;
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(p, st)); }
+  { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; a.O = out; a.B = B; a.H = H; a.KV = KV; a.S = S; a.D = D; a.Dout = Dr; a.scale = scale; a.causal = causal;
+    RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
+  ctx->arena_off = mark;
+  return 0;
+}
+int gvl_op_layernorm(gvl_ctx* ctx, const float* x, const float* w, const float* b, uint16_t* y, int rows, int cols, float eps, void* stream) {
+  if (!ctx) return GVL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_layernorm_f32(x, w, b, y, rows, cols, eps, st));
+  return 0;
+}
+int gvl_op_rmsnorm(gvl_ctx* ctx, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int cols, float eps, void* stream) {
+  if (!ctx) return GVL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w, y, rows, cols, eps, st));
+  return 0;
+}
+int gvl_op_gemv(gvl_ctx* ctx, const uint16_t* W, const uint16_t* x, const float* bias, float* y, int N, int K, void* stream) {
+  if (!ctx) return GVL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  GemvArgs g; memset(&g, 0, sizeof(g)); g.W = W; g.N = N; g.K = K; g.x = x; g.bias = bias; g.out_f32 = y;
+  RUN(GVL_PROF_GEMV, 2.0 * N * K, gvl_launch_gemv(g, st));
+  return 0;
+}
+
+}  // extern "C"

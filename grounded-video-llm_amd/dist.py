@@ -1,0 +1,55 @@
+"""Multi-GPU plan of the hot path: segment sharding + ONE all-gather of visual tokens (RCCL over xGMI).
+
+The reference's inference is single-GPU (inference.py:17); this is new functionality described by
+SURVEY.md §8(e): segments are independent in both encoders (models/llava_next_video.py:503-505,
+:530-532), so rank r encodes a contiguous block of segments with replicated vision weights and the
+per-segment token blocks `[image | temporal | newline]` (:563) are exchanged once per clip.  The
+payload is small (<= 3.5 MB / rank) and latency-bound, so it is a single un-chunked collective; with
+xGMI's point-to-point links every rank pushes its block to all peers at once.
+
+One process per GPU, `torch.distributed` (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_units: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous balanced blocks: the first (n_units % world) ranks get one extra unit."""
+    base, rem = divmod(n_units, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def my_shard(n_units: int, rank: int, world: int) -> Tuple[int, int]:
+    return shard_bounds(n_units, world)[rank]
+
+
+def allgather_visual(local: torch.Tensor, n_units: int, rows_per_unit: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """local: [n_local * rows_per_unit, D] for this rank's block -> full [n_units * rows_per_unit, D] on every rank.
+
+    Blocks are padded to the largest block so that a single fixed-size all_gather_into_tensor is used
+    (12 segments over 8 ranks is uneven: 2,2,2,2,1,1,1,1)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return local
+    bounds = shard_bounds(n_units, world)
+    max_units = max(hi - lo for lo, hi in bounds)
+    D = local.shape[1]
+    lo, hi = bounds[rank]
+    assert local.shape[0] == (hi - lo) * rows_per_unit, (local.shape, lo, hi)
+    send = local.new_zeros((max_units * rows_per_unit, D))
+    send[: local.shape[0]] = local
+    recv = local.new_empty((world * max_units * rows_per_unit, D))
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, max_units * rows_per_unit, D)
+    parts = [recv[r, : (b[1] - b[0]) * rows_per_unit] for r, b in enumerate(bounds)]
+    return torch.cat(parts, dim=0)

@@ -1,0 +1,273 @@
+"""Engine: one gvl_ctx on one GPU, with torch tensors as the caller-owned I/O buffers.
+
+PyTorch here is plumbing only (device allocations, the current HIP stream); all arithmetic runs
+inside libgvl.so.  If the library cannot be loaded this module raises -- there is no eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import lib as L
+
+bf = torch.bfloat16
+
+
+@dataclass
+class TowerGeometry:
+    """Mirrors gvl_config (include/gvl.h).  Defaults = the reference's Phi-3.5 / 96-frame configuration
+    (models/llava_next_video.py:56-71, models/internvideo2.py:1089-1114, HF Phi-3.5 config [ext])."""
+    llm: str = "phi3.5"                      # 'phi3.5' | 'llama3' | 'vicuna'
+    clip_hidden: int = 1024
+    clip_inter: int = 4096
+    clip_layers: int = 24                    # layers in the checkpoint; layers-1 are executed (hidden_states[-2])
+    clip_heads: int = 16
+    clip_image: int = 336
+    clip_patch: int = 14
+    iv2_dim: int = 1408
+    iv2_inter: int = 6144
+    iv2_depth: int = 40                      # blocks in the checkpoint; depth-1 are executed (x_vis_return_idx=-2)
+    iv2_heads: int = 16
+    iv2_image: int = 224
+    iv2_patch: int = 14
+    frames_per_seg: int = 8
+    hidden: int = 3072
+    inter: int = 8192
+    layers: int = 32
+    heads: int = 32
+    kv_heads: int = 32
+    vocab: int = 32366                       # 32064 + 302 temporal tokens (llava_next_video.py:235-268)
+    rms_eps: float = 1e-5
+    lm_head_bias: bool = True
+    rope_theta: float = 10000.0
+    rope_short: Optional[Sequence[float]] = None
+    rope_long: Optional[Sequence[float]] = None
+    rope_max_pos: int = 131072
+    rope_orig_max_pos: int = 4096
+    max_seq: int = 8192
+    max_segs: int = 12
+    kv_pages: int = 128
+    max_prefill: int = 4096
+
+    @property
+    def kind(self) -> str:
+        return "phi3" if self.llm == "phi3.5" else "llama"
+
+    @staticmethod
+    def llama3_8b(**kw) -> "TowerGeometry":
+        base = dict(llm="llama3", hidden=4096, inter=14336, layers=32, heads=32, kv_heads=8, vocab=128558, rope_theta=500000.0,
+                    rope_short=None, rope_long=None, rope_orig_max_pos=0, max_seq=8192)
+        base.update(kw)
+        return TowerGeometry(**base)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    def __init__(self, geo: TowerGeometry, device: str = "cuda:0", towers: Sequence[str] = ("clip", "iv2", "llm")):
+        self.lib = L.load()
+        self.geo = geo
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("grounded_video_llm_amd.Engine needs a HIP device (cuda:N); there is no CPU path")
+        torch.cuda.set_device(self.device)
+        cfg = L.GvlConfig()
+        cfg.llm_kind = L.LLM_PHI3 if geo.kind == "phi3" else L.LLM_LLAMA
+        if "clip" in towers:
+            cfg.clip_hidden, cfg.clip_inter, cfg.clip_layers_run = geo.clip_hidden, geo.clip_inter, geo.clip_layers - 1
+            cfg.clip_heads, cfg.clip_image, cfg.clip_patch = geo.clip_heads, geo.clip_image, geo.clip_patch
+        if "iv2" in towers:
+            cfg.iv2_dim, cfg.iv2_inter, cfg.iv2_blocks_run = geo.iv2_dim, geo.iv2_inter, geo.iv2_depth - 1
+            cfg.iv2_heads, cfg.iv2_image, cfg.iv2_patch, cfg.iv2_frames_per_seg = geo.iv2_heads, geo.iv2_image, geo.iv2_patch, geo.frames_per_seg
+        cfg.hidden = geo.hidden if ("llm" in towers or "proj" in towers) else 0
+        if "llm" in towers:
+            cfg.inter, cfg.layers, cfg.heads, cfg.kv_heads, cfg.vocab = geo.inter, geo.layers, geo.heads, geo.kv_heads, geo.vocab
+            cfg.rms_eps = geo.rms_eps
+            cfg.lm_head_bias = 1 if geo.lm_head_bias else 0
+            cfg.rope_orig_max_pos = geo.rope_orig_max_pos if geo.rope_long is not None else 0
+            cfg.max_seq = geo.max_seq
+            cfg.kv_pages, cfg.max_prefill = geo.kv_pages, geo.max_prefill
+        cfg.max_segs = geo.max_segs
+        self.cfg = cfg
+        self.towers = tuple(towers)
+        h = C.c_void_p()
+        rc = self.lib.gvl_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise L.GvlError(f"gvl_create failed ({rc}): {self.lib.gvl_last_error(None).decode()}")
+        self.ctx = h
+        self._finalized = False
+
+    # ---- lifecycle -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.gvl_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        L.check(self.lib, self.ctx, rc, what)
+
+    @property
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def load_packed(self, packed: Dict[str, torch.Tensor]):
+        for name, t in packed.items():
+            if t.dtype == torch.float32:
+                dt = L.F32
+            elif t.dtype == bf:
+                dt = L.BF16
+            else:
+                raise TypeError(f"{name}: packed tensors must be float32 or bfloat16, got {t.dtype}")
+            t = t.contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*(list(t.shape) or [1]))
+            self._chk(self.lib.gvl_load_weight(self.ctx, name.encode(), C.c_void_p(t.data_ptr()), dt, shape, max(t.dim(), 1),
+                                               1 if t.is_cuda else 0), f"gvl_load_weight({name})")
+
+    def finalize(self):
+        self._chk(self.lib.gvl_finalize_weights(self.ctx), "gvl_finalize_weights")
+        self._finalized = True
+
+    # ---- vision ----------------------------------------------------------------------------------
+    def clip_encode(self, px: torch.Tensor) -> torch.Tensor:
+        """vision_tower(px, output_hidden_states=True).hidden_states[-2][:, 1:] (llava_next_video.py:504-505)."""
+        px = px.to(self.device, torch.float32).contiguous()
+        n = px.shape[0]
+        P = (self.geo.clip_image // self.geo.clip_patch) ** 2
+        out = torch.empty((n, P, self.geo.clip_hidden), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.gvl_clip_encode(self.ctx, _ptr(px), n, _ptr(out), self.stream), "gvl_clip_encode")
+        return out
+
+    def iv2_encode(self, px: torch.Tensor) -> torch.Tensor:
+        """video_encoder(x, None, False, x_vis_return_idx=-2, x_vis_only=True)[:, 1:, :] (llava_next_video.py:532).
+        px [n,3,T,H,W]."""
+        px = px.to(self.device, torch.float32).contiguous()
+        n, T = px.shape[0], px.shape[2]
+        assert T == self.geo.frames_per_seg
+        Lp = (self.geo.iv2_image // self.geo.iv2_patch) ** 2
+        out = torch.empty((n, T * Lp, self.geo.iv2_dim), dtype=bf, device=self.device)
+        self._chk(self.lib.gvl_iv2_encode(self.ctx, _ptr(px), n, _ptr(out), self.stream), "gvl_iv2_encode")
+        return out
+
+    @property
+    def tokens_per_seg(self) -> int:
+        return int(self.lib.gvl_tokens_per_seg(self.ctx))
+
+    def build_visual(self, clip_feats: torch.Tensor, iv2_feats: torch.Tensor) -> torch.Tensor:
+        n = clip_feats.shape[0]
+        out = torch.empty((n * self.tokens_per_seg, self.geo.hidden), dtype=bf, device=self.device)
+        self._chk(self.lib.gvl_build_visual(self.ctx, _ptr(clip_feats.contiguous()), _ptr(iv2_feats.contiguous()), n, _ptr(out), self.stream),
+                  "gvl_build_visual")
+        return out
+
+    def encode_segments(self, spatial_px: torch.Tensor, temporal_px: torch.Tensor) -> torch.Tensor:
+        """encode_images() for n segments: spatial [n,3,336,336], temporal [n,3,T,224,224] -> [n*L, hidden] bf16."""
+        sp = spatial_px.to(self.device, torch.float32).contiguous()
+        tp = temporal_px.to(self.device, torch.float32).contiguous()
+        n = sp.shape[0]
+        out = torch.empty((n * self.tokens_per_seg, self.geo.hidden), dtype=bf, device=self.device)
+        self._chk(self.lib.gvl_encode_segments(self.ctx, _ptr(sp), _ptr(tp), n, _ptr(out), self.stream), "gvl_encode_segments")
+        return out
+
+    # ---- LLM -------------------------------------------------------------------------------------
+    def splice(self, input_ids: Sequence[int], visual: torch.Tensor) -> torch.Tensor:
+        ids = (C.c_int64 * len(input_ids))(*[int(i) for i in input_ids])
+        nv = visual.shape[0]
+        out = torch.empty((len(input_ids) - 1 + nv, self.geo.hidden), dtype=bf, device=self.device)
+        S = C.c_int(0)
+        self._chk(self.lib.gvl_splice(self.ctx, ids, len(input_ids), _ptr(visual.contiguous()), nv, _ptr(out), C.byref(S), self.stream), "gvl_splice")
+        assert S.value == out.shape[0]
+        return out
+
+    def seq_alloc(self, max_tokens: int) -> int:
+        s = C.c_int(-1)
+        self._chk(self.lib.gvl_seq_alloc(self.ctx, int(max_tokens), C.byref(s)), "gvl_seq_alloc")
+        return s.value
+
+    def seq_free(self, seq: int):
+        self._chk(self.lib.gvl_seq_free(self.ctx, int(seq)), "gvl_seq_free")
+
+    def prefill(self, seq: int, embeds: torch.Tensor, want_logits: bool = False) -> Optional[torch.Tensor]:
+        embeds = embeds.contiguous()
+        logits = torch.empty((self.geo.vocab,), dtype=torch.float32, device=self.device) if want_logits else None
+        self._chk(self.lib.gvl_prefill(self.ctx, seq, _ptr(embeds), embeds.shape[0], _ptr(logits), self.stream), "gvl_prefill")
+        return logits
+
+    def decode_greedy(self, seq: int, max_new: int, eos_id: Optional[int]) -> List[int]:
+        buf = (C.c_int32 * max_new)()
+        n = C.c_int(0)
+        self._chk(self.lib.gvl_decode_greedy(self.ctx, seq, int(max_new), -1 if eos_id is None else int(eos_id), buf, C.byref(n), self.stream),
+                  "gvl_decode_greedy")
+        return [int(buf[i]) for i in range(n.value)]
+
+    def decode_step_logits(self, seq: int, tok: int) -> torch.Tensor:
+        logits = torch.empty((self.geo.vocab,), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.gvl_decode_step_logits(self.ctx, seq, int(tok), _ptr(logits), self.stream), "gvl_decode_step_logits")
+        return logits
+
+    def generate_ids(self, embeds: torch.Tensor, max_new_tokens: int, eos_id: Optional[int]) -> List[int]:
+        """language_model.generate(inputs_embeds=..., greedy): returns only the NEW ids (eos included)."""
+        S = embeds.shape[0]
+        seq = self.seq_alloc(min(S + max_new_tokens, self.geo.max_seq))
+        try:
+            self.prefill(seq, embeds)
+            return self.decode_greedy(seq, max_new_tokens, eos_id)
+        finally:
+            self.seq_free(seq)
+
+    # ---- measurement -----------------------------------------------------------------------------
+    def prof_enable(self, on: bool):
+        self._chk(self.lib.gvl_prof_enable(self.ctx, 1 if on else 0), "gvl_prof_enable")
+
+    def prof_read(self, cat: int):
+        ms, n, w = C.c_double(0), C.c_int64(0), C.c_double(0)
+        self._chk(self.lib.gvl_prof_read(self.ctx, cat, C.byref(ms), C.byref(n), C.byref(w)), "gvl_prof_read")
+        return ms.value, n.value, w.value
+
+    # ---- operator-level (parity tests) -------------------------------------------------------------
+    def op_gemm(self, A, W, bias=None, gamma=None, resid=None, act=L.ACT_NONE, out_f32=False, tile_cfg=0):
+        M, K = A.shape
+        N = W.shape[0]
+        n_out = N // 2 if act == L.ACT_SILU_MUL else N
+        Cc = torch.empty((M, n_out), dtype=torch.float32 if out_f32 else bf, device=self.device)
+        self._chk(self.lib.gvl_op_gemm(self.ctx, _ptr(A.contiguous()), _ptr(W.contiguous()), _ptr(Cc), M, N, K, _ptr(bias), _ptr(gamma),
+                                       _ptr(resid), act, 1 if out_f32 else 0, tile_cfg, self.stream), "gvl_op_gemm")
+        return Cc
+
+    def op_attention(self, qkv: torch.Tensor, B, S, H, KV, Dr, scale, causal):
+        """qkv bf16 [B*S, (H+2KV)*Dr] fused rows -> out bf16 [B*S, H*Dr]."""
+        qkv = qkv.contiguous()
+        out = torch.empty((B * S, H * Dr), dtype=bf, device=self.device)
+        base = qkv.data_ptr()
+        self._chk(self.lib.gvl_op_attention(self.ctx, C.c_void_p(base), C.c_void_p(base + 2 * H * Dr), C.c_void_p(base + 2 * (H + KV) * Dr),
+                                            _ptr(out), B, S, H, KV, Dr, float(scale), int(causal), self.stream), "gvl_op_attention")
+        return out
+
+    def op_layernorm(self, x, w, b, eps):
+        y = torch.empty(x.shape, dtype=bf, device=self.device)
+        self._chk(self.lib.gvl_op_layernorm(self.ctx, _ptr(x.contiguous()), _ptr(w), _ptr(b), _ptr(y), x.shape[0], x.shape[1], float(eps), self.stream),
+                  "gvl_op_layernorm")
+        return y
+
+    def op_rmsnorm(self, x, w, eps):
+        y = torch.empty(x.shape, dtype=bf, device=self.device)
+        self._chk(self.lib.gvl_op_rmsnorm(self.ctx, _ptr(x.contiguous()), _ptr(w), _ptr(y), x.shape[0], x.shape[1], float(eps), self.stream),
+                  "gvl_op_rmsnorm")
+        return y
+
+    def op_gemv(self, W, x, bias=None):
+        N, K = W.shape
+        y = torch.empty((N,), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.gvl_op_gemv(self.ctx, _ptr(W.contiguous()), _ptr(x.contiguous()), _ptr(bias), _ptr(y), N, K, self.stream), "gvl_op_gemv")
+        return y

@@ -1,0 +1,205 @@
+"""Host-side mirror of the reference's model surface:  LLAVA_NEXT_VIDEO(...).generate(samples, **kw).
+
+Same constructor arguments and `generate()` contract as models/llava_next_video.py:73-89,616-666:
+`samples` = {"prompts": [str], "temporal_pixel_values": [bs,F,3,224,224], "spatial_pixel_values":
+[bs,S,3,336,336], "video_ids": [...]}; returns List[str].  Everything numeric runs in libgvl.so
+(grounded_video_llm_amd.engine); this file only does the text plumbing and the call order.
+
+Differences that are deliberate and documented: 23 CLIP layers instead of 24
+(#2), last-row lm_head (#7), paged KV instead of DynamicCache (#8), glb_GN projected once (#5), LoRA
+merged at load (#16), greedy decoding only on this tier (the reference CLI defaults to sampling).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import dist as gdist
+from . import prompts as P
+from . import weights as Wt
+from .engine import Engine, TowerGeometry
+
+bf = torch.bfloat16
+
+
+class SyntheticTokenizer:
+    """Stand-in for the HF tokenizer (tokenizer files are not available offline): whitespace words -> ids by a
+    stable hash; the 302 temporal tokens map to the last 302 rows of the vocabulary like `add_tokens` does."""
+
+    def __init__(self, vocab: int, num_temporal_tokens: int = 300, bos_token_id: Optional[int] = 1, eos_token_id: int = 2, pad_token_id: int = 0):
+        self.vocab, self.bos_token_id, self.eos_token_id, self.pad_token_id = vocab, bos_token_id, eos_token_id, pad_token_id
+        self.added = P.temporal_token_strings(num_temporal_tokens)
+        self.base = vocab - len(self.added)
+        self.tok2id = {t: self.base + i for i, t in enumerate(self.added)}
+        self.id2tok = {v: k for k, v in self.tok2id.items()}
+
+    def __len__(self):
+        return self.vocab
+
+    def _word(self, w: str) -> int:
+        if w in self.tok2id:
+            return self.tok2id[w]
+        h = 2166136261
+        for ch in w.encode():
+            h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+        return 3 + h % (self.base - 3)
+
+    def __call__(self, text: str) -> List[int]:
+        import re
+        words = re.findall(r"<\d+>|<timestamp_grounding>|\S+", text)
+        ids = [self._word(w) for w in words]
+        return ([self.bos_token_id] if self.bos_token_id is not None else []) + ids
+
+    def batch_decode(self, batch: Sequence[Sequence[int]], skip_special_tokens: bool = True) -> List[str]:
+        out = []
+        for ids in batch:
+            toks = []
+            for i in ids:
+                if skip_special_tokens and i in (self.bos_token_id, self.eos_token_id, self.pad_token_id):
+                    continue
+                toks.append(self.id2tok.get(int(i), f"w{int(i)}"))
+            out.append(" ".join(toks))
+        return out
+
+
+class LLAVA_NEXT_VIDEO:
+    def __init__(self, dtype=torch.bfloat16, stage="pretrain", max_txt_len=2048, num_frames=96, num_segs=12, lora=False,
+                 num_temporal_tokens=300, llm="llama3", attn_implementation="flash_attention_2",
+                 config_path="weight_path/Phi-3.5-vision-instruct", tokenizer_path="weight_path/Phi-3.5-mini-instruct",
+                 pretrained_video_path="weight_path/internvideo/vision-encoder-InternVideo2-stage2_1b-224p-f4.pt",
+                 pretrained_vision_proj_llm_path="weight_path/Phi-3.5-vision-instruct-seperated/",
+                 *, geometry: Optional[TowerGeometry] = None, tokenizer=None, state_dicts: Optional[Dict[str, Dict[str, torch.Tensor]]] = None,
+                 device: str = "cuda:0", group=None):
+        if dtype not in (torch.bfloat16,):
+            raise ValueError("the MI355X path computes in bfloat16 (the reference's recommended dtype, README.md:57)")
+        if num_frames % num_segs != 0:
+            raise ValueError("num_frames must be a multiple of num_segs (einops rearrange at models/llava_next_video.py:530)")
+        self.dtype, self.stage, self.max_txt_len = dtype, stage, max_txt_len
+        self.num_frames, self.num_segs, self.lora, self.num_temporal_tokens, self.llm = num_frames, num_segs, lora, num_temporal_tokens, llm
+        self.group = group
+        if geometry is None:
+            geometry = TowerGeometry() if llm == "phi3.5" else TowerGeometry.llama3_8b()
+        geometry.frames_per_seg = num_frames // num_segs
+        self.geo = geometry
+        self.tokenizer = tokenizer
+        if self.tokenizer is None:
+            try:
+                from transformers import AutoTokenizer
+                self.tokenizer = AutoTokenizer.from_pretrained(tokenizer_path)
+            except Exception as e:   # no network / no files: the caller must inject one
+                raise RuntimeError(f"cannot load a tokenizer from {tokenizer_path!r} ({e}); pass tokenizer=...") from e
+            if llm == "llama3":
+                self.tokenizer.eos_token_id, self.tokenizer.pad_token_id = 128009, 128001   # llava_next_video.py:103-104
+            elif llm == "phi3.5":
+                self.tokenizer.pad_token = "<|end|>"                                       # :114
+            if stage in ("grounded", "sft"):
+                self.tokenizer.add_tokens(P.temporal_token_strings(num_temporal_tokens))   # :235-236
+        self.engine = Engine(geometry, device)
+        if state_dicts is None:
+            state_dicts = load_reference_checkpoints(llm, pretrained_video_path, pretrained_vision_proj_llm_path)
+        self.load_state_dicts(state_dicts)
+
+    # weights -------------------------------------------------------------------------------------------
+    def load_state_dicts(self, sd: Dict[str, Dict[str, torch.Tensor]], ckpt_frames: Optional[int] = None):
+        g = self.geo
+        self.engine.load_packed(Wt.pack_clip(sd["vision_tower"], g.clip_layers - 1))
+        self.engine.load_packed(Wt.pack_iv2(sd["video_encoder"], g.iv2_depth - 1, g.frames_per_seg, ckpt_frames))
+        self.engine.load_packed(Wt.pack_projectors(sd["projectors"], self.llm))
+        self.engine.load_packed(Wt.pack_llm(sd["language_model"], g.kind, g.layers, g.heads, g.kv_heads, g.max_seq, g.rope_theta,
+                                            g.rope_short, g.rope_long, g.rope_max_pos, g.rope_orig_max_pos))
+        self.engine.finalize()
+
+    def load_ckpt(self, ckpt: Dict[str, Dict[str, torch.Tensor]], base: Dict[str, Dict[str, torch.Tensor]]):
+        """inference.py:156-162: overlay the fine-tuned groups {multi_modal_projector, video_projecter, language_model}."""
+        proj = dict(base["projectors"])
+        for grp in ("multi_modal_projector", "video_projecter"):
+            for k, v in ckpt.get(grp, {}).items():
+                proj[f"{grp}.{k}"] = v
+        sd = dict(base)
+        sd["projectors"] = proj
+        if "language_model" in ckpt:
+            sd["language_model"] = ckpt["language_model"]
+        self.load_state_dicts(sd)
+
+    # text plumbing ----------------------------------------------------------------------------------------
+    def tokenizer_image_token(self, prompt: str) -> List[int]:
+        tok = (lambda s: self.tokenizer(s).input_ids) if hasattr(self.tokenizer("x"), "input_ids") else self.tokenizer
+        return P.tokenize_with_image(prompt, tok, getattr(self.tokenizer, "bos_token_id", None))
+
+    # vision -------------------------------------------------------------------------------------------------
+    def encode_images(self, samples) -> torch.Tensor:
+        """[bs, num_segs*L, hidden] bf16.  With a process group, segments are sharded over the ranks and the
+        token blocks all-gathered (dist.py)."""
+        sp, tp = samples["spatial_pixel_values"], samples["temporal_pixel_values"]
+        bs, S = sp.shape[:2]
+        fps = tp.shape[1] // S
+        sp = sp.reshape(bs * S, *sp.shape[2:])
+        tp = tp.reshape(bs, S, fps, *tp.shape[2:]).permute(0, 1, 3, 2, 4, 5).reshape(bs * S, tp.shape[2], fps, *tp.shape[3:])
+        n = bs * S
+        L = self.engine.tokens_per_seg
+        if self.group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
+            world, rank = torch.distributed.get_world_size(self.group), torch.distributed.get_rank(self.group)
+            lo, hi = gdist.my_shard(n, rank, world)
+            local = self.engine.encode_segments(sp[lo:hi], tp[lo:hi]) if hi > lo else torch.empty((0, self.geo.hidden), dtype=bf, device=self.engine.device)
+            vis = gdist.allgather_visual(local, n, L, self.group)
+        else:
+            chunks = [self.engine.encode_segments(sp[i:i + self.geo.max_segs], tp[i:i + self.geo.max_segs]) for i in range(0, n, self.geo.max_segs)]
+            vis = torch.cat(chunks, 0) if len(chunks) > 1 else chunks[0]
+        return vis.view(bs, S * L, self.geo.hidden)
+
+    # generate -----------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def generate(self, samples, **generate_kwargs) -> List[str]:
+        if generate_kwargs.get("do_sample", False) or generate_kwargs.get("num_beams", 1) != 1:
+            raise NotImplementedError("this tier implements greedy decoding (do_sample=False, num_beams=1)")
+        max_new = int(generate_kwargs.get("max_new_tokens", 2048))
+        ids = [self.tokenizer_image_token(t) for t in samples["prompts"]]
+        pad_id = getattr(self.tokenizer, "pad_token_id", 0) or 0
+        ids_arr, mask = P.left_pad_truncate(ids, pad_id, self.max_txt_len)
+        feats = self.encode_images(samples)
+        out_ids = self.generate_ids(ids_arr, mask, feats, max_new)
+        texts = self.tokenizer.batch_decode(out_ids, skip_special_tokens=True)
+        return [t.strip() for t in texts]
+
+    def generate_ids(self, ids_arr, mask, feats, max_new: int) -> List[List[int]]:
+        eos = getattr(self.tokenizer, "eos_token_id", None)
+        out = []
+        for b in range(ids_arr.shape[0]):
+            row = [int(t) for t, m in zip(ids_arr[b], mask[b]) if m]       # un-padded: identical maths to the left-padded batch
+            emb = self.engine.splice(row, feats[b])
+            out.append(self.engine.generate_ids(emb, max_new, eos))
+        return out
+
+
+def load_reference_checkpoints(llm: str, pretrained_video_path: str, pretrained_vision_proj_llm_path: str):
+    """The reference's on-disk layout (models/llava_next_video.py:117-151): vision_model.pth, image_newline(s).pth,
+    multi_modal_projector.pth, language_model_seperated/ (HF safetensors), InternVideo2 .pt."""
+    d = pretrained_vision_proj_llm_path
+    need = [os.path.join(d, "vision_model.pth"), pretrained_video_path]
+    missing = [p for p in need if not os.path.exists(p)]
+    if missing:
+        raise FileNotFoundError(f"reference checkpoints not found: {missing}; pass state_dicts=... (e.g. synthetic weights from grounded_video_llm_amd.synth)")
+    sd = {"vision_tower": torch.load(os.path.join(d, "vision_model.pth"), map_location="cpu"),
+          "video_encoder": torch.load(pretrained_video_path, map_location="cpu")}
+    proj = {f"multi_modal_projector.{k}": v for k, v in torch.load(os.path.join(d, "multi_modal_projector.pth"), map_location="cpu").items()}
+    if llm == "phi3.5":
+        nl = torch.load(os.path.join(d, "image_newlines.pth"), map_location="cpu")
+        proj["glb_GN"], proj["sub_GN"] = nl["glb_GN"], nl["sub_GN"]
+    else:
+        proj["image_newline"] = torch.load(os.path.join(d, "image_newline.pth"), map_location="cpu")["image_newline"]
+    sd["projectors"] = proj
+    from safetensors.torch import load_file
+    lm = {}
+    lmdir = os.path.join(d, "language_model_seperated")
+    for f in sorted(os.listdir(lmdir)):
+        if f.endswith(".safetensors"):
+            lm.update(load_file(os.path.join(lmdir, f)))
+    sd["language_model"] = lm
+    if "video_projecter.up_proj.weight" not in proj:   # trained group: arrives with the fine-tuned ckpt (inference.py:159-160)
+        emb = next(v for k, v in lm.items() if k.endswith("embed_tokens.weight"))
+        hid, vd = emb.shape[1], sd["video_encoder"]["cls_token"].shape[-1]
+        proj.update({"video_projecter.up_proj.weight": torch.zeros(hid, vd), "video_projecter.up_proj.bias": torch.zeros(hid),
+                     "video_projecter.down_proj.weight": torch.zeros(hid, hid), "video_projecter.down_proj.bias": torch.zeros(hid)})
+    return sd

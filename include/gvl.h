@@ -1,0 +1,150 @@
+/*
+ * gvl.h -- C ABI of libgvl.so, the MI355X-native Grounded-VideoLLM inference hot path.
+ *
+ * The reference (WHB139426/Grounded-Video-LLM) is pure Python/PyTorch and has no FFI seam; the
+ * boundary this library sits behind is the set of Python calls made inside
+ * LLAVA_NEXT_VIDEO.generate() (models/llava_next_video.py:616-666).  Each entry point below names
+ * the reference call it replaces (paths relative to the reference root).  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; no torch types.  All tensor arguments are DEVICE pointers owned by the
+ *     caller and valid for the duration of the call, unless the parameter says "host".
+ *   - every call enqueues its work on the caller's hipStream_t (passed as void*) and returns
+ *     without synchronising, except where noted.
+ *   - return value: 0 = ok, < 0 = error (gvl_status); text via gvl_last_error().  Nothing throws.
+ *   - bf16 tensors are raw uint16 bit patterns; "f32" is IEEE float.
+ *   - one gvl_ctx per GPU / rank; a ctx is not thread-safe (the reference is single-threaded too).
+ */
+#ifndef GVL_H
+#define GVL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gvl_ctx gvl_ctx;
+
+typedef enum {
+  GVL_OK = 0,
+  GVL_ERR_ARG = -1,      /* bad argument / shape */
+  GVL_ERR_STATE = -2,    /* call order (weights missing, sequence not allocated ...) */
+  GVL_ERR_HIP = -3,      /* HIP runtime error */
+  GVL_ERR_OOM = -4,      /* device memory or KV pages exhausted */
+  GVL_ERR_NOGPU = -5     /* no gfx950 device */
+} gvl_status;
+
+enum { GVL_F32 = 0, GVL_BF16 = 1, GVL_I32 = 2, GVL_I64 = 3 };
+enum { GVL_LLM_PHI3 = 0, GVL_LLM_LLAMA = 1 };
+
+/* Geometry of the three towers.  Mirrors the hard-coded / config.json values of the reference:
+ * CLIP  models/llava_next_video.py:56-71;  InternVideo2  models/internvideo2.py:1089-1114;
+ * Phi-3 / Llama  models/modeling_phi3.py:132-156, models/modeling_llama.py (HF config [ext]). */
+typedef struct {
+  int32_t llm_kind;            /* GVL_LLM_PHI3 | GVL_LLM_LLAMA */
+  /* CLIP ViT */
+  int32_t clip_hidden, clip_inter, clip_layers_run, clip_heads, clip_image, clip_patch;
+  /* InternVideo2 */
+  int32_t iv2_dim, iv2_inter, iv2_blocks_run, iv2_heads, iv2_image, iv2_patch, iv2_frames_per_seg;
+  /* LLM */
+  int32_t hidden, inter, layers, heads, kv_heads, vocab;
+  float rms_eps;
+  int32_t lm_head_bias;        /* 1: logits = W h + b (llava_next_video.py:263) */
+  int32_t rope_orig_max_pos;   /* LongRoPE switch point (4096); 0 = plain RoPE (one table) */
+  int32_t max_seq;             /* rows of the rope tables / largest context of one sequence */
+  /* limits */
+  int32_t max_segs;            /* largest number of segments per encode call on this rank */
+  int32_t kv_pages;            /* pages (64 tokens each, all layers) in the paged KV pool */
+  int32_t max_prefill;         /* largest prefill length (rows of the activation workspace) */
+} gvl_config;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int gvl_create(const gvl_config* cfg, gvl_ctx** out);
+int gvl_destroy(gvl_ctx* ctx);
+const char* gvl_last_error(const gvl_ctx* ctx);       /* ctx may be NULL: last create() error */
+int gvl_device_info(char* arch_out, int arch_len, int* num_cus);
+
+/* Packed weights.  `name` is one of the packed names produced by
+ * grounded_video_llm_amd/weights.py from the reference state-dict keys;
+ * replaces nn.Module.load_state_dict (inference.py:156-162).  `data` may be a host or device
+ * pointer (is_device); the library converts to its internal dtype and keeps its own copy.
+ * Synchronous. */
+int gvl_load_weight(gvl_ctx* ctx, const char* name, const void* data, int dtype, const int64_t* shape,
+                    int ndim, int is_device);
+int gvl_finalize_weights(gvl_ctx* ctx);               /* checks every required tensor is present */
+
+/* ---- vision hot path ------------------------------------------------------------------------ */
+/* vision_tower(px, output_hidden_states=True).hidden_states[-2][:, 1:]
+ * (llava_next_video.py:504-505).  px f32 [n,3,336,336] -> out f32 [n,576,clip_hidden]. */
+int gvl_clip_encode(gvl_ctx* ctx, const float* px, int n_images, float* out, void* stream);
+
+/* video_encoder(x, None, False, x_vis_return_idx=-2, x_vis_only=True)[:, 1:, :]
+ * (llava_next_video.py:532).  px f32 [n,3,T,224,224] -> out bf16 [n, T*256, iv2_dim]. */
+int gvl_iv2_encode(gvl_ctx* ctx, const float* px, int n_segs, uint16_t* out, void* stream);
+
+/* merge/pool + both projectors + newline + concat (llava_next_video.py:507-564) for n_segs
+ * segments.  clip_feats f32 [n,576,clip_hidden], iv2_feats bf16 [n,T*256,iv2_dim]
+ * -> visual bf16 [n * gvl_tokens_per_seg(), hidden]. */
+int gvl_build_visual(gvl_ctx* ctx, const float* clip_feats, const uint16_t* iv2_feats, int n_segs,
+                     uint16_t* visual, void* stream);
+int gvl_tokens_per_seg(const gvl_ctx* ctx);           /* 285 (Phi-3.5) / 193 (Llama-3) at 8 f/seg */
+
+/* encode_images() for the caller's segments = the three calls above on the ctx workspace.
+ * spatial f32 [n,3,336,336], temporal f32 [n,3,T,224,224] (already "(b s) c f h w"). */
+int gvl_encode_segments(gvl_ctx* ctx, const float* spatial_px, const float* temporal_px, int n_segs,
+                        uint16_t* visual, void* stream);
+
+/* prepare_multimodal_inputs() for one sample (llava_next_video.py:568-596): ids int64 host
+ * [n_ids] with exactly one IMAGE_TOKEN_INDEX (-200); embeds bf16 [n_ids-1+n_visual, hidden]. */
+int gvl_splice(gvl_ctx* ctx, const int64_t* ids_host, int n_ids, const uint16_t* visual, int n_visual,
+               uint16_t* embeds, int* seq_len_out, void* stream);
+
+/* ---- LLM hot path --------------------------------------------------------------------------- */
+/* language_model.generate(inputs_embeds=...) (llava_next_video.py:655-661), greedy:
+ *   seq_alloc  -> reserves KV pages for up to max_tokens (DynamicCache replacement, paged)
+ *   prefill    -> step 0 of generate(): writes KV, returns last-position logits (f32 [vocab],
+ *                 device pointer, may be NULL)
+ *   decode_greedy -> steps 1..N on the device; out_ids int32 host [max_new]; stops after eos
+ *                 (eos < 0 disables).  Synchronises the stream before returning. */
+int gvl_seq_alloc(gvl_ctx* ctx, int max_tokens, int* seq_id);
+int gvl_seq_free(gvl_ctx* ctx, int seq_id);
+int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int seq_len, float* last_logits,
+                void* stream);
+int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t* out_ids_host,
+                      int* n_out, void* stream);
+/* teacher-forced single step (parity tests): appends token `tok`, returns logits f32 [vocab]. */
+int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, void* stream);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* When enabled, every launch of a kernel family is bracketed by hipEvents on the caller's stream
+ * (slow; bench.py uses it for ONE profiled step after the timed region). */
+enum { GVL_PROF_GEMM = 0, GVL_PROF_ATTN = 1, GVL_PROF_GEMV = 2, GVL_PROF_DECODE_ATTN = 3, GVL_PROF_OTHER = 4,
+       GVL_PROF_NCAT = 5 };
+int gvl_prof_enable(gvl_ctx* ctx, int on);
+int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launches, double* work);
+
+/* ---- operator-level entry points (parity tests call the kernels through these) --------------- */
+/* C[M,N] = act(A[M,K] W[N,K]^T + bias) (+ resid); A,W bf16; bias/gamma f32 or NULL.
+ * act: 0 none, 1 quick_gelu, 2 gelu(erf), 3 silu(gate)*up on interleaved (gate,up) column pairs
+ * (output has N/2 columns).  out_f32: C is f32 else bf16; resid has C's dtype and layout. */
+int gvl_op_gemm(gvl_ctx* ctx, const uint16_t* A, const uint16_t* W, void* C, int M, int N, int K,
+                const float* bias, const float* gamma, const void* resid, int act, int out_f32,
+                int tile_cfg, void* stream);
+/* attention over q/k/v bf16 [B,S,H|KV,D] (plain layout; the library re-tiles internally).
+ * out bf16 [B,S,H*D].  causal: 0/1. */
+int gvl_op_attention(gvl_ctx* ctx, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out,
+                     int B, int S, int H, int KV, int D, float scale, int causal, void* stream);
+int gvl_op_layernorm(gvl_ctx* ctx, const float* x, const float* w, const float* b, uint16_t* y, int rows,
+                     int cols, float eps, void* stream);
+int gvl_op_rmsnorm(gvl_ctx* ctx, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int cols,
+                   float eps, void* stream);
+/* y[N] = W[N,K] x[K] (+bias) -- the decode GEMV; x,W bf16, y f32. */
+int gvl_op_gemv(gvl_ctx* ctx, const uint16_t* W, const uint16_t* x, const float* bias, float* y, int N, int K,
+                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVL_H */

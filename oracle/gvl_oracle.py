@@ -285,13 +285,13 @@ def iv2_block(x, W, i: int, num_heads: int, emu=False, eps=1e-6) -> torch.Tensor
     o = _r(torch.softmax(s, dim=-1) @ v, emu)
     o = o.transpose(1, 2).reshape(B, S, C)
     o = _lin(o, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"], emu)
-    o = _r(o.float() * W[p + "ls1.gamma"].float(), emu)      # LayerScale force_fp32 :458-463
+    o = _r(o.float() * _r(W[p + "ls1.gamma"].float(), emu), emu)      # LayerScale force_fp32 :458-463
     x = _r(x + o, emu)
     h = _rmsnorm(x, W[p + "norm2.weight"], eps, emu)
     h = _lin(h, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"], emu)
     h = _r(F.gelu(h), emu)                                   # nn.GELU (erf) :616
     h = _lin(h, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"], emu)
-    h = _r(h.float() * W[p + "ls2.gamma"].float(), emu)
+    h = _r(h.float() * _r(W[p + "ls2.gamma"].float(), emu), emu)
     return _r(x + h, emu)
 
 

@@ -1,0 +1,49 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU plan: segment sharding + the visual-token all-gather."""
+import os
+import socket
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _gvl_bootstrap  # noqa: E402,F401  (spawned workers re-import this module without conftest)
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from grounded_video_llm_amd import dist as gdist
+
+
+def test_shard_bounds():
+    assert gdist.shard_bounds(12, 8) == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 9), (9, 10), (10, 11), (11, 12)]
+    assert gdist.shard_bounds(12, 1) == [(0, 12)]
+    assert gdist.shard_bounds(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    for n in range(0, 40):
+        for w in range(1, 9):
+            b = gdist.shard_bounds(n, w)
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def _worker(rank, world, port, n_units, rows, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(n_units * rows * 4, dtype=torch.float32).view(n_units * rows, 4)
+        lo, hi = gdist.my_shard(n_units, rank, world)
+        got = gdist.allgather_visual(full[lo * rows: hi * rows].clone(), n_units, rows)
+        q.put((rank, bool(torch.equal(got, full))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_units,rows", [(12, 5), (3, 7), (1, 4)])
+def test_allgather_visual_gloo_world2(n_units, rows):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, n_units, rows, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(60) for p in ps]
+    assert res == [(0, True), (1, True)]

@@ -1,0 +1,126 @@
+"""-m gpu: every HIP kernel family through the C ABI against a plain fp32 torch reference of the same op
+(floating-point kernels; tolerance = bf16 output rounding, stated per test)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, bf, check, tiny_geo  # noqa: E402
+from grounded_video_llm_amd import engine as E, lib as L, synth  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = E.Engine(tiny_geo(), DEV, towers=())
+    yield e
+    e.close()
+
+
+def _rand(name, shape, std=1.0):
+    return synth.det_tensor(name, shape, std).to(DEV)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 0])
+@pytest.mark.parametrize("M,N,K", [(100, 64, 64), (300, 256, 128), (577, 1024, 640), (1000, 1408, 1408), (1, 128, 192), (513, 4224, 256)])
+def test_gemm_plain(eng, M, N, K, cfg):
+    A = _rand(f"gA{M}{N}{K}", (M, K)).to(bf)
+    W = _rand(f"gW{M}{N}{K}", (N, K), K ** -0.5).to(bf)
+    ref = A.float() @ W.float().T
+    got = eng.op_gemm(A, W, tile_cfg=cfg)
+    check(got, ref, 6e-3, f"gemm {M}x{N}x{K} cfg{cfg} bf16 out")
+    got32 = eng.op_gemm(A, W, out_f32=True, tile_cfg=cfg)
+    check(got32, ref, 2e-4, f"gemm {M}x{N}x{K} cfg{cfg} f32 out")
+
+
+def test_gemm_transpose_detect(eng):
+    # A = identity-like with ASYMMETRIC W catches swapped row/col in the C write (guide §3)
+    M = N = K = 128
+    A = torch.eye(M, K, device=DEV).to(bf)
+    W = (torch.arange(N, device=DEV)[:, None] * 0.01 + torch.arange(K, device=DEV)[None, :] * 1.0).to(bf)
+    got = eng.op_gemm(A, W, out_f32=True, tile_cfg=1)
+    check(got, A.float() @ W.float().T, 1e-6, "gemm identity x asymmetric")
+
+
+@pytest.mark.parametrize("cfg", [1, 2])
+def test_gemm_epilogues(eng, cfg):
+    M, N, K = 333, 512, 256
+    A = _rand("eA", (M, K)).to(bf)
+    W = _rand("eW", (N, K), K ** -0.5).to(bf)
+    bias = _rand("eb", (N,), 0.5)
+    acc = A.float() @ W.float().T + bias
+    rb = lambda t: t.to(bf).float()
+    # quick_gelu (CLIP fc1)
+    x = rb(acc)
+    ref = x * rb(torch.sigmoid(rb(1.702 * x)))
+    check(eng.op_gemm(A, W, bias=bias, act=L.ACT_QUICK_GELU, tile_cfg=cfg), ref, 8e-3, "quick_gelu epilogue")
+    # erf gelu (IV2 fc1, projectors)
+    check(eng.op_gemm(A, W, bias=bias, act=L.ACT_GELU, tile_cfg=cfg), torch.nn.functional.gelu(rb(acc)), 8e-3, "gelu epilogue")
+    # f32 residual (CLIP): x + bf16(acc+bias)
+    res = _rand("er", (M, N), 2.0)
+    check(eng.op_gemm(A, W, bias=bias, resid=res, out_f32=True, tile_cfg=cfg), res + rb(acc), 1e-5 + 2e-3, "f32 residual epilogue")
+    # bf16 residual + LayerScale (IV2): bf16(x + bf16(bf16(acc+bias)*gamma))
+    gam = _rand("eg", (N,), 0.05, ) + 0.1
+    resb = res.to(bf)
+    ref = resb.float() + rb(rb(acc) * gam)
+    check(eng.op_gemm(A, W, bias=bias, gamma=gam, resid=resb, tile_cfg=cfg), ref, 8e-3, "bf16 residual + gamma epilogue")
+    # SwiGLU on interleaved (gate, up) columns (Phi-3 gate_up_proj)
+    accn = rb(A.float() @ W.float().T)
+    g, u = accn[:, 0::2], accn[:, 1::2]
+    ref = u * rb(torch.nn.functional.silu(g))
+    check(eng.op_gemm(A, W, act=L.ACT_SILU_MUL, tile_cfg=cfg), ref, 8e-3, "silu-mul epilogue")
+
+
+def test_layernorm_rmsnorm(eng):
+    for rows, cols in ((37, 64), (1154, 1024), (9, 4096)):
+        x = _rand(f"ln{rows}", (rows, cols), 2.0) + 0.3
+        w = _rand(f"lnw{cols}", (cols,), 0.2) + 1.0
+        b = _rand(f"lnb{cols}", (cols,), 0.2)
+        ref = torch.nn.functional.layer_norm(x, (cols,), w, b, 1e-5)
+        check(eng.op_layernorm(x, w, b, 1e-5), ref, 5e-3, f"layernorm {rows}x{cols}")
+    for rows, cols in ((37, 64), (2049, 1408), (9, 3072), (3, 8192)):
+        x = _rand(f"rn{rows}", (rows, cols), 2.0).to(bf)
+        w = (_rand(f"rnw{cols}", (cols,), 0.2) + 1.0).to(bf)
+        xf = x.float()
+        ref = w.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(bf).float()
+        check(eng.op_rmsnorm(x, w, 1e-6), ref, 5e-3, f"rmsnorm {rows}x{cols}")
+
+
+@pytest.mark.parametrize("B,S,H,KV,Dr,causal", [(2, 77, 4, 4, 16, 0), (1, 577, 16, 16, 64, 0), (1, 513, 16, 16, 88, 0), (2, 64, 4, 4, 64, 0),
+                                                (1, 200, 8, 8, 96, 1), (1, 333, 8, 2, 128, 1), (1, 1000, 4, 4, 96, 1), (1, 65, 4, 4, 32, 1)])
+def test_attention(eng, B, S, H, KV, Dr, causal):
+    qkv = _rand(f"att{B}{S}{H}{Dr}", (B * S, (H + 2 * KV) * Dr), 1.0).to(bf)
+    scale = Dr ** -0.5
+    t = qkv.float().view(B, S, H + 2 * KV, Dr)
+    q, k, v = t[:, :, :H], t[:, :, H:H + KV], t[:, :, H + KV:]
+    q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
+    k = k.repeat_interleave(H // KV, dim=1)
+    v = v.repeat_interleave(H // KV, dim=1)
+    s = (q @ k.transpose(-1, -2)) * scale
+    if causal:
+        m = torch.ones(S, S, device=DEV, dtype=torch.bool).tril()
+        s = s.masked_fill(~m, float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * S, H * Dr)
+    got = eng.op_attention(qkv, B, S, H, KV, Dr, scale, causal)
+    check(got, ref, 1.5e-2, f"attention B{B} S{S} H{H}/{KV} D{Dr} causal{causal}")
+
+
+def test_attention_spike_forces_rescale(eng):
+    # one key dominates late in the sequence: the online-softmax rescale branch must fire (guide §5.4 rule 26)
+    B, S, H, Dr = 1, 300, 2, 64
+    qkv = _rand("spike", (S, 3 * H * Dr), 0.3)
+    qkv[250, H * Dr: 2 * H * Dr] *= 40.0
+    qkv = qkv.to(bf)
+    t = qkv.float().view(1, S, 3 * H, Dr)
+    q, k, v = (t[:, :, i * H:(i + 1) * H].transpose(1, 2) for i in range(3))
+    ref = (torch.softmax((q @ k.transpose(-1, -2)) * Dr ** -0.5, -1) @ v).transpose(1, 2).reshape(S, H * Dr)
+    check(eng.op_attention(qkv, B, S, H, H, Dr, Dr ** -0.5, 0), ref, 1.5e-2, "attention with a spiking key")
+
+
+@pytest.mark.parametrize("N,K", [(1000, 512), (32366, 3072), (9216, 3072), (3072, 8192), (7, 64)])
+def test_gemv(eng, N, K):
+    W = _rand(f"gv{N}", (N, K), K ** -0.5).to(bf)
+    x = _rand(f"gx{K}", (K,), 1.0).to(bf)
+    b = _rand(f"gb{N}", (N,), 0.3)
+    check(eng.op_gemv(W, x, b), W.float() @ x.float() + b, 2e-4, f"gemv {N}x{K}")

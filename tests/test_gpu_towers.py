@@ -1,0 +1,104 @@
+"""-m gpu: the vision towers + glue through the C ABI vs (a) the committed goldens produced by the
+reference's own modules and (b) the CPU oracle in bf16-emulation mode on the same seeded inputs.
+Tolerances: the HIP path computes in bf16 with fp32 accumulation (as the reference GPU path does);
+vs the fp32 goldens we allow 3e-2 of the output scale, vs the bf16-emulating oracle 2e-2."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gvl_oracle as O  # noqa: E402
+from conftest import load_golden  # noqa: E402
+from gpu_util import DEV, bf, check, tiny_geo  # noqa: E402
+from grounded_video_llm_amd import engine as E, weights as Wt, synth  # noqa: E402
+
+
+def _clip_engine(c, seed):
+    geo = tiny_geo(clip_hidden=c["hidden"], clip_inter=c["inter"], clip_layers=c["layers"], clip_heads=c["heads"], clip_image=c["image"],
+                   clip_patch=c["patch"], max_segs=2)
+    W = synth.clip_weights(c["hidden"], c["inter"], c["layers"], c["image"], c["patch"], seed=seed)
+    eng = E.Engine(geo, DEV, towers=("clip",))
+    eng.load_packed(Wt.pack_clip(W, c["layers"] - 1))
+    eng.finalize()
+    return eng, W
+
+
+@pytest.mark.parametrize("name,tol_g,tol_o", [("clip_tiny", 3e-2, 2e-2), ("clip_full_layer", 3e-2, 2e-2)])
+def test_clip(name, tol_g, tol_o):
+    meta, g = load_golden(name)
+    c = meta["cfg"]
+    eng, W = _clip_engine(c, meta["seed"])
+    px = synth.det_tensor(meta["px"], meta["px_shape"])
+    got = eng.clip_encode(px.to(DEV))
+    st = meta.get("stride", [1, 1])
+    check(got[:, ::st[0], ::st[1]], g["penultimate"], tol_g, f"{name} vs reference golden (fp32)")
+    ref = O.clip_penultimate(px, W, c["layers"], c["heads"], emu=True)
+    check(got, ref, tol_o, f"{name} vs oracle (bf16 emulation)")
+    eng.close()
+
+
+def _iv2_engine(c, seed, max_segs=2):
+    geo = tiny_geo(iv2_dim=c["dim"], iv2_inter=c["inter"], iv2_depth=c["depth"], iv2_heads=c["heads"], iv2_image=c["image"],
+                   frames_per_seg=c["frames"], max_segs=max_segs)
+    W = synth.iv2_weights(c["dim"], c["inter"], c["depth"], c["frames"], c["image"], 14, seed=seed)
+    eng = E.Engine(geo, DEV, towers=("iv2",))
+    eng.load_packed(Wt.pack_iv2(W, c["depth"] - 1, c["frames"]))
+    eng.finalize()
+    return eng, W
+
+
+@pytest.mark.parametrize("name", ["iv2_tiny", "iv2_full_block"])
+def test_iv2(name):
+    meta, g = load_golden(name)
+    c = meta["cfg"]
+    eng, W = _iv2_engine(c, meta["seed"])
+    px = synth.det_tensor(meta["px"], meta["px_shape"])
+    got = eng.iv2_encode(px.to(DEV))
+    st = meta.get("stride", [1, 1])
+    check(got[:, ::st[0], ::st[1]], g["out"], 3e-2, f"{name} vs reference golden (fp32)")
+    ref = O.iv2_encode(px, W, c["depth"], c["heads"], emu=True)
+    check(got, ref, 2e-2, f"{name} vs oracle (bf16 emulation)")
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["glue_phi3_5", "glue_llama3"])
+def test_encode_segments_and_splice(name):
+    """encode_images + prepare_multimodal_inputs on the 2-segment skeleton."""
+    meta, g = load_golden(name)
+    llm, hid = meta["llm"], meta["hidden"]
+    cc, vc = meta["clip"], meta["iv2"]
+    geo = E.TowerGeometry(llm=llm, clip_hidden=cc["hidden"], clip_inter=cc["inter"], clip_layers=cc["layers"], clip_heads=cc["heads"],
+                          iv2_dim=vc["dim"], iv2_inter=vc["inter"], iv2_depth=vc["depth"], iv2_heads=vc["heads"], frames_per_seg=vc["frames"],
+                          hidden=hid, inter=128, layers=1, heads=hid // 128, kv_heads=hid // 128, vocab=50, max_seq=1024, max_segs=2, kv_pages=16,
+                          max_prefill=1024, lm_head_bias=False, rope_orig_max_pos=0)
+    Wc = synth.clip_weights(cc["hidden"], cc["inter"], cc["layers"], 336, 14, seed="g.glue.clip")
+    Wv = synth.iv2_weights(vc["dim"], vc["inter"], vc["depth"], vc["frames"], 224, 14, seed="g.glue.iv2")
+    Wp = synth.projector_weights(llm, hid, 1024, 1408, seed="g.glue.proj." + llm)
+    emb_w = synth.det_tensor("g.glue.embed." + llm, (50, hid), 0.5)
+    Wl = synth.llm_weights(geo.kind, hid, 128, 1, hid // 128, hid // 128, 50, False, seed="g.glue.llm")
+    Wl["model.embed_tokens.weight"] = emb_w
+    eng = E.Engine(geo, DEV, towers=("clip", "iv2", "llm"))
+    eng.load_packed(Wt.pack_clip(Wc, cc["layers"] - 1))
+    eng.load_packed(Wt.pack_iv2(Wv, vc["depth"] - 1, vc["frames"]))
+    eng.load_packed(Wt.pack_projectors(Wp, llm))
+    eng.load_packed(Wt.pack_llm(Wl, geo.kind, 1, geo.heads, geo.kv_heads, geo.max_seq, geo.rope_theta))
+    eng.finalize()
+    assert eng.tokens_per_seg == (285 if llm == "phi3.5" else 193)
+    sp = synth.det_tensor("g.glue.sp", (1, 2, 3, 336, 336))
+    tp = synth.det_tensor("g.glue.tp", (1, 4, 3, 224, 224))
+    tseg = tp.reshape(1, 2, 2, 3, 224, 224).permute(0, 1, 3, 2, 4, 5).flatten(0, 1)        # (b s) c f h w
+    vis = eng.encode_segments(sp[0].to(DEV), tseg.to(DEV))
+    assert list(vis.shape) == meta["feats_shape"][1:]
+    s = meta["stride"]
+    check(vis[None][:, ::s[0], ::s[1]], g["feats"], 3e-2, f"{name}: encode_images vs reference golden")
+    ref = O.encode_images(sp, tp, Wc, Wv, Wp, llm, clip_layers=cc["layers"], clip_heads=cc["heads"], iv2_depth=vc["depth"], iv2_heads=vc["heads"], emu=True)
+    check(vis, ref[0], 2e-2, f"{name}: encode_images vs oracle (bf16 emulation)")
+    emb = eng.splice(meta["ids"], vis)
+    assert list(emb.shape) == meta["emb_shape"][1:]
+    check(emb[None][:, ::s[0], ::s[1]], g["emb"], 3e-2, f"{name}: spliced inputs_embeds vs reference golden")
+    # the text rows are pure gathers: bit-exact against the bf16 embedding table
+    idx = meta["ids"].index(-200)
+    assert torch.equal(emb[:idx].cpu(), emb_w.to(bf)[meta["ids"][:idx]])
+    assert torch.equal(emb[idx + vis.shape[0]:].cpu(), emb_w.to(bf)[meta["ids"][idx + 1:]])
+    assert torch.equal(emb[idx: idx + vis.shape[0]], vis)
+    eng.close()

@@ -1,0 +1,127 @@
+"""CPU tests of the product's host-side logic (no GPU): prompt/integer plumbing against the reference-generated
+goldens, the weight packer's layout transforms against the oracle's un-fused maths, and the C ABI surface."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import gvl_oracle as O
+from conftest import GOLDEN, ROOT
+from grounded_video_llm_amd import lib as L, prompts as P, synth, weights as Wt
+
+
+def test_prompts_against_reference_goldens():
+    g = json.load(open(os.path.join(GOLDEN, "integer_paths.json")))
+    for k, v in g["frame_indices"].items():
+        n, vlen = map(int, k.split("_"))
+        assert P.sample_frame_indices(n, vlen) == v, k
+    for k, v in g["prompts"].items():
+        llm, mode = k.split("|")
+        assert P.build_prompt(llm, mode, g["prompt_text"]) == v, k
+    for k, v in g["parse_time_interval"].items():
+        llm, txt, dur = k.split("|")
+        assert P.parse_time_interval(txt, float(dur), 300, llm) == v, k
+    for k, v in g["tokenizer_image_token"].items():
+        name, pr = k.split("|", 1)
+        def tok(s, nb=(name == "nobos")):
+            ids = [3 + (sum(map(ord, w)) % 90) for w in s.split()]
+            return ids if nb else [1] + ids
+        assert P.tokenize_with_image(pr, tok, 1) == v, k
+    assert P.spatial_indices(96, 12) == [4 + 8 * i for i in range(12)]
+    assert P.seconds_to_tokens("What is happening from 70 seconds to 80 seconds?", 118.3) == "What is happening from <177> to <202>?"
+    assert P.parse_time_interval("From <36> to <64>.", 118.3) == "From  14.20 seconds to  25.24 seconds."
+    assert len(P.temporal_token_strings(300)) == 302
+    # referring prompt == oracle's
+    q = "What is happening from 70 seconds to 80 seconds?"
+    assert P.build_prompt("phi3.5", "referring", q, 118.3) == O.build_prompt("phi3.5", "referring", q, 118.3)
+    with pytest.raises(ValueError):
+        P.parse_time_interval("<3>", 10.0, 300, "vicuna")
+
+
+def test_left_pad_truncate_matches_oracle():
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        batch = [rng.integers(3, 90, size=int(rng.integers(1, 30))).tolist() for _ in range(int(rng.integers(1, 4)))]
+        mx = int(rng.integers(4, 40))
+        a, am = P.left_pad_truncate(batch, 0, mx)
+        b, bm = O.left_pad_truncate(batch, 0, mx)
+        assert np.array_equal(a, b.numpy()) and np.array_equal(am, bm.numpy())
+
+
+def test_packer_fusions_are_exact():
+    # CLIP qkv fuse, Phi gate/up interleave, Llama q/k/v + gate/up fuse, LoRA merge, K padding, pos-embed interpolation
+    Wc = synth.clip_weights(64, 128, 2, 28, 14, seed="t.pack.clip")
+    pc = Wt.pack_clip(Wc, 1)
+    assert pc["clip.patch.w"].shape == (64, 640) and float(pc["clip.patch.w"][:, 588:].abs().max()) == 0.0
+    q = Wc["vision_model.encoder.layers.0.self_attn.q_proj.weight"].to(torch.bfloat16)
+    assert torch.equal(pc["clip.L0.qkv.w"][:64], q)
+    Wl = synth.llm_weights("phi3", 64, 128, 1, 4, 4, 50, True, seed="t.pack.phi")
+    pl = Wt.pack_llm(Wl, "phi3", 1, 4, 4, 128, 10000.0, *synth.longrope_factors(16))
+    gu = Wl["model.layers.0.mlp.gate_up_proj.weight"].to(torch.bfloat16)
+    assert torch.equal(pl["llm.L0.gu.w"][0::2], gu[:128]) and torch.equal(pl["llm.L0.gu.w"][1::2], gu[128:])
+    assert pl["rope.cos_s"].shape == (128, 8) and "rope.cos_l" in pl
+    ocfg = O.LLMConfig("phi3", 64, 128, 1, 4, 4, 50, 1e-5, 10000.0, 131072, 4096, *synth.longrope_factors(16))
+    cos, sin = O.rope_cos_sin(ocfg, torch.arange(128), 128, emu=True)
+    assert torch.equal(pl["rope.cos_s"], cos[:, :8]) and torch.equal(pl["rope.sin_s"], sin[:, :8])
+    cosl, _ = O.rope_cos_sin(ocfg, torch.arange(128), 5000, emu=True)
+    assert torch.equal(pl["rope.cos_l"], cosl[:, :8])
+    Wm = synth.llm_weights("llama", 64, 128, 1, 4, 2, 50, True, seed="t.pack.llama")
+    pm = Wt.pack_llm(Wm, "llama", 1, 4, 2, 64, 500000.0)
+    assert pm["llm.L0.qkv.w"].shape == (64 + 32 + 32, 64) and "rope.cos_l" not in pm
+    # LoRA: peft-style keys merged == oracle's un-merged maths
+    A, B = synth.det_tensor("t.lora.A", (8, 64), 0.1), synth.det_tensor("t.lora.B", (192, 8), 0.1)
+    Wp = {("base_model.model." + k): v for k, v in Wl.items()}
+    Wp["base_model.model.model.layers.0.self_attn.qkv_proj.lora_A.default.weight"] = A
+    Wp["base_model.model.model.layers.0.self_attn.qkv_proj.lora_B.default.weight"] = B
+    pp = Wt.pack_llm(Wp, "phi3", 1, 4, 4, 128, 10000.0, lora_alpha=16.0, lora_r=8)
+    want = O.lora_merge(Wl["model.layers.0.self_attn.qkv_proj.weight"], A, B, 16.0, 8).to(torch.bfloat16)
+    assert torch.equal(pp["llm.L0.qkv.w"], want)
+    # pos-embed interpolation == oracle == reference golden
+    z = np.load(os.path.join(GOLDEN, "iv2_pos_interp.npz"))
+    meta = json.loads(str(z["meta"]))
+    src = synth.det_tensor(meta["src"], meta["src_shape"])
+    np.testing.assert_allclose(Wt.interpolate_pos_embed_t(src, 4, 8).numpy(), z["pos"], atol=1e-6)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libgvl.so must load (no GPU needed) and export exactly what include/gvl.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "gvl.h")).read()
+    declared = sorted(set(re.findall(r"\b(gvl_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    lib = L.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in gvl.h but not exported"
+    assert sorted(L.EXPORTS) == declared, "lib.py binds a different set of symbols than gvl.h declares"
+    out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r" T (gvl_[a-z_0-9]+)", out)))
+    assert exported == declared
+    # the struct layout the Python side uses matches the header's field count
+    n_fields = len(re.findall(r"^\s*(?:int32_t|float)\s+[^;]+;", hdr.split("typedef struct {")[1].split("} gvl_config;")[0], re.M))
+    assert n_fields >= 10 and ctypes.sizeof(L.GvlConfig) == 4 * len(L.GvlConfig._fields_)
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = L.load()
+    cfg = L.GvlConfig()
+    h = ctypes.c_void_p()
+    rc = lib.gvl_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert rc == -5 and b"no CPU fallback" in lib.gvl_last_error(None)
+    from grounded_video_llm_amd import engine as E
+    with pytest.raises(RuntimeError):
+        E.Engine(E.TowerGeometry(), "cpu")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "grounded-video-llm_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "gvl_oracle" not in src and "oracle/" not in src.replace("the oracle", ""), f"{f} references the oracle"

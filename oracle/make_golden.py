@@ -196,8 +196,9 @@ def g_glue(ns):
         c._attn_implementation = "eager"
         Wc = synth.clip_weights(1024, 256, 2, 336, 14, seed="g.glue.clip")
         sk.vision_tower = load_into(ns.clip.CLIPVisionModel(c), Wc)
-        Wv = synth.iv2_weights(1408, 352, 3, 2, 224, 14, seed="g.glue.iv2")
-        sk.video_encoder = load_into(_iv2(ns, 1408, 3, 16, 0.25, 224, 2), Wv, _IV2_EXTRA)
+        Wv = synth.iv2_weights(1408, 384, 3, 2, 224, 14, seed="g.glue.iv2")
+        sk.video_encoder = load_into(_iv2(ns, 1408, 3, 16, 3 / 11, 224, 2), Wv, _IV2_EXTRA)
+        assert sk.video_encoder.blocks[0].mlp.fc1.weight.shape[0] == 384
         Wp = synth.projector_weights(llm, hid, 1024, 1408, seed="g.glue.proj." + llm)
         sk.video_projecter = load_into(L.Video_Projecter(1408, hid), {k[len("video_projecter."):]: v for k, v in Wp.items() if k.startswith("video_projecter.")})
         mm = {k[len("multi_modal_projector."):]: v for k, v in Wp.items() if k.startswith("multi_modal_projector.")}
@@ -220,7 +221,7 @@ def g_glue(ns):
         emb, _, mask = sk.prepare_multimodal_inputs(ids, ids.clone(), torch.ones_like(ids), feats, ["vid"])
         st = [3, 16]
         save("glue_" + llm.replace(".", "_"), dict(llm=llm, hidden=hid, clip=dict(hidden=1024, inter=256, layers=2, heads=16),
-                                                   iv2=dict(dim=1408, inter=352, depth=3, heads=16, frames=2), ids=ids[0].tolist(),
+                                                   iv2=dict(dim=1408, inter=384, depth=3, heads=16, frames=2), ids=ids[0].tolist(),
                                                    stride=st, feats_shape=list(feats.shape), emb_shape=list(emb.shape)),
              feats=feats[:, ::st[0], ::st[1]], emb=emb[:, ::st[0], ::st[1]], mask=mask)
 

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
           const int n = n0 + r;
           if (n + 1 < a.N) {
             const float g = rbf(acc[r]), u = rbf(acc[r + 1]);
-            const float o = u * rbf(g / (1.f + __expf(-g)));
+            const float o = u * rbf(g * fast_sigmoid(g));
             if (a.out_bf16) a.out_bf16[n >> 1] = f2bf(o);
             if (a.out_f32) a.out_f32[n >> 1] = o;
           }

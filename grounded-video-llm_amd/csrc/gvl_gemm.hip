@@ -20,7 +20,7 @@
 
 #define BK 64  // K tile (bf16 elements) == one 128-byte LDS row
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
   constexpr int NWAVES = WAVES_M * WAVES_N;
   constexpr int NT = NWAVES * 64;
@@ -96,18 +96,46 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
     __syncthreads();  // ... and everybody's; all waves are also done reading buf (t+1)&1
     if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
     const char* sb = smem + (t & 1) * STAGE_BYTES;
+    if constexpr (PIPE == 0) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int coff = ((kk * 2 + h) ^ swz) << 4;
-      bf16x8_t wf[NB], af[MB];
+      for (int kk = 0; kk < 4; ++kk) {
+        const int coff = ((kk * 2 + h) ^ swz) << 4;
+        bf16x8_t wf[NB], af[MB];
 #pragma unroll
-      for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
+        for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
 #pragma unroll
-      for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
+        for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
 #pragma unroll
-      for (int i = 0; i < NB; ++i)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // register double buffer: the ds_reads of k-step kk+1 are in flight while the MFMAs of kk issue
+      bf16x8_t wf[2][NB], af[2][MB];
+      {
+        const int coff = ((0 * 2 + h) ^ swz) << 4;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) wf[0][i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
+#pragma unroll
+        for (int j = 0; j < MB; ++j) af[0][j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {
+          const int coff = (((kk + 1) * 2 + h) ^ swz) << 4;
+#pragma unroll
+          for (int i = 0; i < NB; ++i) wf[(kk + 1) & 1][i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
+#pragma unroll
+          for (int j = 0; j < MB; ++j) af[(kk + 1) & 1][j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
+        }
+        if constexpr (PIPE == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+          for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][i], af[kk & 1][j], acc[i][j], 0, 0, 0);
+        if constexpr (PIPE == 1) __builtin_amdgcn_s_setprio(0);
+      }
     }
   }
 
@@ -135,7 +163,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const float g = rbf(v[2 * e]), u = rbf(v[2 * e + 1]);
-            const float sg = rbf(g / (1.f + __expf(-g)));
+            const float sg = rbf(g * fast_sigmoid(g));
             o2[e] = u * sg;
           }
           bf16_t* cp = (bf16_t*)a.C + orow * a.ldc + (n >> 1);
@@ -147,11 +175,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
           float x = v[e];
           if (a.act == GVL_ACT_QUICK_GELU) {
             x = rbf(x);
-            const float s = rbf(1.f / (1.f + __expf(-rbf(1.702f * x))));
+            const float s = rbf(fast_sigmoid(rbf(1.702f * x)));
             x = x * s;
           } else if (a.act == GVL_ACT_GELU) {
             x = rbf(x);
-            x = 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+            x = gelu_erf(x);
           }
           v[e] = x;
         }
@@ -184,12 +212,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int LDS = 2 * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N>;
+  auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, PIPE>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
     attr_set = true;
@@ -215,9 +243,14 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
     else cfg = 1;
   }
   switch (cfg) {
-    case 1: return launch_cfg<128, 128, 2, 2>(a, st);
-    case 2: return launch_cfg<256, 256, 4, 2>(a, st);
-    case 3: return launch_cfg<256, 128, 4, 2>(a, st);
+    case 1: return launch_cfg<128, 128, 2, 2, 0>(a, st);
+    case 2: return launch_cfg<256, 256, 4, 2, 0>(a, st);
+    case 3: return launch_cfg<256, 128, 4, 2, 0>(a, st);
+    case 11: return launch_cfg<128, 128, 2, 2, 1>(a, st);
+    case 12: return launch_cfg<256, 256, 4, 2, 1>(a, st);
+    case 13: return launch_cfg<256, 128, 4, 2, 1>(a, st);
+    case 14: return launch_cfg<256, 256, 2, 4, 1>(a, st);
+    case 15: return launch_cfg<128, 256, 2, 4, 1>(a, st);
     default: return -1;
   }
 }

@@ -14,16 +14,28 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 #define GVL_KV_PAGE 64          // tokens per KV page == key tile of the attention kernels
 
 // ---- device helpers ---------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even (inputs are finite)
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// float -> bf16 round-to-nearest-even: the (__bf16) cast lowers to v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ bf16_t f2bf(float f) { const __bf16 b = (__bf16)f; return __builtin_bit_cast(unsigned short, b); }
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
 }
-__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }  // round through bf16
+__device__ __forceinline__ float rbf(float f) { return (float)(__bf16)f; }  // round through bf16
+// fast transcendental helpers for epilogues (errors << bf16 resolution)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_erf(float x) {   // Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = 1.f - p * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + fast_erf(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float lo_bf(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_bf(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 

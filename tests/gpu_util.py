@@ -39,3 +39,11 @@ def llm_engine(geo, W, towers=("llm",)):
     eng.load_packed(packed)
     eng.finalize()
     return eng
+
+
+def check_bf16_class(got, ref32, ref_emu, floor, what=""):
+    """The HIP path must be as close to the fp32 truth as a bf16 implementation of the reference can be:
+    err(HIP, fp32) <= max(floor, 2.5 * err(bf16-emulating oracle, fp32))."""
+    e_emu = rel_err(ref_emu, ref32)
+    tol = max(floor, 2.5 * e_emu)
+    return check(got, ref32, tol, what + f" [bf16-emulation itself is {e_emu:.2e} from fp32]")

@@ -83,7 +83,7 @@ def test_encode_segments_and_splice(name):
     eng.load_packed(Wt.pack_projectors(Wp, llm))
     eng.load_packed(Wt.pack_llm(Wl, geo.kind, 1, geo.heads, geo.kv_heads, geo.max_seq, geo.rope_theta))
     eng.finalize()
-    assert eng.tokens_per_seg == (285 if llm == "phi3.5" else 193)
+    assert eng.tokens_per_seg == (156 if llm == "phi3.5" else 64) + 16 * vc["frames"] + 1      # 285 / 193 at 8 frames per segment
     sp = synth.det_tensor("g.glue.sp", (1, 2, 3, 336, 336))
     tp = synth.det_tensor("g.glue.tp", (1, 4, 3, 224, 224))
     tseg = tp.reshape(1, 2, 2, 3, 224, 224).permute(0, 1, 3, 2, 4, 5).flatten(0, 1)        # (b s) c f h w

@@ -1,0 +1,47 @@
+"""GEMM micro-benchmark over the hot-path shapes (run on the GPU box): TFLOP/s per tile configuration."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _gvl_bootstrap  # noqa
+from grounded_video_llm_amd import engine as E
+
+SHAPES = [  # (name, M, N, K)
+    ("clip.qkv", 6924, 3072, 1024), ("clip.out", 6924, 1024, 1024), ("clip.fc1", 6924, 4096, 1024), ("clip.fc2", 6924, 1024, 4096),
+    ("iv2.qkv", 24588, 4224, 1408), ("iv2.proj", 24588, 1408, 1408), ("iv2.fc1", 24588, 6144, 1408), ("iv2.fc2", 24588, 1408, 6144),
+    ("phi.qkv", 3519, 9216, 3072), ("phi.o", 3519, 3072, 3072), ("phi.gu", 3519, 16384, 3072), ("phi.down", 3519, 3072, 8192),
+    ("sq4096", 4096, 4096, 4096), ("sq8192", 8192, 8192, 8192),
+]
+CFGS = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,3,11,12,13,14,15".split(","))]
+
+
+def main():
+    eng = E.Engine(E.TowerGeometry(max_segs=1), "cuda:0", towers=())
+    res = {}
+    for name, M, N, K in SHAPES:
+        A = torch.randn((M, K), device="cuda").to(torch.bfloat16)
+        W = (torch.randn((N, K), device="cuda") * K ** -0.5).to(torch.bfloat16)
+        row = {}
+        for cfg in CFGS:
+            for _ in range(2):
+                eng.op_gemm(A, W, tile_cfg=cfg)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 10
+            e0.record()
+            for _ in range(n):
+                eng.op_gemm(A, W, tile_cfg=cfg)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            row[cfg] = round(2.0 * M * N * K / (ms * 1e-3) / 1e12, 1)
+        res[name] = row
+        print(name, (M, N, K), row, flush=True)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
   __shared__ __attribute__((aligned(16))) float part_s[4][64 * CPR];
   __shared__ __attribute__((aligned(16))) float p_s[4][64];
   __shared__ float red_s[4][D + 2];
+  __shared__ int last_s;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int head = blockIdx.x, split = blockIdx.y;
@@ -277,16 +278,19 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
     const size_t pb = ((size_t)a.block_table[pg] * a.KV + hkv) * (size_t)(64 * D);
     const bf16_t* kp = a.Kt + pb;
     const bf16_t* vp = a.Vt + pb;
-    // partial dots, fully coalesced 16-byte loads
+    // the whole page (K and V^T) is requested up front: 2*NIT fully coalesced 16-byte loads in flight per lane
+    u32x4_t kv[NIT], vv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) kv[it] = __builtin_nontemporal_load((const u32x4_t*)(kp + (it * 64 + lane) * 8));
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) vv[it] = __builtin_nontemporal_load((const u32x4_t*)(vp + (it * 64 + lane) * 8));
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = it * 64 + lane;
-      const int dch = c % CPR;
-      const u32x4_t kv = *(const u32x4_t*)(kp + c * 8);
-      const float* qq = q_s + dch * 8;
+      const float* qq = q_s + (c % CPR) * 8;
       float acc = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc += lo_bf(kv[e]) * qq[2 * e] + hi_bf(kv[e]) * qq[2 * e + 1];
+      for (int e = 0; e < 4; ++e) acc += lo_bf(kv[it][e]) * qq[2 * e] + hi_bf(kv[it][e]) * qq[2 * e + 1];
       part_s[wave][c] = acc;
     }
     __builtin_amdgcn_wave_barrier();
@@ -301,17 +305,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
     m_run = m_new;
     const float p = __builtin_amdgcn_exp2f(sv - m_new);
     l_run = l_run * alpha + wave_sum(p);
-    // the reference multiplies bf16 probabilities into V (flash-attn / eager .to(v.dtype))
-    p_s[wave][lane] = rbf(p);
+    p_s[wave][lane] = rbf(p);                       // the reference multiplies bf16 probabilities into V
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = it * 64 + lane;                 // chunk of V^T: d = c/8, keys 8*(c%8)..+7
-      const u32x4_t vv = *(const u32x4_t*)(vp + c * 8);
       const float* pp = p_s[wave] + (c & 7) * 8;
       float acc = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc += lo_bf(vv[e]) * pp[2 * e] + hi_bf(vv[e]) * pp[2 * e + 1];
+      for (int e = 0; e < 4; ++e) acc += lo_bf(vv[it][e]) * pp[2 * e] + hi_bf(vv[it][e]) * pp[2 * e + 1];
       acc += __shfl_xor(acc, 1, 64);
       acc += __shfl_xor(acc, 2, 64);
       acc += __shfl_xor(acc, 4, 64);
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
     }
     __builtin_amdgcn_wave_barrier();
   }
-  // combine the 4 waves
+  // combine the 4 waves of this block
   if ((lane & 7) == 0) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) red_s[wave][it * 8 + (lane >> 3)] = oacc[it];
@@ -340,27 +342,36 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
     for (int w = 0; w < 4; ++w) l += red_s[w][D + 1] * __builtin_amdgcn_exp2f(red_s[w][D] - mm);
     outp[D] = mm; outp[D + 1] = l;
   }
-}
-
-template <int D>
-__global__ void decode_attn_combine_kernel(const float* part, bf16_t* out, int nsplit, int Dout) {
-  const int head = blockIdx.x, d = threadIdx.x;
-  const float* pp = part + (size_t)head * nsplit * (D + 2);
-  float mm = -1e30f;
-  for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, pp[s * (D + 2) + D]);
-  float l = 0.f, acc = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float w = __builtin_amdgcn_exp2f(pp[s * (D + 2) + D] - mm);
-    l += pp[s * (D + 2) + D + 1] * w;
-    if (d < D) acc += pp[s * (D + 2) + d] * w;
+  // ---- the last split block of this head to arrive merges the partials (placement-independent hand-off:
+  //      agent-scope release by every producer, one agent-scope acquire by the consumer; guide G16) ----------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(a.counters + head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = (t == a.nsplit - 1);
   }
-  if (d < Dout) out[head * Dout + d] = f2bf(acc / l);
+  __syncthreads();
+  if (!last_s) return;
+  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  const float* pp = a.part + (size_t)head * a.nsplit * (D + 2);
+  float gm = -1e30f;
+  for (int s2 = 0; s2 < a.nsplit; ++s2) gm = fmaxf(gm, pp[s2 * (D + 2) + D]);
+  float l = 0.f, acc = 0.f;
+  for (int s2 = 0; s2 < a.nsplit; ++s2) {
+    const float w = __builtin_amdgcn_exp2f(pp[s2 * (D + 2) + D] - gm);
+    l += pp[s2 * (D + 2) + D + 1] * w;
+    if (tid < D) acc += pp[s2 * (D + 2) + tid] * w;
+  }
+  if (tid < a.Dout) a.out[head * a.Dout + tid] = f2bf(acc / l);
+  if (tid == 0) __hip_atomic_store(a.counters + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
 }
 
 template <int D>
 static int launch_decode(const DecodeAttnArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(decode_attn_kernel<D>, dim3(a.H, a.nsplit), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(decode_attn_combine_kernel<D>, dim3(a.H), dim3(D), 0, st, a.part, a.out, a.nsplit, a.Dout);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

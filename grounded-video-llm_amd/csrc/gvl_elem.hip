@@ -225,68 +225,94 @@ int gvl_launch_iv2_embed(const bf16_t* patch, const bf16_t* cls, const bf16_t* p
 //   mode 2: RoPE (models/modeling_phi3.py:413-445; cos/sin tables hold the bf16-rounded values of :397-409)
 // one block per token row.
 // =====================================================================================================
+template <int WPR>   // waves per token row: 1 -> 4 rows per block (bulk), 4 -> one row per block (decode)
 __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
-  __shared__ float red[8];
-  const int row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = WPR == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+  if (row >= a.B * a.S) return;                     // no block-level barrier below
+  constexpr int TEAM = 64 * WPR;
+  const int lt = WPR == 1 ? lane : tid;
   const int b = row / a.S, s_in = row - b * a.S;
-  const int tid = threadIdx.x;
   const bf16_t* qr = a.qkv + (size_t)row * a.ld;
   const bf16_t* kr = qr + a.H * a.Dr;
   const bf16_t* vr = kr + a.KV * a.Dr;
-  const int half = a.Dr >> 1;
+  const int half = a.Dr >> 1, cpr = a.Dr >> 3, cpd = a.D >> 3, hc = half >> 3;
+  const int nq = a.H * cpr, nk = a.KV * cpr;
 
   float q_rs = 1.f, k_rs = 1.f;
-  if (a.mode == 1) {
+  if (a.mode == 1) {                                // full-width RMS statistics (WPR == 1: one wave owns the row)
     float sq = 0.f, sk = 0.f;
-    for (int i = tid; i < a.H * a.Dr; i += 256) { const float v = bf2f(qr[i]); sq += v * v; }
-    for (int i = tid; i < a.KV * a.Dr; i += 256) { const float v = bf2f(kr[i]); sk += v * v; }
-    sq = wave_sum(sq); sk = wave_sum(sk);
-    if ((tid & 63) == 0) { red[tid >> 6] = sq; red[4 + (tid >> 6)] = sk; }
-    __syncthreads();
-    q_rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (a.H * a.Dr) + a.eps);
-    k_rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (a.KV * a.Dr) + a.eps);
+    for (int c = lane; c < nq; c += 64) {
+      const u32x4_t v = *(const u32x4_t*)(qr + c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float x = lo_bf(v[e]), y = hi_bf(v[e]); sq += x * x + y * y; }
+    }
+    for (int c = lane; c < nk; c += 64) {
+      const u32x4_t v = *(const u32x4_t*)(kr + c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float x = lo_bf(v[e]), y = hi_bf(v[e]); sk += x * x + y * y; }
+    }
+    q_rs = rsqrtf(wave_sum(sq) / (a.H * a.Dr) + a.eps);
+    k_rs = rsqrtf(wave_sum(sk) / (a.KV * a.Dr) + a.eps);
   }
-  int pos = a.pos0 + s_in;                     // token position (RoPE, cache slot)
+  int pos = a.pos0 + s_in;                          // token position (RoPE, cache slot)
   if (a.pos_ptr) pos = *a.pos_ptr;
   const float* cosp = a.cos; const float* sinp = a.sin;
   if (a.mode == 2 && a.rope_switch > 0 && pos + 1 > a.rope_switch) { cosp = a.cos_l; sinp = a.sin_l; }
-  const int s_tok = a.pos_ptr ? pos : a.pos0 + s_in;   // index in the sequence's KV space
   const int n_tiles = (a.S + 63) >> 6;
-  const int tile = s_tok >> 6, slot = s_tok & 63;
+  const int tile = pos >> 6, slot = pos & 63;
   const int page = a.block_table ? a.block_table[b * a.max_pages + tile] : b * n_tiles + tile;
 
-  auto xform = [&](const bf16_t* src, int hd, int d, float rs, const bf16_t* nw) -> float {
-    const float v = bf2f(src[hd * a.Dr + d]);
-    if (a.mode == 1) return bf2f(nw[hd * a.Dr + d]) * rbf(v * rs);
-    if (a.mode == 2) {
-      const int j = d < half ? d : d - half;
-      const float c = cosp[(size_t)pos * half + j], sn = sinp[(size_t)pos * half + j];
-      const float other = d < half ? -bf2f(src[hd * a.Dr + d + half]) : bf2f(src[hd * a.Dr + d - half]);
-      return rbf(v * c) + rbf(other * sn);
+  // one 16-byte chunk (8 elements) of q or k -> transformed chunk
+  auto xform = [&](const bf16_t* src, int c, float rs, const bf16_t* nw) -> u32x4_t {
+    const u32x4_t v = *(const u32x4_t*)(src + c * 8);
+    if (a.mode == 0) return v;
+    u32x4_t o;
+    if (a.mode == 1) {
+      const u32x4_t w = *(const u32x4_t*)(nw + c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack2bf(lo_bf(w[e]) * rbf(lo_bf(v[e]) * rs), hi_bf(w[e]) * rbf(hi_bf(v[e]) * rs));
+      return o;
     }
-    return v;
+    const int dc = c % cpr;                          // chunk inside the head
+    const bool first = dc < hc;
+    const u32x4_t p = *(const u32x4_t*)(src + (first ? c + hc : c - hc) * 8);   // rotate_half partner
+    const int j0 = (first ? dc : dc - hc) * 8;
+    const float* cp = cosp + (size_t)pos * half + j0;
+    const float* sp = sinp + (size_t)pos * half + j0;
+    const f32x4_t c0 = *(const f32x4_t*)cp, c1 = *(const f32x4_t*)(cp + 4), s0 = *(const f32x4_t*)sp, s1 = *(const f32x4_t*)(sp + 4);
+    const float sg = first ? -1.f : 1.f;
+    const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+    const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x0 = lo_bf(v[e]), x1 = hi_bf(v[e]), p0 = sg * lo_bf(p[e]), p1 = sg * hi_bf(p[e]);
+      o[e] = pack2bf(rbf(x0 * cc[2 * e]) + rbf(p0 * ss[2 * e]), rbf(x1 * cc[2 * e + 1]) + rbf(p1 * ss[2 * e + 1]));
+    }
+    return o;
   };
-  // Q
-  const int dq = a.D >> 1;
-  bf16_t* Qrow_base = a.Q + ((size_t)b * a.H * a.S + s_in) * a.D;     // + head*S*D
-  for (int i = tid; i < a.H * dq; i += 256) {
-    const int hd = i / dq, d = (i - hd * dq) * 2;
-    unsigned o = 0;
-    if (d < a.Dr) o = pack2bf(xform(qr, hd, d, q_rs, a.qn), xform(qr, hd, d + 1, q_rs, a.qn));
-    *(unsigned*)(Qrow_base + (size_t)hd * a.S * a.D + d) = o;
+  const u32x4_t zero = {0u, 0u, 0u, 0u};
+  // Q [B][H][S][D]
+  bf16_t* Qb = a.Q + ((size_t)b * a.H * a.S + s_in) * a.D;
+  for (int c = lt; c < nq; c += TEAM) {
+    const int hd = c / cpr, dc = c - hd * cpr;
+    *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + dc * 8) = xform(qr, c, q_rs, a.qn);
   }
-  // K
-  bf16_t* Kbase = a.Kt + ((size_t)page * a.KV) * (64 * a.D) + (size_t)slot * a.D;
-  for (int i = tid; i < a.KV * dq; i += 256) {
-    const int hd = i / dq, d = (i - hd * dq) * 2;
-    unsigned o = 0;
-    if (d < a.Dr) o = pack2bf(xform(kr, hd, d, k_rs, a.kn), xform(kr, hd, d + 1, k_rs, a.kn));
-    *(unsigned*)(Kbase + (size_t)hd * (64 * a.D) + d) = o;
+  // K page row [page][KV][64][D]
+  bf16_t* Kb = a.Kt + ((size_t)page * a.KV) * (64 * a.D) + (size_t)slot * a.D;
+  for (int c = lt; c < nk; c += TEAM) {
+    const int hd = c / cpr, dc = c - hd * cpr;
+    *(u32x4_t*)(Kb + (size_t)hd * (64 * a.D) + dc * 8) = xform(kr, c, k_rs, a.kn);
+  }
+  if (cpd > cpr) {                                   // zero the head-dim padding (88 -> 96)
+    const int np = cpd - cpr;
+    for (int c = lt; c < a.H * np; c += TEAM) { const int hd = c / np; *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + (cpr + c % np) * 8) = zero; }
+    for (int c = lt; c < a.KV * np; c += TEAM) { const int hd = c / np; *(u32x4_t*)(Kb + (size_t)hd * (64 * a.D) + (cpr + c % np) * 8) = zero; }
   }
   // V^T column of this single row (decode).  Bulk rows go through v_transpose_kernel.
   if (a.pos_ptr) {
     bf16_t* Vbase = a.Vt + ((size_t)page * a.KV) * (64 * a.D) + slot;
-    for (int i = tid; i < a.KV * a.Dr; i += 256) {
+    for (int i = lt; i < a.KV * a.Dr; i += TEAM) {
       const int hd = i / a.Dr, d = i - hd * a.Dr;
       Vbase[(size_t)hd * (64 * a.D) + d * 64] = vr[i];
     }
@@ -322,9 +348,14 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const QkvPostArgs a) {
 }
 
 int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st) {
-  if (a.Dr & 1 || a.D < a.Dr || a.Dr > 128) return -1;
+  if ((a.Dr & 7) || (a.mode == 2 && (a.Dr & 15)) || (a.D & 7) || a.D < a.Dr || a.Dr > 128 || (a.ld & 7)) return -1;   // 16-byte chunks; rotate_half partner chunk-aligned
   const int rows = a.B * a.S;
-  hipLaunchKernelGGL(qkv_post_kernel, dim3(rows), dim3(256), 0, st, a);
+  if (a.pos_ptr) {
+    if (rows != 1 || a.mode != 2) return -1;
+    hipLaunchKernelGGL(qkv_post_kernel<4>, dim3(1), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(qkv_post_kernel<1>, dim3((rows + 3) / 4), dim3(256), 0, st, a);
+  }
   if (!a.pos_ptr) {
     const int n_tiles = (a.S + 63) >> 6;
     hipLaunchKernelGGL(v_transpose_kernel, dim3(n_tiles, a.KV, a.B), dim3(256), 0, st, a);
@@ -485,6 +516,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K8 = a.K >> 3;
+  const int n0 = (blockIdx.x * 4 + wave) * R;
+  const bf16_t* wp[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { int n = n0 + r; if (n > a.N - 1) n = a.N - 1; wp[r] = a.W + (size_t)n * a.K; }
+  // the first weight chunks do not depend on x: request them before the (latency-bound) x / RMSNorm prologue
+  u32x4_t w0[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) w0[r] = __builtin_nontemporal_load((const u32x4_t*)(wp[r] + (lane < K8 ? lane : 0) * 8));
+
   if (a.norm_w) {
     float s = 0.f;
     for (int c = tid; c < K8; c += 256) {
@@ -508,17 +548,20 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     for (int c = tid; c < K8; c += 256) *(u32x4_t*)(xs + c * 8) = *(const u32x4_t*)(a.x + c * 8);
   }
   __syncthreads();
-
-  const int n0 = (blockIdx.x * 4 + wave) * R;
   if (n0 >= a.N) return;
+
   float acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = 0.f;
-  const bf16_t* wp[R];
+  if (lane < K8) {
+    const u32x4_t xv = *(const u32x4_t*)(xs + lane * 8);
 #pragma unroll
-  for (int r = 0; r < R; ++r) { int n = n0 + r; if (n > a.N - 1) n = a.N - 1; wp[r] = a.W + (size_t)n * a.K; }
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[r] += lo_bf(w0[r][e]) * lo_bf(xv[e]) + hi_bf(w0[r][e]) * hi_bf(xv[e]);
+  }
 #pragma unroll 2
-  for (int c = lane; c < K8; c += 64) {
+  for (int c = lane + 64; c < K8; c += 64) {
     u32x4_t wv[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) wv[r] = __builtin_nontemporal_load((const u32x4_t*)(wp[r] + c * 8));
@@ -532,7 +575,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
   if (lane == 0) {
     if (a.act == GVL_ACT_SILU_MUL) {
-      if constexpr (R >= 2) {
+      if constexpr ((R & 1) == 0) {
 #pragma unroll
         for (int r = 0; r < R; r += 2) {
           const int n = n0 + r;
@@ -563,14 +606,20 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 int gvl_launch_gemv(const GemvArgs& a, hipStream_t st) {
   if (a.K % 8 || a.K > 32768) return -1;
   const size_t lds = (size_t)a.K * 2;
-  int R = 4;
-  while (R > 1 && (a.N + 4 * R - 1) / (4 * R) < 512) R >>= 1;
-  if (a.act == GVL_ACT_SILU_MUL && R < 2) R = 2;
+  // rows per wave: aim at ~768-1024 blocks (3-4 per CU, all co-resident) so the weight stream has no tail
+  int R = (a.N + 4 * 1024 - 1) / (4 * 1024);
+  if (R < 1) R = 1;
+  if (R == 5) R = 6;
+  if (R == 7 || R > 8) R = 8;
+  if (a.act == GVL_ACT_SILU_MUL && (R & 1)) R += 1;
   const int blocks = (a.N + 4 * R - 1) / (4 * R);
   switch (R) {
-    case 4: hipLaunchKernelGGL(gemv_kernel<4>, dim3(blocks), dim3(256), lds, st, a); break;
+    case 1: hipLaunchKernelGGL(gemv_kernel<1>, dim3(blocks), dim3(256), lds, st, a); break;
     case 2: hipLaunchKernelGGL(gemv_kernel<2>, dim3(blocks), dim3(256), lds, st, a); break;
-    default: hipLaunchKernelGGL(gemv_kernel<1>, dim3(blocks), dim3(256), lds, st, a); break;
+    case 3: hipLaunchKernelGGL(gemv_kernel<3>, dim3(blocks), dim3(256), lds, st, a); break;
+    case 4: hipLaunchKernelGGL(gemv_kernel<4>, dim3(blocks), dim3(256), lds, st, a); break;
+    case 6: hipLaunchKernelGGL(gemv_kernel<6>, dim3(blocks), dim3(256), lds, st, a); break;
+    default: hipLaunchKernelGGL(gemv_kernel<8>, dim3(blocks), dim3(256), lds, st, a); break;
   }
   return CHECK_LAUNCH();
 }

@@ -38,7 +38,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int tm = vid / tiles_n, tn = vid - tm * tiles_n;
+  // grouped rasterisation: consecutive tiles walk DOWN a band of GM tile-rows before moving to the next tile
+  // column, so the ~32 blocks resident on one XCD form an (8 x 4)-tile patch that re-reads 8 A-panels and
+  // 4 W-panels from that XCD's L2 instead of 1 + 32 panels.
+  constexpr int GM = 8;
+  const int band = GM * tiles_n;
+  const int g = vid / band, first_m = g * GM;
+  const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+  const int in_band = vid - g * band;
+  const int tm = first_m + in_band % gm, tn = in_band / gm;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int tid = threadIdx.x;

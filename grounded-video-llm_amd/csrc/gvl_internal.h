@@ -93,6 +93,7 @@ struct DecodeAttnArgs {
   const int* block_table; // [max_pages]
   const int* pos_ptr;     // device: index of the new token (the cache holds *pos_ptr + 1 tokens, new one included)
   float* part;            // workspace [H][nsplit][D+2]
+  int* counters;          // [H] arrival tickets, zero between launches (the merging block re-arms them)
   bf16_t* out;            // [H*Dout]
   int H, KV, D, Dout, nsplit;
   float scale;

@@ -65,7 +65,7 @@ struct gvl_ctx {
   std::vector<Seq> seqs;
   // decode buffers
   bf16_t *d_x = nullptr, *d_qkv = nullptr, *d_q = nullptr, *d_attn = nullptr, *d_act = nullptr;
-  float *d_logits = nullptr, *d_part = nullptr; int *d_tok = nullptr, *d_step = nullptr, *d_outlist = nullptr, *d_ids = nullptr;
+  float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_tok = nullptr, *d_step = nullptr, *d_outlist = nullptr, *d_ids = nullptr;
   int nsplit = 16, outlist_cap = 8192, ids_cap = 16384;
   // profiling
   bool prof = false; std::vector<ProfRec> recs;
@@ -314,7 +314,7 @@ int decode_step(gvl_ctx* ctx, Seq& sq, hipStream_t st) {
       q.B = 1; q.S = 1; q.H = H; q.KV = KV; q.Dr = Dr; q.D = D; q.mode = 2; q.cos = ctx->cos_s; q.sin = ctx->sin_s; q.pos_ptr = sq.d_pos;
       q.cos_l = ctx->cos_l; q.sin_l = ctx->sin_l; q.rope_switch = ctx->cos_l ? f.rope_orig_max_pos : 0;
       RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
-    { DecodeAttnArgs a; memset(&a, 0, sizeof(a)); a.q = ctx->d_q; a.Kt = Kt; a.Vt = Vt; a.block_table = sq.d_block_table; a.pos_ptr = sq.d_pos; a.part = ctx->d_part;
+    { DecodeAttnArgs a; memset(&a, 0, sizeof(a)); a.q = ctx->d_q; a.Kt = Kt; a.Vt = Vt; a.block_table = sq.d_block_table; a.pos_ptr = sq.d_pos; a.part = ctx->d_part; a.counters = ctx->d_counters;
       a.out = ctx->d_attn; a.H = H; a.KV = KV; a.D = D; a.Dout = Dr; a.nsplit = ctx->nsplit; a.scale = 1.0f / sqrtf((float)Dr);
       RUN(GVL_PROF_DECODE_ATTN, 4.0 * (sq.pos + 1) * (double)KV * D, gvl_launch_decode_attention(a, st)); }
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.ow; g.N = Hd; g.K = H * Dr; g.x = ctx->d_attn; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
@@ -369,21 +369,21 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
     const int g = f.clip_image / f.clip_patch;
     ctx->c_P = g * g; ctx->c_S = ctx->c_P + 1; ctx->c_Kp = round_up(3 * f.clip_patch * f.clip_patch, 64);
     ctx->c_Dr = f.clip_hidden / f.clip_heads; ctx->c_D = pad_head(ctx->c_Dr);
-    if (ctx->c_D < 0 || (ctx->c_Dr & 3)) return bad("clip head dim unsupported");
+    if (ctx->c_D < 0 || (ctx->c_Dr & 7)) return bad("clip head dim unsupported");
   }
   if (ctx->has_iv2) {
     if (f.iv2_dim % 64 || f.iv2_inter % 64 || f.iv2_dim % f.iv2_heads || f.iv2_image % f.iv2_patch || f.iv2_frames_per_seg <= 0) return bad("iv2 geometry");
     const int g = f.iv2_image / f.iv2_patch;
     ctx->v_L = g * g; ctx->v_TL = ctx->v_L * f.iv2_frames_per_seg; ctx->v_S = ctx->v_TL + 1; ctx->v_Kp = round_up(3 * f.iv2_patch * f.iv2_patch, 64);
     ctx->v_Dr = f.iv2_dim / f.iv2_heads; ctx->v_D = pad_head(ctx->v_Dr);
-    if (ctx->v_D < 0 || (ctx->v_Dr & 3)) return bad("iv2 head dim unsupported");
+    if (ctx->v_D < 0 || (ctx->v_Dr & 7)) return bad("iv2 head dim unsupported");
   }
   if (f.hidden > 0) {
     if (f.hidden % 64) return bad("llm hidden must be a multiple of 64");
     if (ctx->has_llm) {
       if (f.inter % 64 || f.hidden % f.heads || f.heads % f.kv_heads || f.vocab <= 0 || f.max_seq <= 0) return bad("llm geometry");
       ctx->l_Dr = f.hidden / f.heads; ctx->l_D = pad_head(ctx->l_Dr);
-      if (ctx->l_D < 0 || (ctx->l_Dr & 3) || ((f.heads * ctx->l_Dr) % 64)) return bad("llm head dim unsupported");
+      if (ctx->l_D < 0 || (ctx->l_Dr & 15) || ((f.heads * ctx->l_Dr) % 64)) return bad("llm head dim unsupported");
     }
   }
   if (ctx->has_proj) {
@@ -419,6 +419,7 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
     ok &= hipMalloc((void**)&ctx->d_act, (size_t)f.inter * 2) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_logits, (size_t)f.vocab * 4) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_part, (size_t)f.heads * ctx->nsplit * (ctx->l_D + 2) * 4) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_counters, (size_t)f.heads * 4) == hipSuccess && hipMemset(ctx->d_counters, 0, (size_t)f.heads * 4) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_tok, 4) == hipSuccess && hipMalloc((void**)&ctx->d_step, 4) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_outlist, (size_t)ctx->outlist_cap * 4) == hipSuccess;
     if (!ok) { gvl_destroy(ctx); return fail(nullptr, GVL_ERR_OOM, "hipMalloc(decode buffers) failed"); }
@@ -433,7 +434,7 @@ int gvl_destroy(gvl_ctx* ctx) {
   hipDeviceSynchronize();
   for (auto& kv : ctx->w) if (kv.second.p) hipFree(kv.second.p);
   for (auto& s : ctx->seqs) { if (s.d_block_table) hipFree(s.d_block_table); if (s.d_pos) hipFree(s.d_pos); }
-  void* ptrs[] = {ctx->arena, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_tok, ctx->d_step, ctx->d_outlist, ctx->d_ids};
+  void* ptrs[] = {ctx->arena, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_tok, ctx->d_step, ctx->d_outlist, ctx->d_ids};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& r : ctx->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   delete ctx;
@@ -704,7 +705,7 @@ int gvl_op_attention(gvl_ctx* ctx, const uint16_t* q, const uint16_t* k, const u
   if (!ctx) return GVL_ERR_ARG;
   if (k != q + (size_t)H * Dr || v != q + (size_t)(H + KV) * Dr) return fail(ctx, GVL_ERR_ARG, "gvl_op_attention: q,k,v must be the column blocks of one fused qkv tensor");
   const int D = pad_head(Dr);
-  if (D < 0 || (Dr & 3)) return fail(ctx, GVL_ERR_ARG, "gvl_op_attention: head dim unsupported");
+  if (D < 0 || (Dr & 7)) return fail(ctx, GVL_ERR_ARG, "gvl_op_attention: head dim unsupported");
   hipStream_t st = (hipStream_t)stream;
   const int tiles = (S + 63) / 64;
   const size_t mark = ctx->arena_off;

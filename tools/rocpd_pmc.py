@@ -3,9 +3,8 @@ import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 filt = sys.argv[2] if len(sys.argv) > 2 else "gemm"
 cols = [r[1] for r in cur.execute("pragma table_info(pmc_events)")]
-print("# columns:", cols)
 try:
-    rows = cur.execute("select name, counter_name, count(*), avg(value), sum(value) from counters_collection group by name, counter_name").fetchall()
+    rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection group by kernel_name, counter_name").fetchall()
 except Exception as e:
     print("counters_collection query failed:", e)
     ccols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
@@ -13,4 +12,5 @@ except Exception as e:
     rows = []
 for n, c, cnt, avg, tot in rows:
     if filt in n:
-        print(f"{re.sub(r'\(.*', '', n)[:60]:<60} {c:<32} n={cnt:<5} avg={avg:.4g}")
+        short = n.split("(")[0][:60]
+        print(f"{short:<60} {c:<32} n={cnt:<5} avg={avg:.6g} dur_us={tot/1e3:.1f}")

@@ -43,7 +43,7 @@ __device__ __forceinline__ int kperm(int i) {
   return (b >> 1) * 16 + 8 * hh + 4 * (b & 1) + c;
 }
 
-template <int D, int NWAVES>
+template <int D, int NWAVES, int NS>
 __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int NT = NWAVES * 64;
   constexpr int DK = D / 16;          // k-steps of the QK^T contraction
@@ -78,29 +78,6 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     const int vr = pos >> 3, vpc = pos & 7;
     voff[i] = vr * 64 + (vpc ^ ((vr >> 1) & 7)) * 8;
   }
-  auto page_of = [&](int t) -> size_t {
-    const int pg = a.block_table ? a.block_table[b * a.max_pages + t] : b * n_tiles_all + t;
-    return ((size_t)pg * a.KV + hkv) * (size_t)(64 * D);
-  };
-  auto stage = [&](int buf, int t) {
-    const size_t pb = page_of(t);
-    const bf16_t* kp = a.Kt + pb;
-    const bf16_t* vp = a.Vt + pb;
-    char* base = smem + buf * STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < NIK; ++i) {
-      char* dst = base + (i * NT + wave * 64) * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + koff[i]),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NIK; ++i) {
-      char* dst = base + TILE_BYTES + (i * NT + wave * 64) * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + voff[i]),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-  };
-
   // ---- Q fragments (MFMA B operand): lane (q = qw + l31, h) holds d = kk*16 + 8h + 0..7 ----------
   bf16x8_t qf[DK];
   {
@@ -108,7 +85,29 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     const bf16_t* qp = a.Q + (((size_t)b * a.H + head) * a.S + qi) * D + 8 * h;
 #pragma unroll
     for (int kk = 0; kk < DK; ++kk) qf[kk] = *(const bf16x8_t*)(qp + kk * 16);
+    // make hipcc retire these loads HERE: otherwise its scoreboard keeps them pending around the loop back-edge and
+    // emits vmcnt(5..0) waits inside every iteration, which (in hardware) also drain our un-counted DMA ring
+#pragma unroll
+    for (int kk = 0; kk < DK; ++kk) asm volatile("" ::"v"(qf[kk]));
   }
+
+  // page ids of this (b) row of the block table, staged in LDS once: a per-iteration global load of the table would
+  // make hipcc wait vmcnt(0) (draining the DMA ring) every tile
+  int* pages_s = (int*)(smem + NS * STAGE_BYTES);
+  for (int i = tid; i < n_tiles; i += NT) pages_s[i] = a.block_table ? a.block_table[b * a.max_pages + i] : b * n_tiles_all + i;
+  __syncthreads();
+  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  auto stage = [&](int buf, int t) {
+    const int pg = __builtin_amdgcn_readfirstlane(pages_s[t]);
+    const size_t pb = ((size_t)pg * a.KV + hkv) * (size_t)(64 * D);
+    const bf16_t* kp = a.Kt + pb;
+    const bf16_t* vp = a.Vt + pb;
+    const unsigned base = smem_base + buf * STAGE_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < NIK; ++i) glds16(kp + koff[i], base + i * NT * 16);
+#pragma unroll
+    for (int i = 0; i < NIK; ++i) glds16(vp + voff[i], base + TILE_BYTES + i * NT * 16);
+  };
 
   f32x16_t o[DB];
 #pragma unroll
@@ -123,13 +122,21 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   const int vswz = (l31 >> 1) & 7;
   const int my_q = qw + l31;
 
+  // NS-deep LDS ring: tile t+NS-1 is requested while tile t is consumed, so a DMA has NS-1 iterations to land.
+  // Counted vmcnt (never 0 in steady state) + raw s_barrier: __syncthreads() would drain the DMA queue (guide §5).
   stage(0, 0);
+  if (NS == 3 && n_tiles > 1) stage(1, 1);
+  int cur = 0;
   for (int t = 0; t < n_tiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < n_tiles) stage((t + 1) & 1, t + 1);
+    if (NS == 3 && t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIK) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + NS - 1 < n_tiles) { int nb = cur + NS - 1; if (nb >= NS) nb -= NS; stage(nb, t + NS - 1); }
+    const int tb = cur;
+    cur = cur + 1 == NS ? 0 : cur + 1;
     if (a.causal && t * 64 > qw + 31) continue;   // wave-uniform: every key of this tile is in the future
-    const char* kb_ = smem + (t & 1) * STAGE_BYTES;
+    const char* kb_ = smem + tb * STAGE_BYTES;
     const char* vb_ = kb_ + TILE_BYTES;
 
     // ---- S^T = K . Q^T ---------------------------------------------------------------------------
@@ -145,40 +152,43 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
       }
     }
-    // ---- online softmax (lane-local) ----------------------------------------------------------------
+    // ---- online softmax (lane-local; raw-score max, scale folded into the exp2 argument) ---------------
     const bool need_mask = (t == n_tiles_all - 1 && (a.S & 63)) || (a.causal && t * 64 + 63 > qw);
-    float mx = -1e30f;
+    if (need_mask) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = s[kb][r] * sc;
-        if (need_mask) {
+        for (int r = 0; r < 16; ++r) {
           const int key = t * 64 + kb * 32 + (r >> 3) * 16 + 8 * h + (r & 7);
           const bool dead = key >= a.S || (a.causal && key > my_q);
-          v = dead ? -1e30f : v;
+          s[kb][r] = dead ? -1e30f : s[kb][r];
         }
-        s[kb][r] = v;
-        mx = fmaxf(mx, v);
-      }
+    }
+    float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; r += 1) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);     // v_max3_f32
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    float alpha = 1.f;
+    if (!__all(mx <= m_run)) {                   // wave-uniform: some row's running max grows -> rescale O (exact)
+      const float m_new = fmaxf(m_run, mx);
+      alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+    }
+    const float nm = -m_run * sc;
     float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, nm));
         s[kb][r] = p;
         psum += p;
       }
     l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < DB; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
     // ---- O^T += V^T . P^T ---------------------------------------------------------------------------
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
@@ -213,11 +223,11 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   }
 }
 
-template <int D, int NWAVES>
+template <int D, int NWAVES, int NS>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
-  constexpr int LDS = 2 * 2 * 64 * D * 2;
+  constexpr int LDS = NS * 2 * 64 * D * 2 + 1024;   // ring + page-id table (256 pages)
   static bool attr_set = false;
-  auto kern = attn_fwd_kernel<D, NWAVES>;
+  auto kern = attn_fwd_kernel<D, NWAVES, NS>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
     attr_set = true;
@@ -234,11 +244,11 @@ double gvl_attn_flops(const AttnArgs& a) {
 }
 
 int gvl_launch_attention(const AttnArgs& a, hipStream_t st) {
-  if (a.B <= 0 || a.S <= 0 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 3)) return -1;
+  if (a.B <= 0 || a.S <= 0 || a.S > 256 * 64 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 3)) return -1;
   switch (a.D) {
-    case 64: return launch_attn<64, 4>(a, st);
-    case 96: return launch_attn<96, 4>(a, st);
-    case 128: return launch_attn<128, 4>(a, st);
+    case 64: return launch_attn<64, 4, 3>(a, st);
+    case 96: return launch_attn<96, 4, 3>(a, st);
+    case 128: return launch_attn<128, 4, 2>(a, st);
     default: return -1;
   }
 }
@@ -250,7 +260,6 @@ template <int D>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a) {
   constexpr int CPR = D / 8;       // 16-byte chunks per key row
   constexpr int NIT = D / 8;       // 64*CPR chunks per page / 64 lanes
-  __shared__ __attribute__((aligned(16))) float q_s[D];
   __shared__ __attribute__((aligned(16))) float part_s[4][64 * CPR];
   __shared__ __attribute__((aligned(16))) float p_s[4][64];
   __shared__ float red_s[4][D + 2];
@@ -265,8 +274,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
   const int p_begin = split * pps;
   int p_end = p_begin + pps; if (p_end > npages) p_end = npages;
 
-  for (int i = tid; i < D; i += 256) q_s[i] = bf2f(a.q[head * D + i]);
-  __syncthreads();
+  // the lane's q chunks (chunk index (it*64+lane) % CPR): 16-byte L2 hits, no LDS staging / block barrier
+  u32x4_t qv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) qv[it] = *(const u32x4_t*)(a.q + head * D + ((it * 64 + lane) % CPR) * 8);
 
   const float sc = a.scale * 1.4426950408889634f;
   float m_run = -1e30f, l_run = 0.f;
@@ -287,10 +298,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = it * 64 + lane;
-      const float* qq = q_s + (c % CPR) * 8;
       float acc = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc += lo_bf(kv[it][e]) * qq[2 * e] + hi_bf(kv[it][e]) * qq[2 * e + 1];
+      for (int e = 0; e < 4; ++e) acc += lo_bf(kv[it][e]) * lo_bf(qv[it][e]) + hi_bf(kv[it][e]) * hi_bf(qv[it][e]);
       part_s[wave][c] = acc;
     }
     __builtin_amdgcn_wave_barrier();
@@ -328,42 +338,40 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
   }
   if (lane == 0) { red_s[wave][D] = m_run; red_s[wave][D + 1] = l_run; }
   __syncthreads();
+  // ---- publish this block's partial with write-through (sc1) stores, take a ticket; the last block of the head
+  //      merges the partials reading them with sc1 loads (bypass the stale L1): no release/acquire fences needed
+  //      (guide G16 recipe R1; placement independent) ---------------------------------------------------------
   float* outp = a.part + ((size_t)head * a.nsplit + split) * (D + 2);
   const float mm = fmaxf(fmaxf(red_s[0][D], red_s[1][D]), fmaxf(red_s[2][D], red_s[3][D]));
   if (tid < D) {
     float acc = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) acc += red_s[w][tid] * __builtin_amdgcn_exp2f(red_s[w][D] - mm);
-    outp[tid] = acc;
+    __hip_atomic_store(outp + tid, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (tid == 0) {
     float l = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) l += red_s[w][D + 1] * __builtin_amdgcn_exp2f(red_s[w][D] - mm);
-    outp[D] = mm; outp[D + 1] = l;
+    __hip_atomic_store(outp + D, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(outp + D + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // ---- the last split block of this head to arrive merges the partials (placement-independent hand-off:
-  //      agent-scope release by every producer, one agent-scope acquire by the consumer; guide G16) ----------
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int t = __hip_atomic_fetch_add(a.counters + head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_s = (t == a.nsplit - 1);
   }
   __syncthreads();
   if (!last_s) return;
-  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();
   const float* pp = a.part + (size_t)head * a.nsplit * (D + 2);
   float gm = -1e30f;
-  for (int s2 = 0; s2 < a.nsplit; ++s2) gm = fmaxf(gm, pp[s2 * (D + 2) + D]);
+  for (int s2 = 0; s2 < a.nsplit; ++s2) gm = fmaxf(gm, __hip_atomic_load(pp + s2 * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   float l = 0.f, acc = 0.f;
   for (int s2 = 0; s2 < a.nsplit; ++s2) {
-    const float w = __builtin_amdgcn_exp2f(pp[s2 * (D + 2) + D] - gm);
-    l += pp[s2 * (D + 2) + D + 1] * w;
-    if (tid < D) acc += pp[s2 * (D + 2) + tid] * w;
+    const float w = __builtin_amdgcn_exp2f(__hip_atomic_load(pp + s2 * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gm);
+    l += __hip_atomic_load(pp + s2 * (D + 2) + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * w;
+    if (tid < D) acc += __hip_atomic_load(pp + s2 * (D + 2) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * w;
   }
   if (tid < a.Dout) a.out[head * a.Dout + tid] = f2bf(acc / l);
   if (tid == 0) __hip_atomic_store(a.counters + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch

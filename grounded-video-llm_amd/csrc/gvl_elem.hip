@@ -518,8 +518,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   const int K8 = a.K >> 3;
   const int n0 = (blockIdx.x * 4 + wave) * R;
   const bf16_t* wp[R];
+  const int halfd = a.Dr >> 1, npair_qk = (a.H + a.KV) * halfd;
 #pragma unroll
-  for (int r = 0; r < R; ++r) { int n = n0 + r; if (n > a.N - 1) n = a.N - 1; wp[r] = a.W + (size_t)n * a.K; }
+  for (int r = 0; r < R; ++r) {
+    int n = n0 + r; if (n > a.N - 1) n = a.N - 1;
+    if (a.rope_on) {                        // logical row -> weight row: pairs (2j, 2j+1) = rotate_half partners
+      const int j = n >> 1;
+      if (j < npair_qk) { const int hd = j / halfd, d = j - hd * halfd; n = hd * a.Dr + d + (n & 1) * halfd; }
+    }
+    wp[r] = a.W + (size_t)n * a.K;
+  }
   // the first weight chunks do not depend on x: request them before the (latency-bound) x / RMSNorm prologue
   u32x4_t w0[R];
 #pragma unroll
@@ -573,7 +581,34 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-  if (lane == 0) {
+  if (lane == 0 && a.rope_on) {
+    if constexpr ((R & 1) == 0) {
+      const int pos = *a.pos_ptr;
+      const float* cosp = a.cos_s; const float* sinp = a.sin_s;
+      if (a.rope_switch > 0 && pos + 1 > a.rope_switch) { cosp = a.cos_l; sinp = a.sin_l; }
+      const int page = a.block_table[pos >> 6], slot = pos & 63;
+#pragma unroll
+      for (int r = 0; r < R; r += 2) {
+        const int i = n0 + r;
+        if (i + 1 < a.N) {
+          const int j = i >> 1;
+          if (j < npair_qk) {
+            const int hd = j / halfd, d = j - hd * halfd;
+            const float x1 = rbf(acc[r]), x2 = rbf(acc[r + 1]);
+            const float c = cosp[(size_t)pos * halfd + d], sn = sinp[(size_t)pos * halfd + d];
+            const bf16_t o1 = f2bf(rbf(x1 * c) + rbf(-x2 * sn)), o2 = f2bf(rbf(x2 * c) + rbf(x1 * sn));
+            bf16_t* dst = hd < a.H ? a.Q + (size_t)hd * a.D + d
+                                   : a.Kt + (((size_t)page * a.KV + (hd - a.H)) * 64 + slot) * a.D + d;
+            dst[0] = o1; dst[halfd] = o2;
+          } else {
+            const int vi = i - 2 * npair_qk, hv = vi / a.Dr, d = vi - hv * a.Dr;
+            bf16_t* dst = a.Vt + (((size_t)page * a.KV + hv) * a.D + d) * 64 + slot;
+            dst[0] = f2bf(acc[r]); dst[64] = f2bf(acc[r + 1]);
+          }
+        }
+      }
+    }
+  } else if (lane == 0) {
     if (a.act == GVL_ACT_SILU_MUL) {
       if constexpr ((R & 1) == 0) {
 #pragma unroll
@@ -611,6 +646,7 @@ int gvl_launch_gemv(const GemvArgs& a, hipStream_t st) {
   if (R < 1) R = 1;
   if (R == 5) R = 6;
   if (R == 7 || R > 8) R = 8;
+  if (a.rope_on) { if ((a.Dr & 1) || (a.N & 1)) return -1; R = 2; }
   if (a.act == GVL_ACT_SILU_MUL && (R & 1)) R += 1;
   const int blocks = (a.N + 4 * R - 1) / (4 * R);
   switch (R) {

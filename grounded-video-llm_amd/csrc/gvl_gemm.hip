@@ -20,7 +20,7 @@
 
 #define BK 64  // K tile (bf16 elements) == one 128-byte LDS row
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
   constexpr int NWAVES = WAVES_M * WAVES_N;
   constexpr int NT = NWAVES * 64;
@@ -73,13 +73,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
     }
   }
 
+  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   auto stage = [&](int buf, int k0) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int c = i * NWAVES + wave;
-      char* dst = smem + buf * STAGE_BYTES + c * 1024;  // wave-uniform; the DMA adds lane*16
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      if constexpr (NS == 0) {
+        char* dst = smem + buf * STAGE_BYTES + c * 1024;  // wave-uniform; the DMA adds lane*16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      } else {
+        glds16(src[i] + k0, smem_base + buf * STAGE_BYTES + c * 1024);   // not counted by hipcc: waits are ours
+      }
     }
   };
 
@@ -101,18 +106,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
   // STAG 1: waves w and w+4 (same SIMD) use different slots out of 4; STAG 2: everybody after the first k-step;
   // STAG 3: slots {0,1} only (more flight time for the DMA)
   const int dma_slot = STAG == 1 ? ((((wave >> 2) << 1) + (wave & 1)) & 3) : (STAG == 2 ? 1 : ((wave >> 2) & 1));
+  constexpr int RING = NS == 0 ? 2 : NS;       // LDS ring depth; tile t+RING-1 is requested while tile t is consumed
   stage(0, 0);
+  if (RING == 3 && nk > 1) stage(1, BK);
+  int cur = 0;
   for (int t = 0; t < nk; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's DMA pieces of tile t have landed
-    __syncthreads();  // ... and everybody's; all waves are also done reading buf (t+1)&1
-    if constexpr (STAG == 0) { if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK); }
-    const char* sb = smem + (t & 1) * STAGE_BYTES;
+    if constexpr (NS == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's DMA pieces of tile t have landed
+      __syncthreads();  // ... and everybody's; all waves are also done reading the slot that is refilled next
+    } else {
+      if (RING == 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");   // tile t+1 may stay in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    const int tn = t + RING - 1;                // tile requested during this iteration
+    int nbuf = cur + RING - 1; if (nbuf >= RING) nbuf -= RING;
+    if constexpr (STAG == 0) { if (tn < nk) stage(nbuf, tn * BK); }
+    const int tb = cur;
+    cur = cur + 1 == RING ? 0 : cur + 1;
+    const char* sb = smem + tb * STAGE_BYTES;
     if constexpr (PIPE == 0) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         // staggered DMA issue: the two waves that share a SIMD request tile t+1 at different k-steps, so one of
         // them always has MFMAs to issue while the other pays the ~8 x 60-cycle global_load_lds issue cost
-        if constexpr (STAG != 0) { if (kk == dma_slot && t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK); }
+        if constexpr (STAG != 0) { if (kk == dma_slot && tn < nk) stage(nbuf, tn * BK); }
         const int coff = ((kk * 2 + h) ^ swz) << 4;
         bf16x8_t wf[NB], af[MB];
 #pragma unroll
@@ -136,7 +155,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
       }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        if constexpr (STAG != 0) { if (kk == dma_slot && t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK); }
+        if constexpr (STAG != 0) { if (kk == dma_slot && tn < nk) stage(nbuf, tn * BK); }
         if (kk < 3) {
           const int coff = (((kk + 1) * 2 + h) ^ swz) << 4;
 #pragma unroll
@@ -227,12 +246,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int LDS = 2 * (BM + BN) * 128;
+  constexpr int LDS = (NS == 0 ? 2 : NS) * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, STAG>;
+  auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, STAG, NS>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
     attr_set = true;
@@ -250,31 +269,40 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.act == GVL_ACT_SILU_MUL && (a.out_f32 || a.resid || a.gamma)) return -1;
   int cfg = a.tile_cfg;
   if (cfg == 0) {
-    // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_microbench.txt): the 256x256 tile with the DMA
-    // issue split over the two waves of a SIMD (cfg 52) wins when K is long enough to amortise its un-overlapped
-    // prologue/epilogue (1 block / CU) and the N edge wastes < 5 %; otherwise 128x128 (2 blocks / CU, cfg 21).
+    // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_microbench*.txt):
+    //  * 256x256, DMA issue split over the two waves of a SIMD (cfg 72): best when K is long enough to amortise
+    //    its un-overlapped prologue/epilogue (1 block / CU) and the N edge wastes < 5 %;
+    //  * 128x256 with a 3-deep ring (cfg 74): long K with an awkward N (1408 = 5.5 x 256);
+    //  * 128x128, 2 blocks / CU (cfg 21): everything else (short K, few tiles).
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const double n_waste = (double)(((a.N + 255) / 256) * 256) / a.N - 1.0;
-    cfg = (a.K >= 1408 && t256 >= 128 && n_waste < 0.05) ? 52 : 21;
+    if (a.K >= 1408 && t256 >= 128 && n_waste < 0.05) cfg = 72;
+    else if (a.K >= 4096 && a.M >= 2048) cfg = 74;
+    else cfg = 21;
   }
   switch (cfg) {
-    case 1: return launch_cfg<128, 128, 2, 2, 0, 0>(a, st);
-    case 2: return launch_cfg<256, 256, 4, 2, 0, 0>(a, st);
-    case 3: return launch_cfg<256, 128, 4, 2, 0, 0>(a, st);
-    case 21: return launch_cfg<128, 128, 2, 2, 0, 1>(a, st);
-    case 22: return launch_cfg<256, 256, 4, 2, 0, 1>(a, st);
-    case 23: return launch_cfg<256, 128, 4, 2, 0, 1>(a, st);
-    case 31: return launch_cfg<128, 128, 2, 2, 1, 1>(a, st);
-    case 32: return launch_cfg<256, 256, 4, 2, 1, 1>(a, st);
-    case 33: return launch_cfg<256, 128, 4, 2, 1, 1>(a, st);
-    case 42: return launch_cfg<256, 256, 4, 2, 0, 2>(a, st);
-    case 52: return launch_cfg<256, 256, 4, 2, 0, 3>(a, st);
-    case 62: return launch_cfg<256, 256, 4, 2, 1, 3>(a, st);
-    case 11: return launch_cfg<128, 128, 2, 2, 1, 0>(a, st);
-    case 12: return launch_cfg<256, 256, 4, 2, 1, 0>(a, st);
-    case 13: return launch_cfg<256, 128, 4, 2, 1, 0>(a, st);
-    case 14: return launch_cfg<256, 256, 2, 4, 1, 0>(a, st);
-    case 15: return launch_cfg<128, 256, 2, 4, 1, 0>(a, st);
+    case 1: return launch_cfg<128, 128, 2, 2, 0, 0, 0>(a, st);
+    case 2: return launch_cfg<256, 256, 4, 2, 0, 0, 0>(a, st);
+    case 3: return launch_cfg<256, 128, 4, 2, 0, 0, 0>(a, st);
+    case 21: return launch_cfg<128, 128, 2, 2, 0, 1, 0>(a, st);
+    case 22: return launch_cfg<256, 256, 4, 2, 0, 1, 0>(a, st);
+    case 23: return launch_cfg<256, 128, 4, 2, 0, 1, 0>(a, st);
+    case 31: return launch_cfg<128, 128, 2, 2, 1, 1, 0>(a, st);
+    case 32: return launch_cfg<256, 256, 4, 2, 1, 1, 0>(a, st);
+    case 33: return launch_cfg<256, 128, 4, 2, 1, 1, 0>(a, st);
+    case 72: return launch_cfg<256, 256, 4, 2, 0, 3, 2>(a, st);   // cfg 52 with the un-counted (asm) DMA
+    case 73: return launch_cfg<256, 128, 4, 2, 0, 3, 3>(a, st);   // 3-deep ring, 144 KB
+    case 74: return launch_cfg<128, 256, 2, 4, 0, 3, 3>(a, st);
+    case 75: return launch_cfg<256, 128, 4, 2, 0, 0, 3>(a, st);
+    case 71: return launch_cfg<128, 128, 2, 2, 0, 1, 3>(a, st);   // 96 KB: one block / CU
+    case 42: return launch_cfg<256, 256, 4, 2, 0, 2, 0>(a, st);
+    case 52: return launch_cfg<256, 256, 4, 2, 0, 3, 0>(a, st);
+    case 62: return launch_cfg<256, 256, 4, 2, 1, 3, 0>(a, st);
+    case 11: return launch_cfg<128, 128, 2, 2, 1, 0, 0>(a, st);
+    case 12: return launch_cfg<256, 256, 4, 2, 1, 0, 0>(a, st);
+    case 13: return launch_cfg<256, 128, 4, 2, 1, 0, 0>(a, st);
+    case 14: return launch_cfg<256, 256, 2, 4, 1, 0, 0>(a, st);
+    case 15: return launch_cfg<128, 256, 2, 4, 1, 0, 0>(a, st);
     default: return -1;
   }
 }

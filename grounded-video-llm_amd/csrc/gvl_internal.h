@@ -50,6 +50,22 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// global -> LDS DMA, 16 bytes per lane, issued from inline asm so that hipcc does NOT count it in its vmcnt
+// bookkeeping (a builtin glds makes the compiler drain vmcnt(0) before the next LDS read: it cannot prove the
+// DMA destination and the ds_read source are different ring slots).  The caller owns the waits:
+// `s_waitcnt vmcnt(N)` + a barrier before any wave reads the slot.  LDS destination = lds_dst (wave-uniform
+// byte address, via M0) + lane*16; gsrc is per lane.  Recipe: cdna_hip_programming.md §5.7.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {   // 32-bit LDS byte address of a __shared__ pointer
+  return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;
+}
+
 // ---- GEMM ---------------------------------------------------------------------------------------
 enum { GVL_ACT_NONE = 0, GVL_ACT_QUICK_GELU = 1, GVL_ACT_GELU = 2, GVL_ACT_SILU_MUL = 3 };
 
@@ -147,6 +163,10 @@ struct GemvArgs {
   int act;                        // GVL_ACT_NONE or GVL_ACT_SILU_MUL (interleaved gate/up rows, N' = N/2)
   bf16_t* out_bf16;               // [N'] or null
   float* out_f32;                 // [N'] or null
+  // fused decode epilogue of the qkv projection (rope_on): RoPE on q/k at position *pos_ptr, q -> Q[H][D], k/v appended to
+  // the paged cache.  Rows are visited in (d, d+Dr/2) partner pairs so one lane owns both halves of a rotation.
+  int rope_on; const float *cos_s, *sin_s, *cos_l, *sin_l; int rope_switch; const int* pos_ptr; const int* block_table;
+  bf16_t *Q, *Kt, *Vt; int H, KV, Dr, D;
 };
 int gvl_launch_gemv(const GemvArgs& a, hipStream_t st);
 int gvl_launch_argmax(const float* logits, int n, int* out_tok, int* out_list, const int* step_ptr, hipStream_t st);

@@ -308,12 +308,12 @@ int decode_step(gvl_ctx* ctx, Seq& sq, hipStream_t st) {
   for (int l = 0; l < f.layers; ++l) {
     const LlmLayerW& w = ctx->ll[l];
     bf16_t* Kt = ctx->kpool + (size_t)l * ctx->layer_stride; bf16_t* Vt = ctx->vpool + (size_t)l * ctx->layer_stride;
-    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.qkvw; g.N = qkvw; g.K = Hd; g.x = ctx->d_x; g.norm_w = w.ln1; g.eps = f.rms_eps; g.out_bf16 = ctx->d_qkv;
+    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.qkvw; g.N = qkvw; g.K = Hd; g.x = ctx->d_x; g.norm_w = w.ln1; g.eps = f.rms_eps;
+      // fused epilogue: RoPE + Q write + paged-KV append (replaces a separate qkv_post launch per layer per token)
+      g.rope_on = 1; g.cos_s = ctx->cos_s; g.sin_s = ctx->sin_s; g.cos_l = ctx->cos_l; g.sin_l = ctx->sin_l;
+      g.rope_switch = ctx->cos_l ? f.rope_orig_max_pos : 0; g.pos_ptr = sq.d_pos; g.block_table = sq.d_block_table;
+      g.Q = ctx->d_q; g.Kt = Kt; g.Vt = Vt; g.H = H; g.KV = KV; g.Dr = Dr; g.D = D;
       RUN(GVL_PROF_GEMV, 2.0 * qkvw * Hd, gvl_launch_gemv(g, st)); }
-    { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = ctx->d_qkv; q.ld = qkvw; q.Q = ctx->d_q; q.Kt = Kt; q.Vt = Vt; q.block_table = sq.d_block_table; q.max_pages = sq.n_pages;
-      q.B = 1; q.S = 1; q.H = H; q.KV = KV; q.Dr = Dr; q.D = D; q.mode = 2; q.cos = ctx->cos_s; q.sin = ctx->sin_s; q.pos_ptr = sq.d_pos;
-      q.cos_l = ctx->cos_l; q.sin_l = ctx->sin_l; q.rope_switch = ctx->cos_l ? f.rope_orig_max_pos : 0;
-      RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
     { DecodeAttnArgs a; memset(&a, 0, sizeof(a)); a.q = ctx->d_q; a.Kt = Kt; a.Vt = Vt; a.block_table = sq.d_block_table; a.pos_ptr = sq.d_pos; a.part = ctx->d_part; a.counters = ctx->d_counters;
       a.out = ctx->d_attn; a.H = H; a.KV = KV; a.D = D; a.Dout = Dr; a.nsplit = ctx->nsplit; a.scale = 1.0f / sqrtf((float)Dr);
       RUN(GVL_PROF_DECODE_ATTN, 4.0 * (sq.pos + 1) * (double)KV * D, gvl_launch_decode_attention(a, st)); }
@@ -414,7 +414,7 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
     bool ok = true;
     ok &= hipMalloc((void**)&ctx->d_x, (size_t)f.hidden * 2) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_qkv, (size_t)qkvw * 2) == hipSuccess;
-    ok &= hipMalloc((void**)&ctx->d_q, (size_t)f.heads * ctx->l_D * 2) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_q, (size_t)f.heads * ctx->l_D * 2) == hipSuccess && hipMemset(ctx->d_q, 0, (size_t)f.heads * ctx->l_D * 2) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_attn, (size_t)f.heads * ctx->l_Dr * 2) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_act, (size_t)f.inter * 2) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_logits, (size_t)f.vocab * 4) == hipSuccess;

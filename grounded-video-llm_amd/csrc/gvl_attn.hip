@@ -142,12 +142,14 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     // ---- S^T = K . Q^T ---------------------------------------------------------------------------
     f32x16_t s[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
-      const int row = kb * 32 + krow0;
 #pragma unroll
-      for (int kk = 0; kk < DK; ++kk) {
+    for (int kk = 0; kk < DK; ++kk) {            // kk outer: the two accumulators alternate, no back-to-back dependent MFMAs
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int row = kb * 32 + krow0;
         const bf16x8_t kf = *(const bf16x8_t*)(kb_ + row * (D * 2) + (KSwz<D>::phys(row, kk * 2 + h) << 4));
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
       }
@@ -167,7 +169,10 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
     for (int r = 1; r < 16; r += 1) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);     // v_max3_f32
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    {   // exchange with the partner half-wave (lane ^ 32) in the VALU: v_permlane32_swap, no LDS round trip
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
     float alpha = 1.f;
     if (!__all(mx <= m_run)) {                   // wave-uniform: some row's running max grows -> rescale O (exact)
       const float m_new = fmaxf(m_run, mx);
@@ -257,10 +262,12 @@ int gvl_launch_attention(const AttnArgs& a, hipStream_t st) {
 // decode attention: one new query per head against the paged cache, split over the context
 // =====================================================================================================
 template <int D>
-__global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a) {
+__global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArgs a) {
   constexpr int CPR = D / 8;       // 16-byte chunks per key row
   constexpr int NIT = D / 8;       // 64*CPR chunks per page / 64 lanes
-  __shared__ __attribute__((aligned(16))) float part_s[4][64 * CPR];
+  constexpr int QP = (64 % CPR == 0) ? 1 : 3;   // distinct q chunks a lane meets: (it*64+lane) % CPR has period 3 for CPR = 12
+  static_assert(D == 64 || D == 96 || D == 128, "head dim");
+  __shared__ __attribute__((aligned(16))) float part_s[4][64 * (CPR + 1)];   // +1: conflict-free per-key reads
   __shared__ __attribute__((aligned(16))) float p_s[4][64];
   __shared__ float red_s[4][D + 2];
   __shared__ int last_s;
@@ -275,9 +282,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
   int p_end = p_begin + pps; if (p_end > npages) p_end = npages;
 
   // the lane's q chunks (chunk index (it*64+lane) % CPR): 16-byte L2 hits, no LDS staging / block barrier
-  u32x4_t qv[NIT];
+  u32x4_t qv[QP];
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) qv[it] = *(const u32x4_t*)(a.q + head * D + ((it * 64 + lane) % CPR) * 8);
+  for (int it = 0; it < QP; ++it) qv[it] = *(const u32x4_t*)(a.q + head * D + ((it * 64 + lane) % CPR) * 8);
 
   const float sc = a.scale * 1.4426950408889634f;
   float m_run = -1e30f, l_run = 0.f;
@@ -300,13 +307,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
       const int c = it * 64 + lane;
       float acc = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc += lo_bf(kv[it][e]) * lo_bf(qv[it][e]) + hi_bf(kv[it][e]) * hi_bf(qv[it][e]);
-      part_s[wave][c] = acc;
+      for (int e = 0; e < 4; ++e) acc += lo_bf(kv[it][e]) * lo_bf(qv[it % QP][e]) + hi_bf(kv[it][e]) * hi_bf(qv[it % QP][e]);
+      part_s[wave][c + c / CPR] = acc;              // key*(CPR+1) + chunk
     }
     __builtin_amdgcn_wave_barrier();
     float sv = 0.f;
 #pragma unroll
-    for (int i = 0; i < CPR; ++i) sv += part_s[wave][lane * CPR + i];
+    for (int i = 0; i < CPR; ++i) sv += part_s[wave][lane * (CPR + 1) + i];
     sv *= sc;
     if (pg * 64 + lane >= pos) sv = -1e30f;
     const float mx = wave_max(sv);
@@ -364,14 +371,20 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
   }
   __syncthreads();
   if (!last_s) return;
+  // one round trip: every thread fetches its share of the nsplit*(D+2) partial words (sc1 loads, all independent)
+  // into LDS (the score scratch is free by now), then the merge runs out of LDS
   const float* pp = a.part + (size_t)head * a.nsplit * (D + 2);
+  float* mg = &part_s[0][0];
+  const int nword = a.nsplit * (D + 2);
+  for (int i = tid; i < nword; i += 256) mg[i] = __hip_atomic_load(pp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
   float gm = -1e30f;
-  for (int s2 = 0; s2 < a.nsplit; ++s2) gm = fmaxf(gm, __hip_atomic_load(pp + s2 * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  for (int s2 = 0; s2 < a.nsplit; ++s2) gm = fmaxf(gm, mg[s2 * (D + 2) + D]);
   float l = 0.f, acc = 0.f;
   for (int s2 = 0; s2 < a.nsplit; ++s2) {
-    const float w = __builtin_amdgcn_exp2f(__hip_atomic_load(pp + s2 * (D + 2) + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gm);
-    l += __hip_atomic_load(pp + s2 * (D + 2) + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * w;
-    if (tid < D) acc += __hip_atomic_load(pp + s2 * (D + 2) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * w;
+    const float w = __builtin_amdgcn_exp2f(mg[s2 * (D + 2) + D] - gm);
+    l += mg[s2 * (D + 2) + D + 1] * w;
+    if (tid < D) acc += mg[s2 * (D + 2) + tid] * w;
   }
   if (tid < a.Dout) a.out[head * a.Dout + tid] = f2bf(acc / l);
   if (tid == 0) __hip_atomic_store(a.counters + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch

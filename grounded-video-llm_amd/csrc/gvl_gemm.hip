@@ -20,6 +20,81 @@
 
 #define BK 64  // K tile (bf16 elements) == one 128-byte LDS row
 
+template <int TM, int TN, int MB, int NB>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16_t (&acc)[NB][MB], int m0, int n0, int wm, int wn, int l31, int h) {
+  // ---- epilogue: lane owns row m = ..+(lane&31), columns n = ..+8*b+4*h+{0..3} --------------------
+#pragma unroll
+  for (int j = 0; j < MB; ++j) {
+    const int m = m0 + wm * TM + j * 32 + l31;
+    if (m >= a.M) continue;
+    const size_t orow = a.grp_rows ? (size_t)(m / a.grp_rows) * a.grp_stride + (m % a.grp_rows) + a.row_off : (size_t)m + a.row_off;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int n = n0 + wn * TN + i * 32 + 8 * b + 4 * h;
+        if (n >= a.N) continue;
+        float v[4] = {acc[i][j][4 * b + 0], acc[i][j][4 * b + 1], acc[i][j][4 * b + 2], acc[i][j][4 * b + 3]};
+        if (a.bias) {
+          const f32x4_t bv = *(const f32x4_t*)(a.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        }
+        if (a.act == GVL_ACT_SILU_MUL) {
+          // interleaved (gate, up) pairs -> 2 outputs at column n/2.  reference: up * silu(gate), each op in bf16
+          float o2[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float g = rbf(v[2 * e]), u = rbf(v[2 * e + 1]);
+            const float sg = rbf(g * fast_sigmoid(g));
+            o2[e] = u * sg;
+          }
+          bf16_t* cp = (bf16_t*)a.C + orow * a.ldc + (n >> 1);
+          *(unsigned*)cp = pack2bf(o2[0], o2[1]);
+          continue;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = v[e];
+          if (a.act == GVL_ACT_QUICK_GELU) {
+            x = rbf(x);
+            const float s = rbf(fast_sigmoid(rbf(1.702f * x)));
+            x = x * s;
+          } else if (a.act == GVL_ACT_GELU) {
+            x = rbf(x);
+            x = gelu_erf(x);
+          }
+          v[e] = x;
+        }
+        if (a.gamma) {
+          const f32x4_t gv = *(const f32x4_t*)(a.gamma + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) * gv[e];
+        }
+        if (a.out_f32) {
+          float* cp = (float*)a.C + orow * a.ldc + n;
+          if (a.resid) {
+            const f32x4_t rv = *(const f32x4_t*)((const float*)a.resid + orow * a.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rv[e] + (a.round_pre_resid ? rbf(v[e]) : v[e]);
+          }
+          f32x4_t o = {v[0], v[1], v[2], v[3]};
+          *(f32x4_t*)cp = o;
+        } else {
+          bf16_t* cp = (bf16_t*)a.C + orow * a.ldc + n;
+          if (a.resid) {
+            const u32x2_t rv = *(const u32x2_t*)((const bf16_t*)a.resid + orow * a.ldr + n);
+            const float r0 = lo_bf(rv[0]), r1 = hi_bf(rv[0]), r2 = lo_bf(rv[1]), r3 = hi_bf(rv[1]);
+            v[0] = r0 + rbf(v[0]); v[1] = r1 + rbf(v[1]); v[2] = r2 + rbf(v[2]); v[3] = r3 + rbf(v[3]);
+          }
+          u32x2_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(u32x2_t*)cp = o;
+        }
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
   constexpr int NWAVES = WAVES_M * WAVES_N;
@@ -173,77 +248,145 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
     }
   }
 
-  // ---- epilogue: lane owns row m = ..+(lane&31), columns n = ..+8*b+4*h+{0..3} --------------------
+  gemm_epilogue<TM, TN, MB, NB>(a, acc, m0, n0, wm, wn, l31, h);
+}
+
+// =====================================================================================================
+// Ping-pong variant (256x256x64, 8 waves): the two waves that share a SIMD run HALF A PHASE APART.  Every k-step
+// is split into a LOAD phase (6 ds_read_b128 + a share of the next tile's DMA) and an MFMA phase (8 x 32x32x16),
+// separated by workgroup barriers; waves 4-7 start one barrier later than waves 0-3, so at any time one wave per
+// SIMD is issuing MFMAs (at raised priority) while its partner fetches operands.  The matrix pipe therefore never
+// waits for LDS latency, DMA issue or the tile-boundary restart that the lock-step structure pays every 64 K.
+// Barrier schedule (global barrier index b): group 0: loads(s) | b=2s | MFMA(s) | b=2s+1 ; group 1 is shifted by one.
+// Hazards: a wave's `s_waitcnt vmcnt(0)` for tile t+1 sits in the LOAD phase of its k-step 3, which is ahead of
+// barrier 8t+7 for BOTH groups; the first read of tile t+1 (group 0, step 0) comes after that barrier.  The DMA for
+// tile t+1 overwrites the slot of tile t-1, last read before barrier 8t-1; it is issued after that barrier.
+// =====================================================================================================
+template <int BM, int BN, int KPP, int DMODE>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+  constexpr int WAVES_M = 4, WAVES_N = 2, NWAVES = 8, NT = 512;
+  constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, MB = TM / 32, NB = TN / 32;
+  constexpr int ROWS = BM + BN, NI = ROWS * 8 / NT, STAGE_BYTES = ROWS * 128;
+  static_assert(NI % 2 == 0, "DMA pieces are issued in two halves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  constexpr int GM = 8;
+  const int band = GM * tiles_n;
+  const int g = vid / band, first_m = g * GM;
+  const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+  const int in_band = vid - g * band;
+  const int tm = first_m + in_band % gm, tn = in_band / gm;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                       // waves w and w+4 share a SIMD
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const bf16_t* src[NI];
 #pragma unroll
-  for (int j = 0; j < MB; ++j) {
-    const int m = m0 + wm * TM + j * 32 + l31;
-    if (m >= a.M) continue;
-    const size_t orow = a.grp_rows ? (size_t)(m / a.grp_rows) * a.grp_stride + (m % a.grp_rows) + a.row_off : (size_t)m + a.row_off;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int n = n0 + wn * TN + i * 32 + 8 * b + 4 * h;
-        if (n >= a.N) continue;
-        float v[4] = {acc[i][j][4 * b + 0], acc[i][j][4 * b + 1], acc[i][j][4 * b + 2], acc[i][j][4 * b + 3]};
-        if (a.bias) {
-          const f32x4_t bv = *(const f32x4_t*)(a.bias + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bv[e];
-        }
-        if (a.act == GVL_ACT_SILU_MUL) {
-          // interleaved (gate, up) pairs -> 2 outputs at column n/2.  reference: up * silu(gate), each op in bf16
-          float o2[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const float g = rbf(v[2 * e]), u = rbf(v[2 * e + 1]);
-            const float sg = rbf(g * fast_sigmoid(g));
-            o2[e] = u * sg;
-          }
-          bf16_t* cp = (bf16_t*)a.C + orow * a.ldc + (n >> 1);
-          *(unsigned*)cp = pack2bf(o2[0], o2[1]);
-          continue;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x = v[e];
-          if (a.act == GVL_ACT_QUICK_GELU) {
-            x = rbf(x);
-            const float s = rbf(fast_sigmoid(rbf(1.702f * x)));
-            x = x * s;
-          } else if (a.act == GVL_ACT_GELU) {
-            x = rbf(x);
-            x = gelu_erf(x);
-          }
-          v[e] = x;
-        }
-        if (a.gamma) {
-          const f32x4_t gv = *(const f32x4_t*)(a.gamma + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) * gv[e];
-        }
-        if (a.out_f32) {
-          float* cp = (float*)a.C + orow * a.ldc + n;
-          if (a.resid) {
-            const f32x4_t rv = *(const f32x4_t*)((const float*)a.resid + orow * a.ldr + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = rv[e] + (a.round_pre_resid ? rbf(v[e]) : v[e]);
-          }
-          f32x4_t o = {v[0], v[1], v[2], v[3]};
-          *(f32x4_t*)cp = o;
-        } else {
-          bf16_t* cp = (bf16_t*)a.C + orow * a.ldc + n;
-          if (a.resid) {
-            const u32x2_t rv = *(const u32x2_t*)((const bf16_t*)a.resid + orow * a.ldr + n);
-            const float r0 = lo_bf(rv[0]), r1 = hi_bf(rv[0]), r2 = lo_bf(rv[1]), r3 = hi_bf(rv[1]);
-            v[0] = r0 + rbf(v[0]); v[1] = r1 + rbf(v[1]); v[2] = r2 + rbf(v[2]); v[3] = r3 + rbf(v[3]);
-          }
-          u32x2_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          *(u32x2_t*)cp = o;
-        }
-      }
+  for (int i = 0; i < NI; ++i) {
+    const int c = i * NWAVES + wave;
+    const int row = c * 8 + (lane >> 3);
+    const int pc = lane & 7;
+    if (c * 8 < BN) {
+      const int lc = pc ^ ((row >> 1) & 7);
+      int gr = n0 + row; gr = gr < a.N ? gr : a.N - 1;
+      src[i] = a.W + (size_t)gr * a.K + lc * 8;
+    } else {
+      const int ra = row - BN;
+      const int lc = pc ^ ((ra >> 1) & 7);
+      int gr = m0 + ra; gr = gr < a.M ? gr : a.M - 1;
+      src[i] = a.A + (size_t)gr * a.lda + lc * 8;
     }
   }
+  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  auto stage_half = [&](int buf, int k0, int half) {
+#pragma unroll
+    for (int i = 0; i < NI / 2; ++i) {
+      const int ii = half * (NI / 2) + i;
+      glds16(src[ii] + k0, smem_base + buf * STAGE_BYTES + (ii * NWAVES + wave) * 1024);
+    }
+  };
+
+  f32x16_t acc[NB][MB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int l31 = lane & 31, h = lane >> 5;
+  const int swz = (l31 >> 1) & 7;
+  const int w_row_off = (wn * TN + l31) * 128;
+  const int a_row_off = BN * 128 + (wm * TM + l31) * 128;
+  const int nk = a.K / BK;
+
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+  stage_half(0, 0, 0); stage_half(0, 0, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PP_BARRIER();                                   // tile 0 is in LDS for everybody
+  if (grp == 1) PP_BARRIER();                     // half-phase offset of the second wave group
+
+  // KPP k-steps (of 16) per phase: KPP = 1 -> 4 phases / tile of 8 MFMAs; KPP = 2 -> 2 phases / tile of 16 MFMAs.
+  // DMODE 0: DMA halves in the first two LOAD phases, vmcnt(0) in the last LOAD phase of the tile.
+  // (DMODE 1 = wait at the END of the last MFMA phase is a RACE: group 1 would retire its pieces after barrier 8t+8
+  //  while group 0 already reads tile t+1 after barrier 8t+7 -- measured wrong results; kept only as a warning.)
+  constexpr int NPH = 4 / KPP;
+  for (int t = 0; t < nk; ++t) {
+    const char* sb = smem + (t & 1) * STAGE_BYTES;
+    const bool more = t + 1 < nk;
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+      // ---- LOAD phase -------------------------------------------------------------------------------
+      bf16x8_t wf[KPP][NB], af[KPP][MB];
+#pragma unroll
+      for (int u = 0; u < KPP; ++u) {
+        const int coff = (((ph * KPP + u) * 2 + h) ^ swz) << 4;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) wf[u][i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
+#pragma unroll
+        for (int j = 0; j < MB; ++j) af[u][j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
+      }
+      if (ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
+      if (DMODE == 0 && ph == NPH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      // ---- MFMA phase -------------------------------------------------------------------------------
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int u = 0; u < KPP; ++u)
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+          for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][i], af[u][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (DMODE == 1 && ph == NPH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_BARRIER();
+    }
+  }
+  if (grp == 0) PP_BARRIER();                     // pairs with the extra barrier group 1 took at the start
+#undef PP_BARRIER
+  gemm_epilogue<TM, TN, MB, NB>(a, acc, m0, n0, wm, wn, l31, h);
+}
+
+template <int KPP, int DMODE>
+static int launch_pp(const GemmArgs& a, hipStream_t st) {
+  constexpr int BM = 256, BN = 256, LDS = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  auto kern = gemm_pp_kernel<BM, BN, KPP, DMODE>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+    attr_set = true;
+  }
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), LDS, st, a, tiles_m, tiles_n);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS>
@@ -270,15 +413,11 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
   int cfg = a.tile_cfg;
   if (cfg == 0) {
     // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_microbench*.txt):
-    //  * 256x256, DMA issue split over the two waves of a SIMD (cfg 72): best when K is long enough to amortise
-    //    its un-overlapped prologue/epilogue (1 block / CU) and the N edge wastes < 5 %;
-    //  * 128x256 with a 3-deep ring (cfg 74): long K with an awkward N (1408 = 5.5 x 256);
-    //  * 128x128, 2 blocks / CU (cfg 21): everything else (short K, few tiles).
+    //  * cfg 82 = 256x256 ping-pong kernel: best whenever K is long enough to amortise its un-overlapped
+    //    prologue/epilogue (one block / CU) and there are enough tiles;
+    //  * cfg 21 = 128x128, 2 blocks / CU: short K (CLIP's K = 1024) or few tiles.
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    const double n_waste = (double)(((a.N + 255) / 256) * 256) / a.N - 1.0;
-    if (a.K >= 1408 && t256 >= 128 && n_waste < 0.05) cfg = 72;
-    else if (a.K >= 4096 && a.M >= 2048) cfg = 74;
-    else cfg = 21;
+    cfg = (a.K >= 1408 && t256 >= 128) ? 82 : 21;
   }
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 0, 0, 0>(a, st);
@@ -290,6 +429,8 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
     case 31: return launch_cfg<128, 128, 2, 2, 1, 1, 0>(a, st);
     case 32: return launch_cfg<256, 256, 4, 2, 1, 1, 0>(a, st);
     case 33: return launch_cfg<256, 128, 4, 2, 1, 1, 0>(a, st);
+    case 82: return launch_pp<1, 0>(a, st);
+    case 83: return launch_pp<2, 0>(a, st);
     case 72: return launch_cfg<256, 256, 4, 2, 0, 3, 2>(a, st);   // cfg 52 with the un-counted (asm) DMA
     case 73: return launch_cfg<256, 128, 4, 2, 0, 3, 3>(a, st);   // 3-deep ring, 144 KB
     case 74: return launch_cfg<128, 256, 2, 4, 0, 3, 3>(a, st);

@@ -20,82 +20,81 @@
 
 #define BK 64  // K tile (bf16 elements) == one 128-byte LDS row
 
-template <int TM, int TN, int MB, int NB>
+// Epilogue.  EPI >= 0 encodes the flag set at compile time (act | out_f32<<2 | resid<<3 | gamma<<4 | bias<<5) so the
+// hot instantiations carry no per-element branching; EPI = -1 reads the flags at run time (tests, rare shapes).
+// A lane owns row m = ..+(lane&31) and, per 32x32 block, four groups of 4 consecutive columns n = ..+8*b+4*h.
+template <int TM, int TN, int MB, int NB, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16_t (&acc)[NB][MB], int m0, int n0, int wm, int wn, int l31, int h) {
-  // ---- epilogue: lane owns row m = ..+(lane&31), columns n = ..+8*b+4*h+{0..3} --------------------
+  const int act = EPI >= 0 ? (EPI & 3) : a.act;
+  const bool out_f32 = EPI >= 0 ? ((EPI >> 2) & 1) : (a.out_f32 != 0);
+  const bool has_resid = EPI >= 0 ? ((EPI >> 3) & 1) : (a.resid != nullptr);
+  const bool has_gamma = EPI >= 0 ? ((EPI >> 4) & 1) : (a.gamma != nullptr);
+  const bool has_bias = EPI >= 0 ? ((EPI >> 5) & 1) : (a.bias != nullptr);
+  const int nbase = n0 + wn * TN + 4 * h;
 #pragma unroll
   for (int j = 0; j < MB; ++j) {
     const int m = m0 + wm * TM + j * 32 + l31;
     if (m >= a.M) continue;
     const size_t orow = a.grp_rows ? (size_t)(m / a.grp_rows) * a.grp_stride + (m % a.grp_rows) + a.row_off : (size_t)m + a.row_off;
+    char* crow = (char*)a.C + orow * a.ldc * (out_f32 ? 4 : 2);
+    const char* rrow = has_resid ? (const char*)a.resid + orow * a.ldr * (out_f32 ? 4 : 2) : nullptr;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const int n = n0 + wn * TN + i * 32 + 8 * b + 4 * h;
+        const int n = nbase + i * 32 + 8 * b;
         if (n >= a.N) continue;
         float v[4] = {acc[i][j][4 * b + 0], acc[i][j][4 * b + 1], acc[i][j][4 * b + 2], acc[i][j][4 * b + 3]};
-        if (a.bias) {
+        if (has_bias) {
           const f32x4_t bv = *(const f32x4_t*)(a.bias + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bv[e];
         }
-        if (a.act == GVL_ACT_SILU_MUL) {
+        if (act == GVL_ACT_SILU_MUL) {
           // interleaved (gate, up) pairs -> 2 outputs at column n/2.  reference: up * silu(gate), each op in bf16
           float o2[2];
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const float g = rbf(v[2 * e]), u = rbf(v[2 * e + 1]);
-            const float sg = rbf(g * fast_sigmoid(g));
-            o2[e] = u * sg;
+            o2[e] = u * rbf(g * fast_sigmoid(g));
           }
-          bf16_t* cp = (bf16_t*)a.C + orow * a.ldc + (n >> 1);
-          *(unsigned*)cp = pack2bf(o2[0], o2[1]);
+          *(unsigned*)(crow + (n >> 1) * 2) = pack2bf(o2[0], o2[1]);
           continue;
         }
+        if (act == GVL_ACT_QUICK_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x = v[e];
-          if (a.act == GVL_ACT_QUICK_GELU) {
-            x = rbf(x);
-            const float s = rbf(fast_sigmoid(rbf(1.702f * x)));
-            x = x * s;
-          } else if (a.act == GVL_ACT_GELU) {
-            x = rbf(x);
-            x = gelu_erf(x);
-          }
-          v[e] = x;
+          for (int e = 0; e < 4; ++e) { const float x = rbf(v[e]); v[e] = x * rbf(fast_sigmoid(rbf(1.702f * x))); }
+        } else if (act == GVL_ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(rbf(v[e]));
         }
-        if (a.gamma) {
+        if (has_gamma) {
           const f32x4_t gv = *(const f32x4_t*)(a.gamma + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) * gv[e];
         }
-        if (a.out_f32) {
-          float* cp = (float*)a.C + orow * a.ldc + n;
-          if (a.resid) {
-            const f32x4_t rv = *(const f32x4_t*)((const float*)a.resid + orow * a.ldr + n);
+        if (out_f32) {
+          if (has_resid) {
+            const f32x4_t rv = *(const f32x4_t*)(rrow + n * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = rv[e] + (a.round_pre_resid ? rbf(v[e]) : v[e]);
           }
-          f32x4_t o = {v[0], v[1], v[2], v[3]};
-          *(f32x4_t*)cp = o;
+          const f32x4_t o = {v[0], v[1], v[2], v[3]};
+          *(f32x4_t*)(crow + n * 4) = o;
         } else {
-          bf16_t* cp = (bf16_t*)a.C + orow * a.ldc + n;
-          if (a.resid) {
-            const u32x2_t rv = *(const u32x2_t*)((const bf16_t*)a.resid + orow * a.ldr + n);
-            const float r0 = lo_bf(rv[0]), r1 = hi_bf(rv[0]), r2 = lo_bf(rv[1]), r3 = hi_bf(rv[1]);
-            v[0] = r0 + rbf(v[0]); v[1] = r1 + rbf(v[1]); v[2] = r2 + rbf(v[2]); v[3] = r3 + rbf(v[3]);
+          if (has_resid) {
+            const u32x2_t rv = *(const u32x2_t*)(rrow + n * 2);
+            v[0] = lo_bf(rv[0]) + rbf(v[0]); v[1] = hi_bf(rv[0]) + rbf(v[1]); v[2] = lo_bf(rv[1]) + rbf(v[2]); v[3] = hi_bf(rv[1]) + rbf(v[3]);
           }
-          u32x2_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          *(u32x2_t*)cp = o;
+          const u32x2_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(u32x2_t*)(crow + n * 2) = o;
         }
       }
     }
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS, int EPI>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
   constexpr int NWAVES = WAVES_M * WAVES_N;
   constexpr int NT = NWAVES * 64;
@@ -248,7 +247,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
     }
   }
 
-  gemm_epilogue<TM, TN, MB, NB>(a, acc, m0, n0, wm, wn, l31, h);
+  gemm_epilogue<TM, TN, MB, NB, EPI>(a, acc, m0, n0, wm, wn, l31, h);
 }
 
 // =====================================================================================================
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
 // barrier 8t+7 for BOTH groups; the first read of tile t+1 (group 0, step 0) comes after that barrier.  The DMA for
 // tile t+1 overwrites the slot of tile t-1, last read before barrier 8t-1; it is issued after that barrier.
 // =====================================================================================================
-template <int BM, int BN, int KPP, int DMODE>
+template <int BM, int BN, int KPP, int DMODE, int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
   constexpr int WAVES_M = 4, WAVES_N = 2, NWAVES = 8, NT = 512;
   constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, MB = TM / 32, NB = TN / 32;
@@ -372,14 +371,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
   }
   if (grp == 0) PP_BARRIER();                     // pairs with the extra barrier group 1 took at the start
 #undef PP_BARRIER
-  gemm_epilogue<TM, TN, MB, NB>(a, acc, m0, n0, wm, wn, l31, h);
+  gemm_epilogue<TM, TN, MB, NB, EPI>(a, acc, m0, n0, wm, wn, l31, h);
 }
 
-template <int KPP, int DMODE>
+template <int KPP, int DMODE, int EPI>
 static int launch_pp(const GemmArgs& a, hipStream_t st) {
   constexpr int BM = 256, BN = 256, LDS = 2 * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = gemm_pp_kernel<BM, BN, KPP, DMODE>;
+  auto kern = gemm_pp_kernel<BM, BN, KPP, DMODE, EPI>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
     attr_set = true;
@@ -389,12 +388,12 @@ static int launch_pp(const GemmArgs& a, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS, int EPI = -1>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int LDS = (NS == 0 ? 2 : NS) * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, STAG, NS>;
+  auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, STAG, NS, EPI>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
     attr_set = true;
@@ -419,31 +418,32 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     cfg = (a.K >= 1408 && t256 >= 128) ? 82 : 21;
   }
+  const int epi = (a.act & 3) | ((a.out_f32 ? 1 : 0) << 2) | ((a.resid ? 1 : 0) << 3) | ((a.gamma ? 1 : 0) << 4) | ((a.bias ? 1 : 0) << 5);
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 0, 0, 0>(a, st);
     case 2: return launch_cfg<256, 256, 4, 2, 0, 0, 0>(a, st);
     case 3: return launch_cfg<256, 128, 4, 2, 0, 0, 0>(a, st);
-    case 21: return launch_cfg<128, 128, 2, 2, 0, 1, 0>(a, st);
-    case 22: return launch_cfg<256, 256, 4, 2, 0, 1, 0>(a, st);
-    case 23: return launch_cfg<256, 128, 4, 2, 0, 1, 0>(a, st);
-    case 31: return launch_cfg<128, 128, 2, 2, 1, 1, 0>(a, st);
-    case 32: return launch_cfg<256, 256, 4, 2, 1, 1, 0>(a, st);
-    case 33: return launch_cfg<256, 128, 4, 2, 1, 1, 0>(a, st);
-    case 82: return launch_pp<1, 0>(a, st);
-    case 83: return launch_pp<2, 0>(a, st);
+    case 21: {
+      switch (epi) {
+#define S_CASE(E) case E: return launch_cfg<128, 128, 2, 2, 0, 1, 0, E>(a, st);
+        S_CASE(0) S_CASE(32) S_CASE(33) S_CASE(34) S_CASE(3) S_CASE(44) S_CASE(56) S_CASE(8) S_CASE(4) S_CASE(36)
+#undef S_CASE
+        default: return launch_cfg<128, 128, 2, 2, 0, 1, 0, -1>(a, st);
+      }
+    }
+    case 82: {
+      switch (epi) {
+#define PP_CASE(E) case E: return launch_pp<1, 0, E>(a, st);
+        PP_CASE(0) PP_CASE(32) PP_CASE(33) PP_CASE(34) PP_CASE(3) PP_CASE(44) PP_CASE(56) PP_CASE(8) PP_CASE(4) PP_CASE(36)
+#undef PP_CASE
+        default: return launch_pp<1, 0, -1>(a, st);
+      }
+    }
+    case 83: return launch_pp<2, 0, -1>(a, st);
     case 72: return launch_cfg<256, 256, 4, 2, 0, 3, 2>(a, st);   // cfg 52 with the un-counted (asm) DMA
     case 73: return launch_cfg<256, 128, 4, 2, 0, 3, 3>(a, st);   // 3-deep ring, 144 KB
     case 74: return launch_cfg<128, 256, 2, 4, 0, 3, 3>(a, st);
-    case 75: return launch_cfg<256, 128, 4, 2, 0, 0, 3>(a, st);
-    case 71: return launch_cfg<128, 128, 2, 2, 0, 1, 3>(a, st);   // 96 KB: one block / CU
-    case 42: return launch_cfg<256, 256, 4, 2, 0, 2, 0>(a, st);
     case 52: return launch_cfg<256, 256, 4, 2, 0, 3, 0>(a, st);
-    case 62: return launch_cfg<256, 256, 4, 2, 1, 3, 0>(a, st);
-    case 11: return launch_cfg<128, 128, 2, 2, 1, 0, 0>(a, st);
-    case 12: return launch_cfg<256, 256, 4, 2, 1, 0, 0>(a, st);
-    case 13: return launch_cfg<256, 128, 4, 2, 1, 0, 0>(a, st);
-    case 14: return launch_cfg<256, 256, 2, 4, 1, 0, 0>(a, st);
-    case 15: return launch_cfg<128, 256, 2, 4, 1, 0, 0>(a, st);
     default: return -1;
   }
 }

@@ -17,6 +17,7 @@
 //   * XCD-aware block order: each of the 8 XCDs gets a contiguous range of tiles so that the
 //     A row-panel of a tile row stays in that XCD's private L2.
 #include "gvl_internal.h"
+#include <cstdlib>
 
 #define BK 64  // K tile (bf16 elements) == one 128-byte LDS row
 
@@ -388,6 +389,10 @@ static int launch_pp(const GemmArgs& a, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// (A second ping-pong variant with a 4-slot ring of HALF k-tiles -- 64-byte LDS rows, 2 DMA pieces per phase, counted
+//  vmcnt(8) -- was built and measured 10-15 % SLOWER than gemm_pp_kernel on every hot-path shape (64-byte DMA rows fetch
+//  each 128-byte line twice); it was removed.  See DESIGN.md §3.1 and profiles/r01_gemm_microbench_pp.txt.)
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS, int EPI = -1>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -410,6 +415,8 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.K % BK != 0 || a.N % 4 != 0 || a.lda % 8 != 0) return -1;   // K padded to 64 by the packer; 16-byte rows
   if (a.act == GVL_ACT_SILU_MUL && (a.out_f32 || a.resid || a.gamma)) return -1;
   int cfg = a.tile_cfg;
+  static const int env_cfg = [] { const char* e = getenv("GVL_GEMM_CFG"); return e ? atoi(e) : 0; }();   // experiments only
+  if (cfg == 0 && env_cfg) cfg = env_cfg;
   if (cfg == 0) {
     // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_microbench*.txt):
     //  * cfg 82 = 256x256 ping-pong kernel: best whenever K is long enough to amortise its un-overlapped

@@ -1,0 +1,61 @@
+"""-m gpu: the top-level surface LLAVA_NEXT_VIDEO(...).generate(samples, **kw) (the reference's models/llava_next_video.py:616-666
+contract) end to end on a small model: prompt plumbing -> encode_images -> splice -> prefill -> paged greedy decode -> text,
+against the CPU oracle run on the same seeded weights/pixels."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gvl_oracle as O  # noqa: E402
+from gpu_util import DEV, bf  # noqa: E402
+from grounded_video_llm_amd import engine as E, prompts as P, synth  # noqa: E402
+from grounded_video_llm_amd.model import LLAVA_NEXT_VIDEO, SyntheticTokenizer  # noqa: E402
+
+
+@pytest.mark.parametrize("llm", ["phi3.5", "llama3"])
+def test_generate_matches_oracle(llm):
+    hid, vocab = 128, 640
+    kind = "phi3" if llm == "phi3.5" else "llama"
+    short, long = synth.longrope_factors(32)
+    geo = E.TowerGeometry(llm=llm, clip_hidden=64, clip_inter=128, clip_layers=3, clip_heads=4, iv2_dim=64, iv2_inter=128, iv2_depth=3,
+                          iv2_heads=4, hidden=hid, inter=256, layers=2, heads=4, kv_heads=4 if kind == "phi3" else 2, vocab=vocab,
+                          rope_short=short if kind == "phi3" else None, rope_long=long if kind == "phi3" else None,
+                          rope_theta=10000.0 if kind == "phi3" else 500000.0, max_seq=2048, max_segs=2, kv_pages=40, max_prefill=1024)
+    sd = {"vision_tower": synth.clip_weights(64, 128, 3, seed="gen.clip"),
+          "video_encoder": synth.iv2_weights(64, 128, 3, 2, seed="gen.iv2"),
+          "projectors": synth.projector_weights(llm, hid, 64, 64, seed="gen.proj"),
+          "language_model": synth.llm_weights(kind, hid, 256, 2, 4, geo.kv_heads, vocab, True, seed="gen.llm")}
+    tok = SyntheticTokenizer(vocab, 300)
+    model = LLAVA_NEXT_VIDEO(stage="sft", max_txt_len=64, num_frames=4, num_segs=2, num_temporal_tokens=300, lora=False, llm=llm,
+                             geometry=geo, tokenizer=tok, state_dicts=sd, device=DEV)
+    sp = synth.det_tensor("gen.sp", (1, 2, 3, 336, 336))
+    tp = synth.det_tensor("gen.tp", (1, 4, 3, 224, 224))
+    prompt = P.build_prompt(llm, "grounding", "When does the person open the door in the video?")
+    samples = {"prompts": [prompt], "spatial_pixel_values": sp.to(DEV), "temporal_pixel_values": tp.to(DEV), "video_ids": ["synthetic"]}
+    # --- oracle on the same inputs
+    ids = O.tokenizer_image_token(prompt, tok, tok.bos_token_id)
+    assert ids == model.tokenizer_image_token(prompt) and ids.count(-200) == 1
+    ref_vis = O.encode_images(sp, tp, sd["vision_tower"], sd["video_encoder"], sd["projectors"], llm, clip_layers=3, clip_heads=4,
+                              iv2_depth=3, iv2_heads=4, emu=True)[0]
+    ocfg = O.LLMConfig(kind, hid, 256, 2, 4, geo.kv_heads, vocab, 1e-5, geo.rope_theta, 131072, 4096, geo.rope_short, geo.rope_long)
+    ref_emb = O.splice(torch.tensor(ids), ref_vis, sd["language_model"]["model.embed_tokens.weight"], emu=True)
+    ref_ids, margins = O.greedy_generate(ocfg, sd["language_model"], ref_emb, 10, tok.eos_token_id, emu=True, return_margins=True)
+    # --- product
+    feats = model.encode_images(samples)
+    err = float((feats[0].float().cpu() - ref_vis).abs().max() / ref_vis.abs().max())
+    print(f"[parity] generate({llm}): visual tokens rel err {err:.2e}")
+    assert list(feats.shape) == [1, 2 * model.engine.tokens_per_seg, hid] and err < 2e-2
+    ids_arr, mask = P.left_pad_truncate([ids], tok.pad_token_id, model.max_txt_len)
+    got = model.generate_ids(ids_arr, mask, feats, 10)[0]
+    for i, (a, b) in enumerate(zip(got, ref_ids)):
+        if a != b:
+            assert margins[i] < 0.05, f"token {i}: {a} vs {b}, oracle margin {margins[i]}"
+            break
+    else:
+        assert len(got) == len(ref_ids)
+    texts = model.generate(samples, do_sample=False, num_beams=1, max_new_tokens=10)
+    assert isinstance(texts, list) and len(texts) == 1 and texts[0] == tok.batch_decode([got], skip_special_tokens=True)[0].strip()
+    with pytest.raises(NotImplementedError):
+        model.generate(samples, do_sample=True)
+    print(f"[parity] generate({llm}) ids {got} oracle {ref_ids}; text {texts[0]!r}")
+    model.engine.close()

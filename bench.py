@@ -73,14 +73,10 @@ class Stepper:
         self.L = eng.tokens_per_seg
         self.decode_s = 0.0
         if world > 1:
-            # clip c's segment block b goes to rank (b + c) % world; this rank therefore needs, from every clip c,
-            # block (rank - c) % world.  Synthetic pixels: every rank generates the segments it encodes itself.
-            self.bounds = gdist.shard_bounds(12, world)
-            self.mine = []          # (clip, lo, hi) in encode order
-            for c in range(world):
-                lo, hi = self.bounds[(rank - c) % world]
-                if hi > lo:
-                    self.mine.append((c, lo, hi))
+            # clip c's segment block b goes to rank (b + c) % world (dist.rotated_encode_plan): every rank encodes exactly 12
+            # segments.  Synthetic pixels: every rank generates the segments it encodes itself.
+            self.mine = gdist.rotated_encode_plan(12, rank, world)
+            self.gather = gdist.rotated_gather_index(12, rank, world)
             n_mine = sum(h - l for _, l, h in self.mine)
             assert n_mine == 12
             g = torch.Generator(device=self.dev); g.manual_seed(1000 + rank)
@@ -92,22 +88,12 @@ class Stepper:
         vis = eng.encode_segments(self.sp, self.tp)                     # [12*L, hidden]
         if self.world > 1:
             recv = torch.empty((self.world * vis.shape[0], vis.shape[1]), dtype=bf, device=self.dev)
-            torch.distributed.all_gather_into_tensor(recv, vis)           # ONE collective per step (RCCL over xGMI)
+            if torch.distributed.get_backend() == "gloo":                 # debug only (GVL_BENCH_BACKEND=gloo): stage through the host
+                rc = recv.cpu(); torch.distributed.all_gather_into_tensor(rc, vis.cpu()); recv.copy_(rc)
+            else:
+                torch.distributed.all_gather_into_tensor(recv, vis)       # ONE collective per step (RCCL over xGMI)
             recv = recv.view(self.world, 12 * self.L, -1)
-            # reassemble clip == rank: block b was encoded by rank (b + rank) % world, at that rank's offset for this clip
-            parts = []
-            for b, (lo, hi) in enumerate(self.bounds):
-                if hi == lo:
-                    continue
-                src = (b + self.rank) % self.world
-                off = 0
-                for c in range(self.world):          # offset of clip `rank`'s block inside src's encode order
-                    l2, h2 = self.bounds[(src - c) % self.world]
-                    if c == self.rank:
-                        break
-                    off += h2 - l2
-                parts.append(recv[src, off * self.L:(off + hi - lo) * self.L])
-            vis = torch.cat(parts, 0)
+            vis = torch.cat([recv[src, off * self.L:(off + n) * self.L] for src, off, n in self.gather], 0)   # clip == rank, segment order
         emb = eng.splice(self.ids, vis)
         seq = eng.seq_alloc(emb.shape[0] + self.new_tokens)
         eng.prefill(seq, emb)
@@ -168,10 +154,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("GVL_BENCH_BACKEND", "nccl")        # "gloo" + GVL_BENCH_SAME_DEVICE=1: debug the N>1 path on one GPU
+    if os.environ.get("GVL_BENCH_SAME_DEVICE"):
+        local = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            torch.distributed.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
@@ -194,7 +186,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     clips_per_s = world * args.steps / dt
@@ -215,8 +207,14 @@ def main():
     eng.prof_enable(False)
     g = prof["gemm"]
     gemm_tflops = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)", "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+    traffic = None   # HBM-side bytes per GEMM launch from the PMC passes of the same command (profiles/r01_pmc_traffic.json)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fpm:
+            traffic = json.load(fpm)["families"]["gemm"]["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)", "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 2), "launches_per_step": g["launches"],
                 "algorithmic_tflop_per_step": round(g["work"] / 1e12, 2)}
     stages = {}

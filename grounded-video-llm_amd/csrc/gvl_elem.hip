@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[r] += lo_bf(w0[r][e]) * lo_bf(xv[e]) + hi_bf(w0[r][e]) * hi_bf(xv[e]);
   }
-#pragma unroll 2
+#pragma unroll (R >= 6 ? 2 : 4)
   for (int c = lane + 64; c < K8; c += 64) {
     u32x4_t wv[R];
 #pragma unroll

@@ -53,3 +53,33 @@ def allgather_visual(local: torch.Tensor, n_units: int, rows_per_unit: int, grou
     recv = recv.view(world, max_units * rows_per_unit, D)
     parts = [recv[r, : (b[1] - b[0]) * rows_per_unit] for r, b in enumerate(bounds)]
     return torch.cat(parts, dim=0)
+
+
+# ---- N clips in flight (bench.py --gpus N): every clip's segment batch is sharded over ALL ranks, with the block
+# assignment rotated per clip so that the n_units % world remainder balances (each rank encodes exactly n_units units).
+def rotated_encode_plan(n_units: int, rank: int, world: int) -> List[Tuple[int, int, int]]:
+    """Units this rank encodes, in encode order: [(clip, lo, hi)].  Block b of clip c goes to rank (b + c) % world."""
+    bounds = shard_bounds(n_units, world)
+    plan = []
+    for c in range(world):
+        lo, hi = bounds[(rank - c) % world]
+        if hi > lo:
+            plan.append((c, lo, hi))
+    return plan
+
+
+def rotated_gather_index(n_units: int, rank: int, world: int) -> List[Tuple[int, int, int]]:
+    """Where clip == rank's units sit after the all-gather: [(src_rank, unit_offset_in_src, n)] in unit order 0..n_units."""
+    bounds = shard_bounds(n_units, world)
+    out = []
+    for b, (lo, hi) in enumerate(bounds):
+        if hi == lo:
+            continue
+        src = (b + rank) % world
+        off = 0
+        for c, l2, h2 in rotated_encode_plan(n_units, src, world):
+            if c == rank:
+                break
+            off += h2 - l2
+        out.append((src, off, hi - lo))
+    return out

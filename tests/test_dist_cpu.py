@@ -47,3 +47,22 @@ def test_allgather_visual_gloo_world2(n_units, rows):
     res = sorted(q.get(timeout=120) for _ in ps)
     [p.join(60) for p in ps]
     assert res == [(0, True), (1, True)]
+
+
+def test_rotated_plan_balances_and_reassembles():
+    """bench.py's N-clips-in-flight plan: every rank encodes exactly n units, and after the all-gather every rank can
+    rebuild ITS clip's units in order (simulated without processes)."""
+    n = 12
+    for world in (1, 2, 3, 4, 8):
+        enc = {}
+        for r in range(world):
+            plan = gdist.rotated_encode_plan(n, r, world)
+            assert sum(h - l for _, l, h in plan) == n                      # balanced: 12 segments per rank
+            enc[r] = [(c, u) for c, lo, hi in plan for u in range(lo, hi)]  # what rank r holds, in encode order
+        covered = sorted(x for r in range(world) for x in enc[r])
+        assert covered == [(c, u) for c in range(world) for u in range(n)]  # every (clip, unit) encoded exactly once
+        for r in range(world):
+            got = []
+            for src, off, cnt in gdist.rotated_gather_index(n, r, world):
+                got += enc[src][off: off + cnt]
+            assert got == [(r, u) for u in range(n)], (world, r, got)

@@ -83,7 +83,9 @@ class Stepper:
             self.sp = torch.randn((n_mine, 3, 336, 336), device=self.dev, generator=g)
             self.tp = torch.randn((n_mine, 3, 8, 224, 224), device=self.dev, generator=g)
 
-    def step(self):
+    # ---- the three stages of one clip ---------------------------------------------------------------------
+    def encode(self):
+        """vision towers + projectors for this rank's 12 segments (+ the all-gather for N > 1) -> visual tokens of THIS rank's clip."""
         eng = self.eng
         vis = eng.encode_segments(self.sp, self.tp)                     # [12*L, hidden]
         if self.world > 1:
@@ -94,17 +96,54 @@ class Stepper:
                 torch.distributed.all_gather_into_tensor(recv, vis)       # ONE collective per step (RCCL over xGMI)
             recv = recv.view(self.world, 12 * self.L, -1)
             vis = torch.cat([recv[src, off * self.L:(off + n) * self.L] for src, off, n in self.gather], 0)   # clip == rank, segment order
+        return vis
+
+    def llm(self, vis):
+        eng = self.eng
         emb = eng.splice(self.ids, vis)
         seq = eng.seq_alloc(emb.shape[0] + self.new_tokens)
         eng.prefill(seq, emb)
+        return seq, emb.shape[0]
+
+    def decode(self, seq):
         if self.time_decode:
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()
         t0 = time.perf_counter()
-        out = eng.decode_greedy(seq, self.new_tokens, None)            # synchronises the stream
+        out = self.eng.decode_greedy(seq, self.new_tokens, None)       # synchronises its stream
         if self.time_decode:
             self.decode_s += time.perf_counter() - t0
-        eng.seq_free(seq)
-        return out, emb.shape[0]
+        self.eng.seq_free(seq)
+        return out
+
+    def step(self):
+        """One clip, stages back to back on one stream (single-clip latency)."""
+        vis = self.encode()
+        seq, S = self.llm(vis)
+        return self.decode(seq), S
+
+    # ---- two clips in flight per GPU: vision of clip k+1 overlaps the (HBM-bound) decode of clip k ---------------
+    def pipe_start(self):
+        self.sV, self.sL = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        self.evV, self.evL = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(self.sV):
+            self.vis_next = self.encode()
+            self.evV.record(self.sV)
+
+    def pipe_step(self):
+        """Completes ONE clip (prefill + decode) and launches ONE clip's vision encode for the next step."""
+        with torch.cuda.stream(self.sL):
+            self.sL.wait_event(self.evV)                   # this clip's visual tokens are ready
+            vis = self.vis_next
+            vis.record_stream(self.sL)
+            seq, S = self.llm(vis)                         # splice + prefill (uses the workspace arena)
+            self.evL.record(self.sL)
+        with torch.cuda.stream(self.sV):
+            self.sV.wait_event(self.evL)                   # the arena is free again: next clip's towers may run ...
+            self.vis_next = self.encode()                  # ... concurrently with the decode below (MFMA-bound vs HBM-bound)
+            self.evV.record(self.sV)
+        with torch.cuda.stream(self.sL):
+            out = self.decode(seq)
+        return out, S
 
     time_decode = False
 
@@ -149,6 +188,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--new-tokens", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["pipelined", "serial"], default="pipelined",
+                    help="pipelined: 2 clips in flight per GPU (vision of clip k+1 overlaps decode of clip k); serial: one clip at a time")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,13 +218,18 @@ def main():
         torch.cuda.synchronize()
 
     S = 0
+    if args.mode == "pipelined":
+        st.pipe_start()
+        stepfn = st.pipe_step
+    else:
+        stepfn = st.step
     for _ in range(args.warmup):
-        _, S = st.step()
+        _, S = stepfn()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        _, S = st.step()
-    barrier()
+        _, S = stepfn()
+    barrier()                       # torch.cuda.synchronize(): every stream, incl. the vision encode launched by the last step
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -191,7 +237,13 @@ def main():
         dt = float(tt.item())
     clips_per_s = world * args.steps / dt
 
-    # ---- untimed extras: decode-only rate, per-kernel-family profile, CPU baseline -------------------------
+    # ---- untimed extras: single-clip latency, decode-only rate, per-kernel-family profile, CPU baseline -----
+    torch.cuda.synchronize()
+    tl = time.perf_counter()
+    for _ in range(2):
+        st.step()
+    torch.cuda.synchronize()
+    latency_ms = 1e3 * (time.perf_counter() - tl) / 2
     st.time_decode = True
     st.decode_s = 0.0
     for _ in range(2):
@@ -233,9 +285,10 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights at full shape, N(0,1) pixels)",
                "config": {"workload": "Phi-3.5-3.8B, 96 frames (12 segs x 8), 336^2 spatial + 224^2 temporal, ~100-token prompt, "
-                                      f"{args.new_tokens} greedy tokens, 1 clip per GPU per step", "prefill_len": S, "visual_tokens": 12 * st.L,
+                                      f"{args.new_tokens} greedy tokens, 1 clip per GPU per step" + (" (2 clips in flight per GPU: vision encode of clip k+1 overlaps the decode of clip k)" if args.mode == "pipelined" else ""), "prefill_len": S, "visual_tokens": 12 * st.L,
                           "parallelism": "1 GPU" if world == 1 else f"frame-batch sharded over {world} GPUs + all-gather of visual tokens, LLM replica per clip"},
                "decode_tokens_per_s": None if decode_tok_s is None else round(world * decode_tok_s, 1),
+               "single_clip_latency_ms": round(latency_ms, 2), "mode": args.mode,
                "roofline": roofline, "stages": stages}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(geo)

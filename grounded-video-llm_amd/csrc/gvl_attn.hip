@@ -251,8 +251,10 @@ double gvl_attn_flops(const AttnArgs& a) {
 int gvl_launch_attention(const AttnArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.S <= 0 || a.S > 256 * 64 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 3)) return -1;
   switch (a.D) {
-    case 64: return launch_attn<64, 4, 3>(a, st);
-    case 96: return launch_attn<96, 4, 3>(a, st);
+    // ring depth 2: 48 KB (D=96) -> 3 blocks / CU at 151 VGPRs (measured 427 us vs 461 us for the 73 KB depth-3 ring, which
+    // caps residency at 2 blocks / CU; DMA latency is not the limiter -- PMC shows the kernel is VALU-issue-bound)
+    case 64: return launch_attn<64, 4, 2>(a, st);
+    case 96: return launch_attn<96, 4, 2>(a, st);
     case 128: return launch_attn<128, 4, 2>(a, st);
     default: return -1;
   }

@@ -354,8 +354,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
 #pragma unroll
         for (int j = 0; j < MB; ++j) af[u][j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
       }
-      if (ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
-      if (DMODE == 0 && ph == NPH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (DMODE != 2 && ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
+      if (DMODE != 1 && ph == NPH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       PP_BARRIER();
       // ---- MFMA phase -------------------------------------------------------------------------------
       __builtin_amdgcn_s_setprio(1);
@@ -366,6 +366,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
 #pragma unroll
           for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][i], af[u][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
+      // DMODE 2: the DMA pieces are issued BEHIND this phase's MFMAs (they execute for ~256 cycles after issue), so the LOAD
+      // phase carries only the 6 ds_reads and stays shorter than the partner wave's MFMA phase
+      if (DMODE == 2 && ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
       if (DMODE == 1 && ph == NPH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       PP_BARRIER();
     }

@@ -63,6 +63,8 @@ struct gvl_ctx {
   // KV pool
   bf16_t *kpool = nullptr, *vpool = nullptr; size_t layer_stride = 0; std::vector<int> free_pages;
   std::vector<Seq> seqs;
+  static constexpr int kMaxSeqs = 64;
+  int* d_seq_tables = nullptr; int* d_seq_pos = nullptr; int seq_table_cap = 0;   // [kMaxSeqs][seq_table_cap], [kMaxSeqs]
   // decode buffers
   bf16_t *d_x = nullptr, *d_qkv = nullptr, *d_q = nullptr, *d_attn = nullptr, *d_act = nullptr;
   float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_tok = nullptr, *d_step = nullptr, *d_outlist = nullptr, *d_ids = nullptr;
@@ -422,6 +424,9 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
     ok &= hipMalloc((void**)&ctx->d_counters, (size_t)f.heads * 4) == hipSuccess && hipMemset(ctx->d_counters, 0, (size_t)f.heads * 4) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_tok, 4) == hipSuccess && hipMalloc((void**)&ctx->d_step, 4) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_outlist, (size_t)ctx->outlist_cap * 4) == hipSuccess;
+    ctx->seq_table_cap = (f.max_seq + 63) / 64;
+    ok &= hipMalloc((void**)&ctx->d_seq_tables, (size_t)gvl_ctx::kMaxSeqs * ctx->seq_table_cap * 4) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_seq_pos, (size_t)gvl_ctx::kMaxSeqs * 4) == hipSuccess;
     if (!ok) { gvl_destroy(ctx); return fail(nullptr, GVL_ERR_OOM, "hipMalloc(decode buffers) failed"); }
   }
   if (hipMalloc((void**)&ctx->d_ids, (size_t)ctx->ids_cap * 4) != hipSuccess) { gvl_destroy(ctx); return fail(nullptr, GVL_ERR_OOM, "hipMalloc failed"); }
@@ -433,8 +438,7 @@ int gvl_destroy(gvl_ctx* ctx) {
   if (!ctx) return 0;
   hipDeviceSynchronize();
   for (auto& kv : ctx->w) if (kv.second.p) hipFree(kv.second.p);
-  for (auto& s : ctx->seqs) { if (s.d_block_table) hipFree(s.d_block_table); if (s.d_pos) hipFree(s.d_pos); }
-  void* ptrs[] = {ctx->arena, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_tok, ctx->d_step, ctx->d_outlist, ctx->d_ids};
+  void* ptrs[] = {ctx->arena, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_tok, ctx->d_step, ctx->d_outlist, ctx->d_ids, ctx->d_seq_tables, ctx->d_seq_pos};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& r : ctx->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   delete ctx;
@@ -587,23 +591,26 @@ int gvl_seq_alloc(gvl_ctx* ctx, int max_tokens, int* seq_id) {
   if ((int)ctx->free_pages.size() < np) return fail(ctx, GVL_ERR_OOM, "gvl_seq_alloc: KV pages exhausted");
   int id = -1;
   for (size_t i = 0; i < ctx->seqs.size(); ++i) if (!ctx->seqs[i].used) { id = (int)i; break; }
-  if (id < 0) { ctx->seqs.emplace_back(); id = (int)ctx->seqs.size() - 1; }
+  if (id < 0) {
+    if ((int)ctx->seqs.size() >= gvl_ctx::kMaxSeqs) return fail(ctx, GVL_ERR_OOM, "gvl_seq_alloc: too many live sequences");
+    ctx->seqs.emplace_back(); id = (int)ctx->seqs.size() - 1;
+  }
   Seq& s = ctx->seqs[id];
   s.used = true; s.max_tokens = max_tokens; s.n_pages = np; s.pos = 0; s.n_gen = 0; s.pages.clear();
   for (int i = 0; i < np; ++i) { s.pages.push_back(ctx->free_pages.back()); ctx->free_pages.pop_back(); }
-  HIPCHK(ctx, hipMalloc((void**)&s.d_block_table, (size_t)np * 4));
-  HIPCHK(ctx, hipMalloc((void**)&s.d_pos, 4));
-  HIPCHK(ctx, hipMemcpy(s.d_block_table, s.pages.data(), (size_t)np * 4, hipMemcpyHostToDevice));
-  HIPCHK(ctx, hipMemset(s.d_pos, 0, 4));
+  // preallocated slot: no hipMalloc / hipFree / device-wide sync per clip.  Work that uses the slot is stream ordered;
+  // a freed slot or page may be handed out again only for work enqueued later on the same stream (one stream per ctx
+  // for the LLM path -- the reference is single-stream too).
+  s.d_block_table = ctx->d_seq_tables + (size_t)id * ctx->seq_table_cap;
+  s.d_pos = ctx->d_seq_pos + id;
+  HIPCHK(ctx, hipMemcpy(s.d_block_table, s.pages.data(), (size_t)np * 4, hipMemcpyHostToDevice));   // blocking; d_pos is set by gvl_prefill on ITS stream
   *seq_id = id;
   return 0;
 }
 int gvl_seq_free(gvl_ctx* ctx, int seq_id) {
   if (!ctx || seq_id < 0 || seq_id >= (int)ctx->seqs.size() || !ctx->seqs[seq_id].used) return fail(ctx, GVL_ERR_ARG, "gvl_seq_free: bad seq");
   Seq& s = ctx->seqs[seq_id];
-  hipDeviceSynchronize();
   for (int p : s.pages) ctx->free_pages.push_back(p);
-  hipFree(s.d_block_table); hipFree(s.d_pos);
   s = Seq();
   return 0;
 }

@@ -82,7 +82,8 @@ struct GemmArgs {
   int round_pre_resid;           // 1: round (acc+bias) [and the gamma product] to bf16 before adding resid
   // output row remap: row m -> (m / grp_rows) * grp_stride + (m % grp_rows) + row_off   (grp_rows==0: identity)
   int grp_rows, grp_stride, row_off;
-  int tile_cfg;                  // 0 auto, 1 = 128x128, 2 = 256x256, 3 = 256(M)x128(N)
+  int tile_cfg;                  // 0 auto; see gvl_launch_gemm
+  int m_begin;                   // launch covers rows [m_begin, M) -- set internally by the wave-quantisation split
 };
 int gvl_launch_gemm(const GemmArgs& a, hipStream_t st);
 double gvl_gemm_flops(const GemmArgs& a);

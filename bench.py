@@ -138,14 +138,16 @@ class Stepper:
             seq, S = self.llm(vis)                         # splice + prefill (uses the workspace arena)
             self.evL.record(self.sL)
         with torch.cuda.stream(self.sV):
-            self.sV.wait_event(self.evL)                   # the arena is free again: next clip's towers may run ...
-            self.vis_next = self.encode()                  # ... concurrently with the decode below (MFMA-bound vs HBM-bound)
-            self.evV.record(self.sV)
+            if self.overlap == "decode":
+                self.sV.wait_event(self.evL)               # next clip's towers start after this clip's prefill ...
+            self.vis_next = self.encode()                  # ... and run concurrently with the decode below (MFMA-bound vs HBM-bound);
+            self.evV.record(self.sV)                       # "full": also beside the prefill (separate workspace arenas), filling its tail/launch bubbles
         with torch.cuda.stream(self.sL):
             out = self.decode(seq)
         return out, S
 
     time_decode = False
+    overlap = os.environ.get("GVL_BENCH_OVERLAP", "full")
 
 
 def cpu_baseline(geo):
@@ -227,8 +229,9 @@ def main():
         _, S = stepfn()
     barrier()
     t0 = time.perf_counter()
+    out_timed = None
     for _ in range(args.steps):
-        _, S = stepfn()
+        out_timed, S = stepfn()
     barrier()                       # torch.cuda.synchronize(): every stream, incl. the vision encode launched by the last step
     dt = time.perf_counter() - t0
     if world > 1:
@@ -241,9 +244,12 @@ def main():
     torch.cuda.synchronize()
     tl = time.perf_counter()
     for _ in range(2):
-        st.step()
+        out_serial, _ = st.step()
     torch.cuda.synchronize()
     latency_ms = 1e3 * (time.perf_counter() - tl) / 2
+    same_ids = list(out_timed) == list(out_serial)       # overlapped streams must not change the generated ids (same inputs every step)
+    if not same_ids:
+        print(f"bench: WARNING timed-mode ids {list(out_timed)} differ from serial ids {list(out_serial)}", file=sys.stderr)
     st.time_decode = True
     st.decode_s = 0.0
     for _ in range(2):
@@ -288,7 +294,7 @@ def main():
                                       f"{args.new_tokens} greedy tokens, 1 clip per GPU per step" + (" (2 clips in flight per GPU: vision encode of clip k+1 overlaps the decode of clip k)" if args.mode == "pipelined" else ""), "prefill_len": S, "visual_tokens": 12 * st.L,
                           "parallelism": "1 GPU" if world == 1 else f"frame-batch sharded over {world} GPUs + all-gather of visual tokens, LLM replica per clip"},
                "decode_tokens_per_s": None if decode_tok_s is None else round(world * decode_tok_s, 1),
-               "single_clip_latency_ms": round(latency_ms, 2), "mode": args.mode,
+               "single_clip_latency_ms": round(latency_ms, 2), "mode": args.mode, "ids_match_serial": same_ids,
                "roofline": roofline, "stages": stages}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(geo)

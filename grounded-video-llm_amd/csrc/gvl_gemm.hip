@@ -95,7 +95,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16_t (&acc)
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS, int EPI, int STG = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
   constexpr int NWAVES = WAVES_M * WAVES_N;
   constexpr int NT = NWAVES * 64;
@@ -248,7 +248,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
     }
   }
 
-  gemm_epilogue<TM, TN, MB, NB, EPI>(a, acc, m0, n0, wm, wn, l31, h);
+  if constexpr (STG != 0 && EPI >= 0) {
+    constexpr int STG_BYTES = 32 * ((EPI & 4) ? TN * 4 + 16 : TN * 2 + 16);
+    static_assert(NWAVES * STG_BYTES <= 2 * STAGE_BYTES, "staging does not fit the ring");
+    __syncthreads();                               // the other waves may still be reading the last k-tile
+    gemm_epilogue_staged<MB, NB, EPI>(a, acc, smem + wave * STG_BYTES, m0 + wm * TM, n0 + wn * TN, lane);
+  } else {
+    gemm_epilogue<TM, TN, MB, NB, EPI>(a, acc, m0, n0, wm, wn, l31, h);
+  }
 }
 
 // =====================================================================================================
@@ -262,7 +269,95 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
 // barrier 8t+7 for BOTH groups; the first read of tile t+1 (group 0, step 0) comes after that barrier.  The DMA for
 // tile t+1 overwrites the slot of tile t-1, last read before barrier 8t-1; it is issued after that barrier.
 // =====================================================================================================
-template <int BM, int BN, int KPP, int DMODE, int EPI>
+// Staged epilogue (ping-pong kernel): the natural MFMA store is one 8-byte piece per lane at a ROW stride -- a wave
+// instruction touches 32 different cache lines with 16 bytes each and the store tail is issue-bound (MI355X guide, T21).
+// Here every wave transposes its 32 x TN sub-tile through its private slice of the (now idle) LDS ring and writes whole
+// rows: 16-byte pieces, 4 (bf16) / 2 (f32) full rows per wave instruction; the residual is read the same way.
+// Requires 16-byte aligned rows (checked by the launcher); arithmetic and rounding points are those of gemm_epilogue.
+template <int MB, int NB, int EPI>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x16_t (&acc)[NB][MB], char* stg, int mw, int nw, int lane) {
+  static_assert(EPI >= 0, "staged epilogue is compile-time specialised");
+  constexpr int act = EPI & 3;
+  constexpr bool out_f32 = (EPI >> 2) & 1, has_resid = (EPI >> 3) & 1, has_gamma = (EPI >> 4) & 1, has_bias = (EPI >> 5) & 1;
+  constexpr bool silu = act == GVL_ACT_SILU_MUL;
+  constexpr int TN = NB * 32, OUTC = silu ? TN / 2 : TN, ES = out_f32 ? 4 : 2;
+  constexpr int ROWB = OUTC * ES + 16;             // +16: the column-of-rows writes spread over the banks
+  constexpr int LPR = OUTC * ES / 16, RPI = 64 / LPR;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int n_out0 = silu ? (nw >> 1) : nw, n_out_end = silu ? (a.N >> 1) : a.N;
+  const int rrow_l = lane / LPR, chunk = lane % LPR;
+#pragma unroll
+  for (int j = 0; j < MB; ++j) {
+    char* wrow = stg + l31 * ROWB;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int nl = i * 32 + 8 * b + 4 * h;
+        const int n = nw + nl;
+        float v[4] = {acc[i][j][4 * b + 0], acc[i][j][4 * b + 1], acc[i][j][4 * b + 2], acc[i][j][4 * b + 3]};
+        if (n < a.N) {
+          if (has_bias) {
+            const f32x4_t bv = *(const f32x4_t*)(a.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+          }
+          if (act == GVL_ACT_QUICK_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float x = rbf(v[e]); v[e] = x * rbf(fast_sigmoid(rbf(1.702f * x))); }
+          } else if (act == GVL_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(rbf(v[e]));
+          }
+          if (has_gamma) {
+            const f32x4_t gv = *(const f32x4_t*)(a.gamma + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) * gv[e];
+          }
+        }
+        if (silu) {
+          float o2[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) { const float g = rbf(v[2 * e]), u = rbf(v[2 * e + 1]); o2[e] = u * rbf(g * fast_sigmoid(g)); }
+          *(unsigned*)(wrow + (nl >> 1) * 2) = pack2bf(o2[0], o2[1]);
+        } else if (out_f32) {
+          if (has_resid && a.round_pre_resid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+          }
+          const f32x4_t o = {v[0], v[1], v[2], v[3]};
+          *(f32x4_t*)(wrow + nl * 4) = o;
+        } else {
+          const u32x2_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(u32x2_t*)(wrow + nl * 2) = o;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 32 / RPI; ++k) {
+      const int row = k * RPI + rrow_l;
+      const int m = mw + j * 32 + row;
+      const int nc = n_out0 + chunk * (16 / ES);
+      u32x4_t sv = *(const u32x4_t*)(stg + row * ROWB + chunk * 16);
+      if (m >= a.M || nc >= n_out_end) continue;
+      const size_t orow = a.grp_rows ? (size_t)(m / a.grp_rows) * a.grp_stride + (m % a.grp_rows) + a.row_off : (size_t)m + a.row_off;
+      char* cp = (char*)a.C + (orow * a.ldc + nc) * ES;
+      if (has_resid) {
+        const u32x4_t rv = *(const u32x4_t*)((const char*)a.resid + (orow * a.ldr + nc) * ES);
+        if (out_f32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sv[e] = __float_as_uint(__uint_as_float(rv[e]) + __uint_as_float(sv[e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sv[e] = pack2bf(lo_bf(rv[e]) + lo_bf(sv[e]), hi_bf(rv[e]) + hi_bf(sv[e]));
+        }
+      }
+      *(u32x4_t*)cp = sv;
+    }
+  }
+}
+
+template <int BM, int BN, int KPP, int DMODE, int EPI, int STG = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
   constexpr int WAVES_M = 4, WAVES_N = 2, NWAVES = 8, NT = 512;
   constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, MB = TM / 32, NB = TN / 32;
@@ -375,14 +470,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
   }
   if (grp == 0) PP_BARRIER();                     // pairs with the extra barrier group 1 took at the start
 #undef PP_BARRIER
-  gemm_epilogue<TM, TN, MB, NB, EPI>(a, acc, m0, n0, wm, wn, l31, h);
+  if constexpr (STG != 0 && EPI >= 0) {
+    // every LDS read of the ring is complete (both groups are past their last MFMA phase): reuse it as staging space
+    constexpr int STG_BYTES = 32 * ((EPI & 4) ? TN * 4 + 16 : TN * 2 + 16);
+    gemm_epilogue_staged<MB, NB, EPI>(a, acc, smem + wave * STG_BYTES, m0 + wm * TM, n0 + wn * TN, lane);
+  } else {
+    gemm_epilogue<TM, TN, MB, NB, EPI>(a, acc, m0, n0, wm, wn, l31, h);
+  }
 }
 
-template <int KPP, int DMODE, int EPI>
+template <int KPP, int DMODE, int EPI, int STG = 0>
 static int launch_pp(const GemmArgs& a, hipStream_t st) {
-  constexpr int BM = 256, BN = 256, LDS = 2 * (BM + BN) * 128;
+  constexpr int BM = 256, BN = 256, RING = 2 * (BM + BN) * 128;
+  constexpr int STGB = (STG && EPI >= 0) ? 8 * 32 * ((EPI & 4) ? 128 * 4 + 16 : 128 * 2 + 16) : 0;
+  constexpr int LDS = RING > STGB ? RING : STGB;
   static bool attr_set = false;
-  auto kern = gemm_pp_kernel<BM, BN, KPP, DMODE, EPI>;
+  auto kern = gemm_pp_kernel<BM, BN, KPP, DMODE, EPI, STG>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
     attr_set = true;
@@ -396,12 +499,12 @@ static int launch_pp(const GemmArgs& a, hipStream_t st) {
 //  vmcnt(8) -- was built and measured 10-15 % SLOWER than gemm_pp_kernel on every hot-path shape (64-byte DMA rows fetch
 //  each 128-byte line twice); it was removed.  See DESIGN.md §3.1 and profiles/r01_gemm_microbench_pp.txt.)
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS, int EPI = -1>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS, int EPI = -1, int STG = 0>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int LDS = (NS == 0 ? 2 : NS) * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, STAG, NS, EPI>;
+  auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, STAG, NS, EPI, STG>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
     attr_set = true;
@@ -453,26 +556,34 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
       }
     }
   }
+  const int es = a.out_f32 ? 4 : 2;
+  const bool stg_ok = a.N % 16 == 0 && ((size_t)a.ldc * es) % 16 == 0 && ((uintptr_t)a.C & 15) == 0 &&
+                      (!a.resid || (((size_t)a.ldr * es) % 16 == 0 && ((uintptr_t)a.resid & 15) == 0));
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 0, 0, 0>(a, st);
     case 2: return launch_cfg<256, 256, 4, 2, 0, 0, 0>(a, st);
     case 3: return launch_cfg<256, 128, 4, 2, 0, 0, 0>(a, st);
+    // cfg 21 / 82 run the LDS-staged whole-row epilogue (compile-time specialised per fused-epilogue code) whenever the
+    // output rows are 16-byte aligned; anything else takes the generic per-lane epilogue (EPI = -1).
     case 21: {
-      switch (epi) {
-#define S_CASE(E) case E: return launch_cfg<128, 128, 2, 2, 0, 1, 0, E>(a, st);
+      if (stg_ok) switch (epi) {
+#define S_CASE(E) case E: return launch_cfg<128, 128, 2, 2, 0, 1, 0, E, 1>(a, st);
         S_CASE(0) S_CASE(32) S_CASE(33) S_CASE(34) S_CASE(3) S_CASE(44) S_CASE(56) S_CASE(8) S_CASE(4) S_CASE(36)
 #undef S_CASE
-        default: return launch_cfg<128, 128, 2, 2, 0, 1, 0, -1>(a, st);
+        default: break;
       }
+      return launch_cfg<128, 128, 2, 2, 0, 1, 0, -1>(a, st);
     }
     case 82: {
-      switch (epi) {
-#define PP_CASE(E) case E: return launch_pp<1, 0, E>(a, st);
+      if (stg_ok) switch (epi) {
+#define PP_CASE(E) case E: return launch_pp<1, 0, E, 1>(a, st);
         PP_CASE(0) PP_CASE(32) PP_CASE(33) PP_CASE(34) PP_CASE(3) PP_CASE(44) PP_CASE(56) PP_CASE(8) PP_CASE(4) PP_CASE(36)
 #undef PP_CASE
-        default: return launch_pp<1, 0, -1>(a, st);
+        default: break;
       }
+      return launch_pp<1, 0, -1>(a, st);
     }
+    case 85: return launch_pp<1, 0, -1>(a, st);                   // ping-pong with the per-lane epilogue (A/B only)
     case 83: return launch_pp<2, 0, -1>(a, st);
     case 72: return launch_cfg<256, 256, 4, 2, 0, 3, 2>(a, st);   // cfg 52 with the un-counted (asm) DMA
     case 73: return launch_cfg<256, 128, 4, 2, 0, 3, 3>(a, st);   // 3-deep ring, 144 KB

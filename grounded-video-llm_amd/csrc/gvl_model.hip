@@ -59,7 +59,8 @@ struct gvl_ctx {
   const float *cos_s = nullptr, *sin_s = nullptr, *cos_l = nullptr, *sin_l = nullptr;
   std::vector<LlmLayerW> ll;
   // arena
-  char* arena = nullptr; size_t arena_bytes = 0, arena_off = 0;
+  char* arena = nullptr; size_t arena_bytes = 0, arena_off = 0;          // vision towers, glue, op-level entries
+  char* arena_l = nullptr; size_t arena_l_bytes = 0, arena_l_off = 0;    // LLM prefill (own arena: may overlap vision on another stream)
   // KV pool
   bf16_t *kpool = nullptr, *vpool = nullptr; size_t layer_stride = 0; std::vector<int> free_pages;
   std::vector<Seq> seqs;
@@ -109,6 +110,13 @@ void* arena_alloc(gvl_ctx* c, size_t bytes) {
   return c->arena + off;
 }
 #define AALLOC(var, type, count) type* var = (type*)arena_alloc(ctx, (size_t)(count) * sizeof(type)); if (!var) return fail(ctx, GVL_ERR_OOM, "workspace arena too small for " #var)
+void* arena_l_alloc(gvl_ctx* c, size_t bytes) {
+  const size_t off = al256(c->arena_l_off);
+  if (off + bytes > c->arena_l_bytes) return nullptr;
+  c->arena_l_off = off + bytes;
+  return c->arena_l + off;
+}
+#define LALLOC(var, type, count) type* var = (type*)arena_l_alloc(ctx, (size_t)(count) * sizeof(type)); if (!var) return fail(ctx, GVL_ERR_OOM, "LLM workspace arena too small for " #var)
 
 const Tensor* find(gvl_ctx* c, const std::string& n) { auto it = c->w.find(n); return it == c->w.end() ? nullptr : &it->second; }
 
@@ -273,9 +281,9 @@ int llm_prefill(gvl_ctx* ctx, Seq& sq, const bf16_t* embeds, int S, hipStream_t 
   const gvl_config& f = ctx->cfg;
   const int Hd = f.hidden, H = f.heads, KV = f.kv_heads, Dr = ctx->l_Dr, D = ctx->l_D, I = f.inter;
   const int qkvw = (H + 2 * KV) * Dr;
-  const size_t mark = ctx->arena_off;
-  AALLOC(x, bf16_t, (size_t)S * Hd); AALLOC(h, bf16_t, (size_t)S * Hd); AALLOC(qkv, bf16_t, (size_t)S * qkvw);
-  AALLOC(att, bf16_t, (size_t)S * H * Dr); AALLOC(act, bf16_t, (size_t)S * I); AALLOC(Q, bf16_t, (size_t)H * S * D);
+  const size_t mark = ctx->arena_l_off;
+  LALLOC(x, bf16_t, (size_t)S * Hd); LALLOC(h, bf16_t, (size_t)S * Hd); LALLOC(qkv, bf16_t, (size_t)S * qkvw);
+  LALLOC(att, bf16_t, (size_t)S * H * Dr); LALLOC(act, bf16_t, (size_t)S * I); LALLOC(Q, bf16_t, (size_t)H * S * D);
   HIPCHK(ctx, hipMemcpyAsync(x, embeds, (size_t)S * Hd * 2, hipMemcpyDeviceToDevice, st));
   const bool use_long = f.rope_orig_max_pos > 0 && S > f.rope_orig_max_pos && ctx->cos_l;
   const float* cs = use_long ? ctx->cos_l : ctx->cos_s; const float* sn = use_long ? ctx->sin_l : ctx->sin_s;
@@ -298,7 +306,7 @@ int llm_prefill(gvl_ctx* ctx, Seq& sq, const bf16_t* embeds, int S, hipStream_t 
   // last-row-only lm_head: final RMSNorm fused into the GEMV
   { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = ctx->l_headw; g.N = f.vocab; g.K = Hd; g.x = x + (size_t)(S - 1) * Hd; g.norm_w = ctx->l_norm; g.eps = f.rms_eps;
     g.bias = ctx->l_headb; g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, gvl_launch_gemv(g, st)); }
-  ctx->arena_off = mark;
+  ctx->arena_l_off = mark;
   return 0;
 }
 
@@ -399,11 +407,14 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
   if (ctx->has_clip) need_b = std::max(need_b, clip_bytes(ctx, ns));
   if (ctx->has_iv2) need_b = std::max(need_b, iv2_bytes(ctx, ns));
   if (ctx->has_proj) need_b = std::max(need_b, visual_bytes(ctx, ns));
-  if (ctx->has_llm && f.max_prefill > 0) need_b = std::max(need_b, prefill_bytes(ctx, f.max_prefill));
   if (ctx->has_clip && ctx->has_iv2) need_b += feats_bytes(ctx, ns);
   need_b += 64 << 20;   // slack for the operator-level test entry points
   ctx->arena_bytes = need_b;
   if (hipMalloc((void**)&ctx->arena, need_b) != hipSuccess) { delete ctx; return fail(nullptr, GVL_ERR_OOM, "hipMalloc(arena) failed"); }
+  if (ctx->has_llm && f.max_prefill > 0) {
+    ctx->arena_l_bytes = prefill_bytes(ctx, f.max_prefill) + (1 << 20);
+    if (hipMalloc((void**)&ctx->arena_l, ctx->arena_l_bytes) != hipSuccess) { gvl_destroy(ctx); return fail(nullptr, GVL_ERR_OOM, "hipMalloc(LLM arena) failed"); }
+  }
   // KV pool + decode buffers
   if (ctx->has_llm) {
     const int pages = f.kv_pages > 0 ? f.kv_pages : 1;
@@ -438,7 +449,7 @@ int gvl_destroy(gvl_ctx* ctx) {
   if (!ctx) return 0;
   hipDeviceSynchronize();
   for (auto& kv : ctx->w) if (kv.second.p) hipFree(kv.second.p);
-  void* ptrs[] = {ctx->arena, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_tok, ctx->d_step, ctx->d_outlist, ctx->d_ids, ctx->d_seq_tables, ctx->d_seq_pos};
+  void* ptrs[] = {ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_tok, ctx->d_step, ctx->d_outlist, ctx->d_ids, ctx->d_seq_tables, ctx->d_seq_pos};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& r : ctx->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   delete ctx;

@@ -17,6 +17,8 @@
 //   * XCD-aware block order: each of the 8 XCDs gets a contiguous range of tiles so that the
 //     A row-panel of a tile row stays in that XCD's private L2.
 #include "gvl_internal.h"
+#include <vector>
+#include <cstdio>
 #include <cstdlib>
 
 #define BK 64  // K tile (bf16 elements) == one 128-byte LDS row
@@ -91,6 +93,195 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16_t (&acc)
           *(u32x2_t*)(crow + n * 2) = o;
         }
       }
+    }
+  }
+}
+
+// Staged epilogue (ping-pong kernel): the natural MFMA store is one 8-byte piece per lane at a ROW stride -- a wave
+// instruction touches 32 different cache lines with 16 bytes each and the store tail is issue-bound (MI355X guide, T21).
+// Here every wave transposes its 32 x TN sub-tile through its private slice of the (now idle) LDS ring and writes whole
+// rows: 16-byte pieces, 4 (bf16) / 2 (f32) full rows per wave instruction; the residual is read the same way.
+// Requires 16-byte aligned rows (checked by the launcher); arithmetic and rounding points are those of gemm_epilogue.
+// SWZ = 1 (bf16 rows of 256 bytes only): no row padding, 16-byte chunk c of row r is stored at chunk c ^ (r & 15) -- the
+// slice is then exactly 8 KiB per wave, which lets the persistent kernel keep one ring slot free for the next tile.
+// Latency: bias / gamma go global -> per-wave LDS scratch `bg` (ONE load per lane) -> broadcast ds_read_b128, and the
+// residual pieces are requested up front into registers, so a tile pays one memory round trip instead of one per piece
+// (hipcc serialises `load; s_waitcnt; use` chains inside the unrolled loops: measured 20-39 k cycles per tile before).
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int NB, int EPI>
+struct StgGeom {                                   // compile-time geometry of one wave's staged read-back
+  static constexpr int act = EPI & 3;
+  static constexpr bool out_f32 = (EPI >> 2) & 1, has_resid = (EPI >> 3) & 1, has_gamma = (EPI >> 4) & 1, has_bias = (EPI >> 5) & 1;
+  static constexpr bool silu = act == GVL_ACT_SILU_MUL;
+  static constexpr int TN = NB * 32, OUTC = silu ? TN / 2 : TN, ES = out_f32 ? 4 : 2;
+  static constexpr int LPR = OUTC * ES / 16, RPI = 64 / LPR, KI = 32 / RPI;   // lanes / row, rows / instruction, instructions / 32-row block
+  static constexpr int CPL = TN / 64;              // bias columns per lane (2 for TN = 128, 1 for TN = 64)
+};
+// buffer descriptor over the EXISTING rows [mw, min(mw + rows, M)) of a wave tile of `base` (row pitch row_bytes): the
+// hardware bounds check then drops rows >= M, and lanes whose column is out of range use the offset 2^31 (always dropped)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stg_rsrc(const GemmArgs& a, const void* base, size_t row_bytes, int mw, int rows) {
+  const int rows_ok = a.M - mw < rows ? (a.M - mw > 0 ? a.M - mw : 0) : rows;
+  const unsigned long long p = (unsigned long long)base + (size_t)(mw + a.row_off) * row_bytes;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+  const unsigned nrec = __builtin_amdgcn_readfirstlane((unsigned)(rows_ok * row_bytes));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, nrec, 0x00020000);
+}
+// residual pieces of 32-row block j of the wave tile at (mw, nw) -> rv  (KI x 16 bytes per lane, whole rows per instruction)
+template <int MB, int NB, int EPI>
+__device__ __forceinline__ void stg_request_resid(const GemmArgs& a, int mw, int nw, int lane, int j, u32x4_t (&rv)[StgGeom<NB, EPI>::KI]) {
+  using G = StgGeom<NB, EPI>;
+  const int nc = nw + (lane % G::LPR) * (16 / G::ES);
+  const size_t ldrb = (size_t)a.ldr * G::ES;
+  const __amdgpu_buffer_rsrc_t rrs = stg_rsrc(a, a.resid, ldrb, mw, MB * 32);
+  const unsigned roff = nc < a.N ? (unsigned)((lane / G::LPR) * ldrb) + (unsigned)nc * G::ES : 0x80000000u;
+#pragma unroll
+  for (int k = 0; k < G::KI; ++k)
+    rv[k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(roff + (unsigned)((j * 32 + k * G::RPI) * ldrb)), 0, 0);
+}
+// bias / gamma slice of the wave (TN floats each): one global load per lane ...
+template <int NB, int EPI>
+__device__ __forceinline__ void stg_request_bias(const GemmArgs& a, int nw, int lane, u32x2_t& bv, u32x2_t& gv) {
+  using G = StgGeom<NB, EPI>;
+  int c0 = nw + lane * G::CPL;
+  c0 = c0 + G::CPL <= a.N ? c0 : a.N - G::CPL;     // overhanging columns read a valid address and are never stored
+  if constexpr (G::CPL == 2) {
+    if (G::has_bias) bv = *(const u32x2_t*)(a.bias + c0);
+    if (G::has_gamma) gv = *(const u32x2_t*)(a.gamma + c0);
+  } else {
+    if (G::has_bias) bv[0] = *(const unsigned*)(a.bias + c0);
+    if (G::has_gamma) gv[0] = *(const unsigned*)(a.gamma + c0);
+  }
+}
+// ... and into the wave's LDS scratch `bg` (read back as broadcast ds_read_b128 in the epilogue)
+template <int NB, int EPI>
+__device__ __forceinline__ void stg_store_bias(char* bg, int lane, const u32x2_t& bv, const u32x2_t& gv) {
+  using G = StgGeom<NB, EPI>;
+  if constexpr (G::CPL == 2) {
+    if (G::has_bias) *(u32x2_t*)(bg + lane * 8) = bv;
+    if (G::has_gamma) *(u32x2_t*)(bg + G::TN * 4 + lane * 8) = gv;
+  } else {
+    if (G::has_bias) *(unsigned*)(bg + lane * 4) = bv[0];
+    if (G::has_gamma) *(unsigned*)(bg + G::TN * 4 + lane * 4) = gv[0];
+  }
+}
+
+// PRE bit 0: the caller has already put bias/gamma into `bg`; bit 1: it has requested residual block 0 into rv (ping-pong
+// kernel: both are issued inside the main loop, so the epilogue starts with its operands on chip).
+template <int MB, int NB, int EPI, int SWZ = 0, int PRE = 0, typename Hook = NoHook>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x16_t (&acc)[NB][MB], char* stg, char* bg, int mw, int nw, int lane,
+                                                     u32x4_t (&rv)[StgGeom<NB, EPI>::KI], Hook&& after_requests = NoHook()) {
+  static_assert(EPI >= 0, "staged epilogue is compile-time specialised");
+  using G = StgGeom<NB, EPI>;
+  constexpr int act = G::act;
+  constexpr bool out_f32 = G::out_f32, has_resid = G::has_resid, has_gamma = G::has_gamma, has_bias = G::has_bias, silu = G::silu;
+  constexpr int TN = G::TN, OUTC = G::OUTC, ES = G::ES, LPR = G::LPR, RPI = G::RPI, KI = G::KI;
+  static_assert(SWZ == 0 || (OUTC * ES == 256 && !out_f32 && !silu), "swizzled staging: 256-byte bf16 rows");
+  constexpr int ROWB = OUTC * ES + (SWZ ? 0 : 16); // +16: the column-of-rows writes spread over the banks
+  const int l31 = lane & 31, h = lane >> 5;
+  const int n_out0 = silu ? (nw >> 1) : nw, n_out_end = silu ? (a.N >> 1) : a.N;
+  const int rrow_l = lane / LPR, chunk = lane % LPR;
+  const int nc = n_out0 + chunk * (16 / ES);
+  const bool col_ok = nc < n_out_end;
+
+  // ---- requests first (PRE = 0): bias / gamma slice of this wave, residual block 0 ------------------------------------
+  if constexpr ((PRE & 1) == 0 && (has_bias || has_gamma)) {
+    u32x2_t bv, gv;
+    stg_request_bias<NB, EPI>(a, nw, lane, bv, gv);
+    stg_store_bias<NB, EPI>(bg, lane, bv, gv);
+  }
+  if constexpr ((PRE & 2) == 0 && has_resid) stg_request_resid<MB, NB, EPI>(a, mw, nw, lane, 0, rv);
+  // output addressing: straight-line buffer stores (no exec-masked branches into which hipcc would sink the residual adds)
+  const size_t ldcb = (size_t)a.ldc * ES;
+  const __amdgpu_buffer_rsrc_t crs = stg_rsrc(a, a.C, ldcb, mw, MB * 32);
+  const unsigned coff = col_ok ? (unsigned)(rrow_l * ldcb) + (unsigned)nc * ES : 0x80000000u;
+  // the caller's next-tile DMA goes BEHIND the requests: vmcnt retires in order, so a wait for an operand would otherwise
+  // also wait for the whole prefetch
+  after_requests();
+
+#pragma unroll
+  for (int j = 0; j < MB; ++j) {
+    char* wrow = stg + l31 * ROWB;
+    const int wx = SWZ ? ((l31 & 15) << 4) : 0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      // bias / gamma of this 32-column block: 2 + 2 broadcast reads at a time, fenced so that hipcc does not hoist all 32
+      // reads of the tile to the top (128 VGPRs -> spills, whose reloads force vmcnt(0) in front of every store)
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+      f32x4_t bv4[4], gv4[4];
+#pragma unroll
+      for (int b = 2 * hb; b < 2 * hb + 2; ++b) {
+        if (has_bias) bv4[b] = *(const f32x4_t*)(bg + (i * 32 + 8 * b + 4 * h) * 4);
+        if (has_gamma) gv4[b] = *(const f32x4_t*)(bg + TN * 4 + (i * 32 + 8 * b + 4 * h) * 4);
+      }
+#pragma unroll
+      for (int b = 2 * hb; b < 2 * hb + 2; ++b) {
+        const int nl = i * 32 + 8 * b + 4 * h;
+        float v[4] = {acc[i][j][4 * b + 0], acc[i][j][4 * b + 1], acc[i][j][4 * b + 2], acc[i][j][4 * b + 3]};
+        if (has_bias) {
+          const f32x4_t bv = bv4[b];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        }
+        if (act == GVL_ACT_QUICK_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float x = rbf(v[e]); v[e] = x * rbf(fast_sigmoid(rbf(1.702f * x))); }
+        } else if (act == GVL_ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(rbf(v[e]));
+        }
+        if (has_gamma) {
+          const f32x4_t gv = gv4[b];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) * gv[e];
+        }
+        if (silu) {
+          float o2[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) { const float g = rbf(v[2 * e]), u = rbf(v[2 * e + 1]); o2[e] = u * rbf(g * fast_sigmoid(g)); }
+          *(unsigned*)(wrow + (nl >> 1) * 2) = pack2bf(o2[0], o2[1]);
+        } else if (out_f32) {
+          if (has_resid && a.round_pre_resid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+          }
+          const f32x4_t o = {v[0], v[1], v[2], v[3]};
+          *(f32x4_t*)(wrow + nl * 4) = o;
+        } else {
+          const u32x2_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(u32x2_t*)(wrow + ((nl * 2) ^ wx)) = o;
+        }
+      }
+      if constexpr (has_bias || has_gamma) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // read-back in two passes: hipcc must use vmcnt(0) whenever loads AND stores are pending (they retire out of order
+    // with respect to each other), so a store issued between two residual uses would serialise a full round trip per piece
+    u32x4_t ov[KI];
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int row = k * RPI + rrow_l;
+      u32x4_t sv = *(const u32x4_t*)(stg + row * ROWB + ((chunk ^ (SWZ ? (row & 15) : 0)) << 4));
+      if (has_resid) {
+        const u32x4_t r4 = rv[k];
+        if (out_f32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sv[e] = __float_as_uint(__uint_as_float(r4[e]) + __uint_as_float(sv[e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sv[e] = pack2bf(lo_bf(r4[e]) + lo_bf(sv[e]), hi_bf(r4[e]) + hi_bf(sv[e]));
+        }
+      }
+      ov[k] = sv;
+    }
+    if constexpr (has_resid) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 1 < MB) stg_request_resid<MB, NB, EPI>(a, mw, nw, lane, j + 1, rv);   // ahead of this block's stores and the next block's math
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      __builtin_amdgcn_raw_buffer_store_b128(ov[k], crs, (int)(coff + (unsigned)((j * 32 + k * RPI) * ldcb)), 0, 0);
     }
   }
 }
@@ -252,7 +443,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
     constexpr int STG_BYTES = 32 * ((EPI & 4) ? TN * 4 + 16 : TN * 2 + 16);
     static_assert(NWAVES * STG_BYTES <= 2 * STAGE_BYTES, "staging does not fit the ring");
     __syncthreads();                               // the other waves may still be reading the last k-tile
-    gemm_epilogue_staged<MB, NB, EPI>(a, acc, smem + wave * STG_BYTES, m0 + wm * TM, n0 + wn * TN, lane);
+    constexpr int BG_OFF = 2 * STAGE_BYTES - NWAVES * TN * 8;   // bias/gamma scratch: TN floats each per wave, top of the ring
+    static_assert(NWAVES * STG_BYTES <= BG_OFF, "staging overlaps the bias scratch");
+    u32x4_t rv[StgGeom<NB, EPI>::KI];
+    gemm_epilogue_staged<MB, NB, EPI>(a, acc, smem + wave * STG_BYTES, smem + BG_OFF + wave * TN * 8, m0 + wm * TM, n0 + wn * TN, lane, rv);
   } else {
     gemm_epilogue<TM, TN, MB, NB, EPI>(a, acc, m0, n0, wm, wn, l31, h);
   }
@@ -269,137 +463,74 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
 // barrier 8t+7 for BOTH groups; the first read of tile t+1 (group 0, step 0) comes after that barrier.  The DMA for
 // tile t+1 overwrites the slot of tile t-1, last read before barrier 8t-1; it is issued after that barrier.
 // =====================================================================================================
-// Staged epilogue (ping-pong kernel): the natural MFMA store is one 8-byte piece per lane at a ROW stride -- a wave
-// instruction touches 32 different cache lines with 16 bytes each and the store tail is issue-bound (MI355X guide, T21).
-// Here every wave transposes its 32 x TN sub-tile through its private slice of the (now idle) LDS ring and writes whole
-// rows: 16-byte pieces, 4 (bf16) / 2 (f32) full rows per wave instruction; the residual is read the same way.
-// Requires 16-byte aligned rows (checked by the launcher); arithmetic and rounding points are those of gemm_epilogue.
-template <int MB, int NB, int EPI>
-__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x16_t (&acc)[NB][MB], char* stg, int mw, int nw, int lane) {
-  static_assert(EPI >= 0, "staged epilogue is compile-time specialised");
-  constexpr int act = EPI & 3;
-  constexpr bool out_f32 = (EPI >> 2) & 1, has_resid = (EPI >> 3) & 1, has_gamma = (EPI >> 4) & 1, has_bias = (EPI >> 5) & 1;
-  constexpr bool silu = act == GVL_ACT_SILU_MUL;
-  constexpr int TN = NB * 32, OUTC = silu ? TN / 2 : TN, ES = out_f32 ? 4 : 2;
-  constexpr int ROWB = OUTC * ES + 16;             // +16: the column-of-rows writes spread over the banks
-  constexpr int LPR = OUTC * ES / 16, RPI = 64 / LPR;
-  const int l31 = lane & 31, h = lane >> 5;
-  const int n_out0 = silu ? (nw >> 1) : nw, n_out_end = silu ? (a.N >> 1) : a.N;
-  const int rrow_l = lane / LPR, chunk = lane % LPR;
-#pragma unroll
-  for (int j = 0; j < MB; ++j) {
-    char* wrow = stg + l31 * ROWB;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int nl = i * 32 + 8 * b + 4 * h;
-        const int n = nw + nl;
-        float v[4] = {acc[i][j][4 * b + 0], acc[i][j][4 * b + 1], acc[i][j][4 * b + 2], acc[i][j][4 * b + 3]};
-        if (n < a.N) {
-          if (has_bias) {
-            const f32x4_t bv = *(const f32x4_t*)(a.bias + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bv[e];
-          }
-          if (act == GVL_ACT_QUICK_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float x = rbf(v[e]); v[e] = x * rbf(fast_sigmoid(rbf(1.702f * x))); }
-          } else if (act == GVL_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(rbf(v[e]));
-          }
-          if (has_gamma) {
-            const f32x4_t gv = *(const f32x4_t*)(a.gamma + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) * gv[e];
-          }
-        }
-        if (silu) {
-          float o2[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) { const float g = rbf(v[2 * e]), u = rbf(v[2 * e + 1]); o2[e] = u * rbf(g * fast_sigmoid(g)); }
-          *(unsigned*)(wrow + (nl >> 1) * 2) = pack2bf(o2[0], o2[1]);
-        } else if (out_f32) {
-          if (has_resid && a.round_pre_resid) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
-          }
-          const f32x4_t o = {v[0], v[1], v[2], v[3]};
-          *(f32x4_t*)(wrow + nl * 4) = o;
-        } else {
-          const u32x2_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          *(u32x2_t*)(wrow + nl * 2) = o;
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 32 / RPI; ++k) {
-      const int row = k * RPI + rrow_l;
-      const int m = mw + j * 32 + row;
-      const int nc = n_out0 + chunk * (16 / ES);
-      u32x4_t sv = *(const u32x4_t*)(stg + row * ROWB + chunk * 16);
-      if (m >= a.M || nc >= n_out_end) continue;
-      const size_t orow = a.grp_rows ? (size_t)(m / a.grp_rows) * a.grp_stride + (m % a.grp_rows) + a.row_off : (size_t)m + a.row_off;
-      char* cp = (char*)a.C + (orow * a.ldc + nc) * ES;
-      if (has_resid) {
-        const u32x4_t rv = *(const u32x4_t*)((const char*)a.resid + (orow * a.ldr + nc) * ES);
-        if (out_f32) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sv[e] = __float_as_uint(__uint_as_float(rv[e]) + __uint_as_float(sv[e]));
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sv[e] = pack2bf(lo_bf(rv[e]) + lo_bf(sv[e]), hi_bf(rv[e]) + hi_bf(sv[e]));
-        }
-      }
-      *(u32x4_t*)cp = sv;
-    }
-  }
-}
-
-template <int BM, int BN, int KPP, int DMODE, int EPI, int STG = 0>
+template <int BM, int BN, int EPI, int STG = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
   constexpr int WAVES_M = 4, WAVES_N = 2, NWAVES = 8, NT = 512;
   constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, MB = TM / 32, NB = TN / 32;
   constexpr int ROWS = BM + BN, NI = ROWS * 8 / NT, STAGE_BYTES = ROWS * 128;
   static_assert(NI % 2 == 0, "DMA pieces are issued in two halves");
+  // PERSISTENT: the grid is min(tiles, CUs) and every workgroup walks its XCD's share of the tile list.  With the staged
+  // bf16 epilogue (8 KiB / wave = one ring slot) the NEXT tile's first k-tile is requested into slot 0 BEFORE the epilogue,
+  // so its HBM/L2 latency is covered by the epilogue's VALU work, LDS transpose and row stores.
+  constexpr bool STAGED = STG != 0 && EPI >= 0;
+  constexpr bool F32OUT = EPI >= 0 && (EPI & 4);
+  constexpr bool SILU = EPI >= 0 && (EPI & 3) == GVL_ACT_SILU_MUL;
+  constexpr bool OVERLAP = STAGED && !F32OUT;                     // staging fits ring slot 1
+  constexpr int SWZ = (OVERLAP && !SILU) ? 1 : 0;
+  constexpr int STG_BYTES = F32OUT ? 32 * (TN * 4 + 16) : (SILU ? 32 * (TN + 16) : (SWZ ? 32 * TN * 2 : 32 * (TN * 2 + 16)));
+  static_assert(!OVERLAP || NWAVES * STG_BYTES <= STAGE_BYTES, "staging must fit one ring slot");
+  constexpr int PP_BG_OFF = (2 * STAGE_BYTES > NWAVES * STG_BYTES ? 2 * STAGE_BYTES : NWAVES * STG_BYTES);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int nwg = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
+  const int bid = blockIdx.x, G = gridDim.x;
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  constexpr int GM = 8;
-  const int band = GM * tiles_n;
-  const int g = vid / band, first_m = g * GM;
-  const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-  const int in_band = vid - g * band;
-  const int tm = first_m + in_band % gm, tn = in_band / gm;
-  const int m0 = a.m_begin + tm * BM, n0 = tn * BN;
+  const int xbase = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;   // this XCD's contiguous run of tile ids
+  const int xcnt = q + (xcd < r ? 1 : 0);
+  const int wpx = (G + 7 - xcd) >> 3;                                          // workgroups resident on this XCD
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;                       // waves w and w+4 share a SIMD
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const int l31 = lane & 31, h = lane >> 5;
+  const int swz = (l31 >> 1) & 7;
+  const int w_row_off = (wn * TN + l31) * 128;
+  const int a_row_off = BN * 128 + (wm * TM + l31) * 128;
+  const int nk = a.K / BK;
 
   const bf16_t* src[NI];
+  int m0 = 0, n0 = 0;
+  auto setup = [&](int vid, int& om0, int& on0) {
+    // grouped rasterisation inside the XCD's run: walk DOWN a band of GM tile-rows, then the next tile column
+    constexpr int GM = 8;
+    const int band = GM * tiles_n;
+    const int g = vid / band, first_m = g * GM;
+    const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_band = vid - g * band;
+    const int tm = first_m + in_band % gm, tn = in_band / gm;
+    om0 = a.m_begin + tm * BM; on0 = tn * BN;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                   // re-derive the lane terms per call: hoisted out of the tile loop they cost
+                                                   // ~16 VGPRs that spill around the epilogue (a reload = vmcnt(0) in front of the DMA)
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int c = i * NWAVES + wave;
-    const int row = c * 8 + (lane >> 3);
-    const int pc = lane & 7;
-    if (c * 8 < BN) {
-      const int lc = pc ^ ((row >> 1) & 7);
-      int gr = n0 + row; gr = gr < a.N ? gr : a.N - 1;
-      src[i] = a.W + (size_t)gr * a.K + lc * 8;
-    } else {
-      const int ra = row - BN;
-      const int lc = pc ^ ((ra >> 1) & 7);
-      int gr = m0 + ra; gr = gr < a.M ? gr : a.M - 1;
-      src[i] = a.A + (size_t)gr * a.lda + lc * 8;
+    for (int i = 0; i < NI; ++i) {
+      const int c = i * NWAVES + wave;
+      const int row = c * 8 + (ln >> 3);
+      const int pc = ln & 7;
+      if (c * 8 < BN) {
+        const int lc = pc ^ ((row >> 1) & 7);
+        int gr = on0 + row; gr = gr < a.N ? gr : a.N - 1;
+        src[i] = a.W + (size_t)gr * a.K + lc * 8;
+      } else {
+        const int ra = row - BN;
+        const int lc = pc ^ ((ra >> 1) & 7);
+        int gr = om0 + ra; gr = gr < a.M ? gr : a.M - 1;
+        src[i] = a.A + (size_t)gr * a.lda + lc * 8;
+      }
     }
-  }
-  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  };
   auto stage_half = [&](int buf, int k0, int half) {
 #pragma unroll
     for (int i = 0; i < NI / 2; ++i) {
@@ -407,91 +538,144 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
       glds16(src[ii] + k0, smem_base + buf * STAGE_BYTES + (ii * NWAVES + wave) * 1024);
     }
   };
-
-  f32x16_t acc[NB][MB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i)
-#pragma unroll
-    for (int j = 0; j < MB; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int l31 = lane & 31, h = lane >> 5;
-  const int swz = (l31 >> 1) & 7;
-  const int w_row_off = (wn * TN + l31) * 128;
-  const int a_row_off = BN * 128 + (wm * TM + l31) * 128;
-  const int nk = a.K / BK;
-
 #define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
+  int it = bid >> 3;
+  if (it >= xcnt) return;
+  setup(xbase + it, m0, n0);
   stage_half(0, 0, 0); stage_half(0, 0, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  PP_BARRIER();                                   // tile 0 is in LDS for everybody
-  if (grp == 1) PP_BARRIER();                     // half-phase offset of the second wave group
+  for (; it < xcnt; it += wpx) {
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (a.dbg) ts0 = __builtin_readcyclecounter();
+    f32x16_t acc[NB][MB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int j = 0; j < MB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // KPP k-steps (of 16) per phase: KPP = 1 -> 4 phases / tile of 8 MFMAs; KPP = 2 -> 2 phases / tile of 16 MFMAs.
-  // DMODE 0: DMA halves in the first two LOAD phases, vmcnt(0) in the last LOAD phase of the tile.
-  // (DMODE 1 = wait at the END of the last MFMA phase is a RACE: group 1 would retire its pieces after barrier 8t+8
-  //  while group 0 already reads tile t+1 after barrier 8t+7 -- measured wrong results; kept only as a warning.)
-  constexpr int NPH = 4 / KPP;
-  for (int t = 0; t < nk; ++t) {
-    const char* sb = smem + (t & 1) * STAGE_BYTES;
-    const bool more = t + 1 < nk;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();                                   // k-tile 0 is in LDS for everybody; everybody is done with the staging slot
+    if (grp == 1) PP_BARRIER();                     // half-phase offset of the second wave group
+    if (a.dbg) ts1 = __builtin_readcyclecounter();
+
+    // 4 phases per k-tile (one 16-wide k-step each): LOAD = 6 ds_read_b128 (+ a half of the next k-tile's DMA in phases
+    // 0/1, vmcnt(0) in phase 3), MFMA = 8 x 32x32x16 at raised priority.
+    // (Waiting for the DMA at the END of the last MFMA phase instead is a RACE: group 1 would retire its pieces after
+    //  barrier 8t+8 while group 0 already reads tile t+1 after barrier 8t+7 -- measured wrong results.)
+    // operands of the staged epilogue are requested INSIDE the main loop: bias/gamma with the first k-tile (parked in the wave's
+    // LDS scratch after that tile's wait), residual block 0 with the last k-tile (it stays in flight across the tail)
+    constexpr int EPI_G = STAGED ? EPI : 0;
+    using G = StgGeom<NB, EPI_G>;
+    constexpr bool PRE_RES = G::has_resid && G::KI <= 8;           // 32 VGPRs across the last k-tile; the f32 residual (64) would spill
+    constexpr int PRE = 1 | (PRE_RES ? 2 : 0);
+    u32x4_t rv[G::KI];
+    u32x2_t ebv, egv;
+    char* bgw = smem + PP_BG_OFF + wave * TN * 8;   // bias / gamma scratch of this wave (above the ring and the staging slices)
+    for (int t = 0; t < nk; ++t) {
+      const char* sb = smem + (t & 1) * STAGE_BYTES;
+      const bool more = t + 1 < nk;
 #pragma unroll
-    for (int ph = 0; ph < NPH; ++ph) {
-      // ---- LOAD phase -------------------------------------------------------------------------------
-      bf16x8_t wf[KPP][NB], af[KPP][MB];
+      for (int ph = 0; ph < 4; ++ph) {
+        if constexpr (STAGED) {
+          if (ph == 0 && t == 0 && (G::has_bias || G::has_gamma)) stg_request_bias<NB, EPI_G>(a, n0 + wn * TN, lane, ebv, egv);
+          if (ph == 0 && !more && PRE_RES) stg_request_resid<MB, NB, EPI_G>(a, m0 + wm * TM, n0 + wn * TN, lane, 0, rv);
+        }
+        bf16x8_t wf[NB], af[MB];
+        const int coff = ((ph * 2 + h) ^ swz) << 4;
 #pragma unroll
-      for (int u = 0; u < KPP; ++u) {
-        const int coff = (((ph * KPP + u) * 2 + h) ^ swz) << 4;
+        for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) wf[u][i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
-#pragma unroll
-        for (int j = 0; j < MB; ++j) af[u][j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
-      }
-      if (DMODE != 2 && ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
-      if (DMODE != 1 && ph == NPH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PP_BARRIER();
-      // ---- MFMA phase -------------------------------------------------------------------------------
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int u = 0; u < KPP; ++u)
+        for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
+        if (ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
+        if (ph == 3 && (more || !STAGED)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last k-tile: no DMA pending, residual stays in flight
+        if constexpr (STAGED) {
+          if (ph == 3 && t == 0 && (G::has_bias || G::has_gamma)) stg_store_bias<NB, EPI_G>(bgw, lane, ebv, egv);
+        }
+        PP_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
-          for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][i], af[u][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      // DMODE 2: the DMA pieces are issued BEHIND this phase's MFMAs (they execute for ~256 cycles after issue), so the LOAD
-      // phase carries only the 6 ds_reads and stays shorter than the partner wave's MFMA phase
-      if (DMODE == 2 && ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
-      if (DMODE == 1 && ph == NPH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PP_BARRIER();
+          for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BARRIER();
+      }
+    }
+    if (grp == 0) PP_BARRIER();                     // pairs with the extra barrier group 1 took at the start
+    // every LDS read of the ring is complete (both groups are past their last MFMA phase)
+    if (a.dbg) ts2 = __builtin_readcyclecounter();
+    const int em0 = m0, en0 = n0;
+    const bool has_next = it + wpx < xcnt;
+    if constexpr (OVERLAP) {
+      gemm_epilogue_staged<MB, NB, EPI, SWZ, PRE>(a, acc, smem + STAGE_BYTES + wave * STG_BYTES, bgw, em0 + wm * TM, en0 + wn * TN, lane, rv, [&]() {
+        if (has_next) { setup(xbase + it + wpx, m0, n0); stage_half(0, 0, 0); stage_half(0, 0, 1); }
+      });
+      if (has_next) {
+        // the 16 DMA source pointers are RE-derived here instead of staying live across the epilogue (they would spill)
+        int vnext = xbase + it + wpx;
+        asm volatile("" : "+s"(vnext));
+        setup(vnext, m0, n0);
+      }
+    } else {
+      if constexpr (STAGED) gemm_epilogue_staged<MB, NB, EPI, 0, PRE>(a, acc, smem + wave * STG_BYTES, bgw, em0 + wm * TM, en0 + wn * TN, lane, rv);
+      else gemm_epilogue<TM, TN, MB, NB, EPI>(a, acc, em0, en0, wm, wn, l31, h);
+      if (has_next) {
+        if constexpr (STAGED) __syncthreads();      // staging slices overlap ring slot 0
+        setup(xbase + it + wpx, m0, n0); stage_half(0, 0, 0); stage_half(0, 0, 1);
+      }
+    }
+    if (a.dbg && lane == 0) {
+      unsigned long long* d = a.dbg + ((size_t)bid * 8 + wave) * 4;
+      d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter();
     }
   }
-  if (grp == 0) PP_BARRIER();                     // pairs with the extra barrier group 1 took at the start
 #undef PP_BARRIER
-  if constexpr (STG != 0 && EPI >= 0) {
-    // every LDS read of the ring is complete (both groups are past their last MFMA phase): reuse it as staging space
-    constexpr int STG_BYTES = 32 * ((EPI & 4) ? TN * 4 + 16 : TN * 2 + 16);
-    gemm_epilogue_staged<MB, NB, EPI>(a, acc, smem + wave * STG_BYTES, m0 + wm * TM, n0 + wn * TN, lane);
-  } else {
-    gemm_epilogue<TM, TN, MB, NB, EPI>(a, acc, m0, n0, wm, wn, l31, h);
-  }
 }
 
-template <int KPP, int DMODE, int EPI, int STG = 0>
+template <int EPI, int STG = 0>
 static int launch_pp(const GemmArgs& a, hipStream_t st) {
   constexpr int BM = 256, BN = 256, RING = 2 * (BM + BN) * 128;
-  constexpr int STGB = (STG && EPI >= 0) ? 8 * 32 * ((EPI & 4) ? 128 * 4 + 16 : 128 * 2 + 16) : 0;
-  constexpr int LDS = RING > STGB ? RING : STGB;
+  constexpr int STGB = (STG && EPI >= 0 && (EPI & 4)) ? 8 * 32 * (128 * 4 + 16) : 0;    // f32 staging: 132 KiB
+  constexpr int LDS = (RING > STGB ? RING : STGB) + (STG ? 8 * 128 * 8 : 0);           // + bias/gamma scratch
   static bool attr_set = false;
-  auto kern = gemm_pp_kernel<BM, BN, KPP, DMODE, EPI, STG>;
+  static int n_cu = 256;
+  auto kern = gemm_pp_kernel<BM, BN, EPI, STG>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+    hipDeviceProp_t p; int d = 0;
+    if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n_cu = p.multiProcessorCount & ~7;
     attr_set = true;
   }
   const int tiles_m = (a.M - a.m_begin + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), LDS, st, a, tiles_m, tiles_n);
+  const int tiles = tiles_m * tiles_n;
+  static const bool no_persist = getenv("GVL_GEMM_NO_PERSIST") != nullptr;                // A/B only
+  const int grid = (tiles <= n_cu || no_persist) ? tiles : n_cu;
+  static const bool timing = getenv("GVL_GEMM_TIMING") != nullptr;                        // anatomy probe (tools/gemm_one.py)
+  if (timing) {
+    GemmArgs b = a;
+    const size_t n = (size_t)grid * 8 * 4;
+    if (hipMalloc((void**)&b.dbg, n * 8) != hipSuccess) return -3;
+    hipMemsetAsync(b.dbg, 0, n * 8, st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, b, tiles_m, tiles_n);
+    std::vector<unsigned long long> hbuf(n);
+    hipStreamSynchronize(st);
+    hipMemcpy(hbuf.data(), b.dbg, n * 8, hipMemcpyDeviceToHost);
+    hipFree(b.dbg);
+    double s[3] = {0, 0, 0}; unsigned long long tmin = ~0ull, tmax = 0;
+    for (int g = 0; g < grid; ++g) for (int w = 0; w < 8; ++w) {
+      const unsigned long long* d = &hbuf[((size_t)g * 8 + w) * 4];
+      for (int k = 0; k < 3; ++k) s[k] += (double)(d[k + 1] - d[k]);
+      if (d[0] < tmin) tmin = d[0];
+      if (d[3] > tmax) tmax = d[3];
+    }
+    const double nw = (double)grid * 8;
+    fprintf(stderr, "[gemm timing] EPI %d M %d N %d K %d grid %d tiles %d: last tile per wave (cycles of s_memtime): prologue %.0f mainloop %.0f epilogue %.0f ; span of last tiles %llu\n",
+            EPI, a.M - a.m_begin, a.N, a.K, grid, tiles, s[0] / nw, s[1] / nw, s[2] / nw, tmax - tmin);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, a, tiles_m, tiles_n);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -557,7 +741,7 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
     }
   }
   const int es = a.out_f32 ? 4 : 2;
-  const bool stg_ok = a.N % 16 == 0 && ((size_t)a.ldc * es) % 16 == 0 && ((uintptr_t)a.C & 15) == 0 &&
+  const bool stg_ok = a.N % 16 == 0 && a.grp_rows == 0 && ((size_t)a.ldc * es) % 16 == 0 && ((uintptr_t)a.C & 15) == 0 &&
                       (!a.resid || (((size_t)a.ldr * es) % 16 == 0 && ((uintptr_t)a.resid & 15) == 0));
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 0, 0, 0>(a, st);
@@ -576,15 +760,14 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
     }
     case 82: {
       if (stg_ok) switch (epi) {
-#define PP_CASE(E) case E: return launch_pp<1, 0, E, 1>(a, st);
+#define PP_CASE(E) case E: return launch_pp<E, 1>(a, st);
         PP_CASE(0) PP_CASE(32) PP_CASE(33) PP_CASE(34) PP_CASE(3) PP_CASE(44) PP_CASE(56) PP_CASE(8) PP_CASE(4) PP_CASE(36)
 #undef PP_CASE
         default: break;
       }
-      return launch_pp<1, 0, -1>(a, st);
+      return launch_pp<-1>(a, st);
     }
-    case 85: return launch_pp<1, 0, -1>(a, st);                   // ping-pong with the per-lane epilogue (A/B only)
-    case 83: return launch_pp<2, 0, -1>(a, st);
+    case 85: return launch_pp<-1>(a, st);                   // ping-pong with the per-lane epilogue (A/B only)
     case 72: return launch_cfg<256, 256, 4, 2, 0, 3, 2>(a, st);   // cfg 52 with the un-counted (asm) DMA
     case 73: return launch_cfg<256, 128, 4, 2, 0, 3, 3>(a, st);   // 3-deep ring, 144 KB
     case 74: return launch_cfg<128, 256, 2, 4, 0, 3, 3>(a, st);

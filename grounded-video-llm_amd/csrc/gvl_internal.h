@@ -84,6 +84,7 @@ struct GemmArgs {
   int grp_rows, grp_stride, row_off;
   int tile_cfg;                  // 0 auto; see gvl_launch_gemm
   int m_begin;                   // launch covers rows [m_begin, M) -- set internally by the wave-quantisation split
+  unsigned long long* dbg;       // null, or [grid][8 waves][4] s_memtime stamps of the LAST tile (GVL_GEMM_TIMING=1, ping-pong kernel)
 };
 int gvl_launch_gemm(const GemmArgs& a, hipStream_t st);
 double gvl_gemm_flops(const GemmArgs& a);

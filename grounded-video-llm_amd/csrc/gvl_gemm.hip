@@ -18,6 +18,8 @@
 //     A row-panel of a tile row stays in that XCD's private L2.
 #include "gvl_internal.h"
 #include <vector>
+#include <cmath>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 
@@ -108,6 +110,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16_t (&acc)
 // residual pieces are requested up front into registers, so a tile pays one memory round trip instead of one per piece
 // (hipcc serialises `load; s_waitcnt; use` chains inside the unrolled loops: measured 20-39 k cycles per tile before).
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// ---- erf-GELU by table (ping-pong kernel) -------------------------------------------------------------------------------
+// The GELU input is ALREADY rounded to bf16 (reference: nn.GELU on a bf16 tensor), so gelu(x) = x * Phi(x) needs Phi only at
+// bf16 points.  Phi(x) in f32 is tabulated for 2^-12 <= |x| <= 5.5 (1841 bf16 values per sign, 2 x 8 KiB, built on the host
+// in double precision); below 2^-12 Phi is 0.5 to 2e-4 relative, above 5.5 it is 1 (resp. < 2e-8) in f32 -- both ends clamp.
+// 7 full-rate VALU + one ds_read_b32 per element instead of ~16 issue slots with v_rcp + v_exp: the epilogue of
+// InternVideo2's fc1 tile drops from ~16 k to ~7 k cycles (tools/gemm_one.py, GVL_GEMM_TIMING=1).
+constexpr int GELU_LO = 0x3980, GELU_HI = 0x40B0, GELU_NE = GELU_HI - GELU_LO + 1;
+constexpr int GELU_NEG_OFF = 0x2000;               // byte offset of the negative half = sign << 13: no select needed
+constexpr int GELU_TAB_BYTES = 2 * GELU_NEG_OFF;
+static_assert(GELU_NE * 4 <= GELU_NEG_OFF, "positive half overlaps the negative half");
+// HI = 0: bf16 pattern in bits 0..15 of p; HI = 1: in bits 16..31.  Returns the LDS byte address of Phi(x); tab_adj is the
+// table's LDS address minus GELU_LO * 4 (uniform).  Five VALU ops, spelled out because hipcc's own selection needs seven.
+template <int HI>
+__device__ __forceinline__ unsigned gelu_tab_addr(unsigned p, unsigned tab_adj, unsigned lo, unsigned hi) {
+  unsigned key, sg, off;
+  if (HI) asm("v_bfe_u32 %0, %1, 16, 15" : "=v"(key) : "v"(p)); else asm("v_and_b32 %0, 0x7fff, %1" : "=v"(key) : "v"(p));
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(key) : "v"(key), "s"(lo), "v"(hi));   // one SGPR per VOP3 on gfx9
+  asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(key), "s"(tab_adj));
+  if (HI) asm("v_lshrrev_b32 %0, 31, %1" : "=v"(sg) : "v"(p)); else asm("v_bfe_u32 %0, %1, 15, 1" : "=v"(sg) : "v"(p));
+  asm("v_lshl_add_u32 %0, %1, 13, %2" : "=v"(off) : "v"(sg), "v"(off));
+  return off;
+}
 template <int NB, int EPI>
 struct StgGeom {                                   // compile-time geometry of one wave's staged read-back
   static constexpr int act = EPI & 3;
@@ -167,9 +191,9 @@ __device__ __forceinline__ void stg_store_bias(char* bg, int lane, const u32x2_t
 
 // PRE bit 0: the caller has already put bias/gamma into `bg`; bit 1: it has requested residual block 0 into rv (ping-pong
 // kernel: both are issued inside the main loop, so the epilogue starts with its operands on chip).
-template <int MB, int NB, int EPI, int SWZ = 0, int PRE = 0, typename Hook = NoHook>
+template <int MB, int NB, int EPI, int SWZ = 0, int PRE = 0, int TABLE = 0, typename Hook = NoHook>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x16_t (&acc)[NB][MB], char* stg, char* bg, int mw, int nw, int lane,
-                                                     u32x4_t (&rv)[StgGeom<NB, EPI>::KI], Hook&& after_requests = NoHook()) {
+                                                     u32x4_t (&rv)[StgGeom<NB, EPI>::KI], Hook&& after_requests = NoHook(), const char* tab = nullptr) {
   static_assert(EPI >= 0, "staged epilogue is compile-time specialised");
   using G = StgGeom<NB, EPI>;
   constexpr int act = G::act;
@@ -214,19 +238,39 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x16_t
         if (has_bias) bv4[b] = *(const f32x4_t*)(bg + (i * 32 + 8 * b + 4 * h) * 4);
         if (has_gamma) gv4[b] = *(const f32x4_t*)(bg + TN * 4 + (i * 32 + 8 * b + 4 * h) * 4);
       }
+      float vv[2][4];
 #pragma unroll
-      for (int b = 2 * hb; b < 2 * hb + 2; ++b) {
-        const int nl = i * 32 + 8 * b + 4 * h;
-        float v[4] = {acc[i][j][4 * b + 0], acc[i][j][4 * b + 1], acc[i][j][4 * b + 2], acc[i][j][4 * b + 3]};
-        if (has_bias) {
-          const f32x4_t bv = bv4[b];
+      for (int q = 0; q < 2; ++q) {
+        const int b = 2 * hb + q;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        for (int e = 0; e < 4; ++e) vv[q][e] = acc[i][j][4 * b + e] + (has_bias ? bv4[b][e] : 0.f);
+      }
+      if constexpr (act == GVL_ACT_GELU && TABLE != 0) {
+        // Phi table resident in LDS: 8 offsets, 8 reads in flight, 8 products -- one LDS latency per 8 elements
+        unsigned pk[4]; float phi[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { pk[2 * q] = pack2bf(vv[q][0], vv[q][1]); pk[2 * q + 1] = pack2bf(vv[q][2], vv[q][3]); }
+        const unsigned tab_adj = __builtin_amdgcn_readfirstlane(lds_addr(tab)) - GELU_LO * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          phi[2 * e] = *(const __attribute__((address_space(3))) float*)(size_t)gelu_tab_addr<0>(pk[e], tab_adj, GELU_LO, GELU_HI);
+          phi[2 * e + 1] = *(const __attribute__((address_space(3))) float*)(size_t)gelu_tab_addr<1>(pk[e], tab_adj, GELU_LO, GELU_HI);
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vv[e >> 1][2 * (e & 1)] = lo_bf(pk[e]) * phi[2 * e];
+          vv[e >> 1][2 * (e & 1) + 1] = hi_bf(pk[e]) * phi[2 * e + 1];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int b = 2 * hb + q;
+        const int nl = i * 32 + 8 * b + 4 * h;
+        float (&v)[4] = vv[q];
         if (act == GVL_ACT_QUICK_GELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) { const float x = rbf(v[e]); v[e] = x * rbf(fast_sigmoid(rbf(1.702f * x))); }
-        } else if (act == GVL_ACT_GELU) {
+        } else if (act == GVL_ACT_GELU && TABLE == 0) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(rbf(v[e]));
         }
@@ -480,6 +524,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
   constexpr int STG_BYTES = F32OUT ? 32 * (TN * 4 + 16) : (SILU ? 32 * (TN + 16) : (SWZ ? 32 * TN * 2 : 32 * (TN * 2 + 16)));
   static_assert(!OVERLAP || NWAVES * STG_BYTES <= STAGE_BYTES, "staging must fit one ring slot");
   constexpr int PP_BG_OFF = (2 * STAGE_BYTES > NWAVES * STG_BYTES ? 2 * STAGE_BYTES : NWAVES * STG_BYTES);
+  constexpr bool GELU_TAB = STAGED && (EPI & 3) == GVL_ACT_GELU;       // Phi table behind the bias scratch
+  constexpr int PP_TAB_OFF = PP_BG_OFF + NWAVES * TN * 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int nwg = tiles_m * tiles_n;
@@ -500,7 +546,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
   const int a_row_off = BN * 128 + (wm * TM + l31) * 128;
   const int nk = a.K / BK;
 
-  const bf16_t* src[NI];
+  // DMA sources: wave-uniform bases (a.W / a.A advanced by k0, in SGPRs) + per-lane 32-bit byte offsets (row, swizzled chunk);
+  // pieces 0..NI/2-1 are W rows, the rest A rows.  (The launcher routes operands >= 4 GiB to the lock-step kernel.)
+  static_assert(NI / 2 == 4 && BN * 8 == (NI / 2) * NWAVES * 64, "piece halves = operand halves");
+  unsigned voff[NI];
   int m0 = 0, n0 = 0;
   auto setup = [&](int vid, int& om0, int& on0) {
     // grouped rasterisation inside the XCD's run: walk DOWN a band of GM tile-rows, then the next tile column
@@ -513,35 +562,38 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
     om0 = a.m_begin + tm * BM; on0 = tn * BN;
     int ln = lane;
     asm volatile("" : "+v"(ln));                   // re-derive the lane terms per call: hoisted out of the tile loop they cost
-                                                   // ~16 VGPRs that spill around the epilogue (a reload = vmcnt(0) in front of the DMA)
+                                                   // VGPRs that spill around the epilogue (a reload = vmcnt(0) in front of the DMA)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int c = i * NWAVES + wave;
       const int row = c * 8 + (ln >> 3);
       const int pc = ln & 7;
-      if (c * 8 < BN) {
+      if (i < NI / 2) {
         const int lc = pc ^ ((row >> 1) & 7);
         int gr = on0 + row; gr = gr < a.N ? gr : a.N - 1;
-        src[i] = a.W + (size_t)gr * a.K + lc * 8;
+        voff[i] = ((unsigned)gr * (unsigned)a.K + lc * 8) * 2;
       } else {
         const int ra = row - BN;
         const int lc = pc ^ ((ra >> 1) & 7);
         int gr = om0 + ra; gr = gr < a.M ? gr : a.M - 1;
-        src[i] = a.A + (size_t)gr * a.lda + lc * 8;
+        voff[i] = ((unsigned)gr * (unsigned)a.lda + lc * 8) * 2;
       }
     }
   };
   auto stage_half = [&](int buf, int k0, int half) {
-#pragma unroll
-    for (int i = 0; i < NI / 2; ++i) {
-      const int ii = half * (NI / 2) + i;
-      glds16(src[ii] + k0, smem_base + buf * STAGE_BYTES + (ii * NWAVES + wave) * 1024);
-    }
+    const bf16_t* sb = (half == 0 ? a.W : a.A) + k0;
+    const unsigned d0 = smem_base + buf * STAGE_BYTES + (half * (NI / 2) * NWAVES + wave) * 1024;
+    if (half == 0) glds16x4(sb, voff[0], voff[1], voff[2], voff[3], d0, NWAVES * 1024);
+    else glds16x4(sb, voff[4], voff[5], voff[6], voff[7], d0, NWAVES * 1024);
   };
 #define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
   int it = bid >> 3;
   if (it >= xcnt) return;
+  if constexpr (GELU_TAB) {                          // once per (persistent) workgroup; first read is many barriers away
+    for (int o = tid * 16; o < GELU_TAB_BYTES; o += NT * 16) *(u32x4_t*)(smem + PP_TAB_OFF + o) = *(const u32x4_t*)((const char*)a.act_table + o);
+  }
+  const char* tabp = GELU_TAB ? smem + PP_TAB_OFF : nullptr;
   setup(xbase + it, m0, n0);
   stage_half(0, 0, 0); stage_half(0, 0, 1);
   for (; it < xcnt; it += wpx) {
@@ -609,9 +661,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
     const int em0 = m0, en0 = n0;
     const bool has_next = it + wpx < xcnt;
     if constexpr (OVERLAP) {
-      gemm_epilogue_staged<MB, NB, EPI, SWZ, PRE>(a, acc, smem + STAGE_BYTES + wave * STG_BYTES, bgw, em0 + wm * TM, en0 + wn * TN, lane, rv, [&]() {
+      gemm_epilogue_staged<MB, NB, EPI, SWZ, PRE, GELU_TAB ? 1 : 0>(a, acc, smem + STAGE_BYTES + wave * STG_BYTES, bgw, em0 + wm * TM, en0 + wn * TN, lane, rv, [&]() {
         if (has_next) { setup(xbase + it + wpx, m0, n0); stage_half(0, 0, 0); stage_half(0, 0, 1); }
-      });
+      }, tabp);
       if (has_next) {
         // the 16 DMA source pointers are RE-derived here instead of staying live across the epilogue (they would spill)
         int vnext = xbase + it + wpx;
@@ -634,11 +686,33 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
 #undef PP_BARRIER
 }
 
+// Phi(x) table of the current device (built once per device; blocking upload on first use, outside any timed region after warmup)
+static const float* gelu_table_device() {
+  static const float* tabs[64] = {nullptr};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+  if (!tabs[d]) {
+    std::vector<float> h(GELU_TAB_BYTES / 4, 0.f);
+    for (int sgn = 0; sgn < 2; ++sgn)
+      for (int k = 0; k < GELU_NE; ++k) {
+        const unsigned bits = ((unsigned)(GELU_LO + k) | (sgn ? 0x8000u : 0u)) << 16;
+        float x; memcpy(&x, &bits, 4);
+        h[sgn * (GELU_NEG_OFF / 4) + k] = (float)(0.5 * std::erfc(-(double)x * 0.70710678118654752440));
+      }
+    float* dptr = nullptr;
+    if (hipMalloc((void**)&dptr, GELU_TAB_BYTES) != hipSuccess) return nullptr;
+    if (hipMemcpy(dptr, h.data(), GELU_TAB_BYTES, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    tabs[d] = dptr;
+  }
+  return tabs[d];
+}
+
 template <int EPI, int STG = 0>
-static int launch_pp(const GemmArgs& a, hipStream_t st) {
+static int launch_pp(const GemmArgs& a_in, hipStream_t st) {
   constexpr int BM = 256, BN = 256, RING = 2 * (BM + BN) * 128;
   constexpr int STGB = (STG && EPI >= 0 && (EPI & 4)) ? 8 * 32 * (128 * 4 + 16) : 0;    // f32 staging: 132 KiB
-  constexpr int LDS = (RING > STGB ? RING : STGB) + (STG ? 8 * 128 * 8 : 0);           // + bias/gamma scratch
+  constexpr bool TAB = STG && EPI >= 0 && (EPI & 3) == GVL_ACT_GELU;
+  constexpr int LDS = (RING > STGB ? RING : STGB) + (STG ? 8 * 128 * 8 : 0) + (TAB ? GELU_TAB_BYTES : 0);   // + bias/gamma scratch + Phi table
   static bool attr_set = false;
   static int n_cu = 256;
   auto kern = gemm_pp_kernel<BM, BN, EPI, STG>;
@@ -648,6 +722,8 @@ static int launch_pp(const GemmArgs& a, hipStream_t st) {
     if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n_cu = p.multiProcessorCount & ~7;
     attr_set = true;
   }
+  GemmArgs a = a_in;
+  if constexpr (TAB) { a.act_table = gelu_table_device(); if (!a.act_table) return -3; }
   const int tiles_m = (a.M - a.m_begin + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const int tiles = tiles_m * tiles_n;
   static const bool no_persist = getenv("GVL_GEMM_NO_PERSIST") != nullptr;                // A/B only
@@ -715,6 +791,7 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     cfg = (a.K >= 1408 && t256 >= 128) ? 82 : 21;
   }
+  if ((cfg == 82 || cfg == 85) && ((size_t)a.N * a.K * 2 >= (1ull << 32) || (size_t)a.M * a.lda * 2 >= (1ull << 32))) cfg = 21;   // 32-bit DMA offsets
   const int epi = (a.act & 3) | ((a.out_f32 ? 1 : 0) << 2) | ((a.resid ? 1 : 0) << 3) | ((a.gamma ? 1 : 0) << 4) | ((a.bias ? 1 : 0) << 5);
   if (cfg == 82 && a.tile_cfg == 0 && env_cfg == 0 && a.m_begin == 0) {
     // Wave-quantisation split: the 256x256 kernel runs one block per CU, so a launch costs ceil(tiles / 256) full tile

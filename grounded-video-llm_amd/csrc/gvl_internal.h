@@ -62,6 +62,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "v"(gsrc), "s"(lds_dst)
                : "memory");
 }
+// Four DMA pieces from ONE wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offsets: no per-piece 64-bit VALU
+// address arithmetic in the issuing phase.  lds_dst0 + q*lds_step is piece q's wave-uniform LDS byte address.
+__device__ __forceinline__ void glds16x4(const void* sbase, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned lds_dst0, unsigned lds_step) {
+  unsigned keep, d;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+      "s_add_u32 %1, %7, %8\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6\n\t"
+      "s_add_u32 %1, %1, %8\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\t"
+      "s_add_u32 %1, %1, %8\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(d)
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(lds_dst0), "s"(lds_step)
+      : "memory", "scc");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {   // 32-bit LDS byte address of a __shared__ pointer
   return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;
 }
@@ -84,6 +99,7 @@ struct GemmArgs {
   int grp_rows, grp_stride, row_off;
   int tile_cfg;                  // 0 auto; see gvl_launch_gemm
   int m_begin;                   // launch covers rows [m_begin, M) -- set internally by the wave-quantisation split
+  const float* act_table;        // set by the launcher: Phi(x) table for the erf-GELU epilogue of the ping-pong kernel (see gvl_gemm.hip)
   unsigned long long* dbg;       // null, or [grid][8 waves][4] s_memtime stamps of the LAST tile (GVL_GEMM_TIMING=1, ping-pong kernel)
 };
 int gvl_launch_gemm(const GemmArgs& a, hipStream_t st);

@@ -69,14 +69,14 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   const int n_tiles = a.causal ? (last_q >> 6) + 1 : n_tiles_all;
 
   // ---- DMA source offsets inside a page (elements), loop invariant --------------------------------
-  int koff[NIK], voff[NIK];
+  unsigned koff[NIK], voff[NIK];              // BYTE offsets (32-bit): the page base stays in SGPRs, no 64-bit VALU adds per piece
 #pragma unroll
   for (int i = 0; i < NIK; ++i) {
     const int pos = i * NT + tid;
     const int kr = pos / CPR, kpc = pos - kr * CPR;
-    koff[i] = kr * D + KSwz<D>::logical(kr, kpc) * 8;
+    koff[i] = (unsigned)(kr * D + KSwz<D>::logical(kr, kpc) * 8) * 2;
     const int vr = pos >> 3, vpc = pos & 7;
-    voff[i] = vr * 64 + (vpc ^ ((vr >> 1) & 7)) * 8;
+    voff[i] = (unsigned)(vr * 64 + (vpc ^ ((vr >> 1) & 7)) * 8) * 2;
   }
   // ---- Q fragments (MFMA B operand): lane (q = qw + l31, h) holds d = kk*16 + 8h + 0..7 ----------
   bf16x8_t qf[DK];
@@ -103,10 +103,15 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     const bf16_t* kp = a.Kt + pb;
     const bf16_t* vp = a.Vt + pb;
     const unsigned base = smem_base + buf * STAGE_BYTES + wave * 1024;
+    if constexpr (NIK == 2 || NIK == 3) {
+      glds16xn<NIK>(kp, koff, base, NT * 16);
+      glds16xn<NIK>(vp, voff, base + TILE_BYTES, NT * 16);
+    } else {
 #pragma unroll
-    for (int i = 0; i < NIK; ++i) glds16(kp + koff[i], base + i * NT * 16);
+      for (int i = 0; i < NIK; ++i) glds16((const char*)kp + koff[i], base + i * NT * 16);
 #pragma unroll
-    for (int i = 0; i < NIK; ++i) glds16(vp + voff[i], base + TILE_BYTES + i * NT * 16);
+      for (int i = 0; i < NIK; ++i) glds16((const char*)vp + voff[i], base + TILE_BYTES + i * NT * 16);
+    }
   };
 
   f32x16_t o[DB];
@@ -213,21 +218,29 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   // ---- epilogue -------------------------------------------------------------------------------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
-  if (my_q < a.S) {
-    bf16_t* op = a.O + ((size_t)b * a.S + my_q) * (size_t)(a.H * a.Dout) + head * a.Dout;
+  // Row-per-lane store, widened (MI355X guide T21): lanes l and l+32 hold columns 8g..8g+3 / 8g+4..8g+7 of the SAME row, so
+  // one v_permlane32_swap per dword pairs the column groups (g, g+1): afterwards the lower half-wave owns all 8 columns of
+  // group g and the upper half-wave those of group g+1 -> one 16-byte store per lane per pair instead of two 8-byte ones.
+  {
+    const int qs = my_q < a.S ? my_q : a.S - 1;
+    char* op = (char*)(a.O + ((size_t)b * a.S + qs) * (size_t)(a.H * a.Dout) + head * a.Dout);
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = db * 32 + 8 * g + 4 * h;
-        if (d < a.Dout) {
-          u32x2_t w = {pack2bf(o[db][4 * g] * inv, o[db][4 * g + 1] * inv), pack2bf(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv)};
-          *(u32x2_t*)(op + d) = w;
+      for (int gp = 0; gp < 2; ++gp) {
+        const int g0 = 2 * gp;
+        unsigned ax = pack2bf(o[db][4 * g0] * inv, o[db][4 * g0 + 1] * inv), ay = pack2bf(o[db][4 * g0 + 2] * inv, o[db][4 * g0 + 3] * inv);
+        unsigned bx = pack2bf(o[db][4 * g0 + 4] * inv, o[db][4 * g0 + 5] * inv), by = pack2bf(o[db][4 * g0 + 6] * inv, o[db][4 * g0 + 7] * inv);
+        const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false); ax = rx[0]; bx = rx[1];
+        const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false); ay = ry[0]; by = ry[1];
+        const int grp = db * 4 + g0 + h;           // column group this lane now owns entirely
+        if (my_q < a.S && grp * 8 < a.Dout) {
+          const u32x4_t w = {ax, ay, bx, by};
+          *(u32x4_t*)(op + grp * 16) = w;
         }
       }
   }
 }
-
 template <int D, int NWAVES, int NS>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
   constexpr int LDS = NS * 2 * 64 * D * 2 + 1024;   // ring + page-id table (256 pages)
@@ -249,7 +262,7 @@ double gvl_attn_flops(const AttnArgs& a) {
 }
 
 int gvl_launch_attention(const AttnArgs& a, hipStream_t st) {
-  if (a.B <= 0 || a.S <= 0 || a.S > 256 * 64 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 3)) return -1;
+  if (a.B <= 0 || a.S <= 0 || a.S > 256 * 64 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 7) || ((uintptr_t)a.O & 15)) return -1;   // 16-byte O stores
   switch (a.D) {
     // ring depth 2: 48 KB (D=96) -> 3 blocks / CU at 151 VGPRs (measured 427 us vs 461 us for the 73 KB depth-3 ring, which
     // caps residency at 2 blocks / CU; DMA latency is not the limiter -- PMC shows the kernel is VALU-issue-bound)

@@ -77,6 +77,32 @@ __device__ __forceinline__ void glds16x4(const void* sbase, unsigned v0, unsigne
       : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(lds_dst0), "s"(lds_step)
       : "memory", "scc");
 }
+// N pieces (N = 2 or 3) from one SGPR base, LDS destinations lds_dst0 + q*lds_step  (attention K / V^T tiles)
+template <int N>
+__device__ __forceinline__ void glds16xn(const void* sbase, const unsigned (&v)[N], unsigned lds_dst0, unsigned lds_step) {
+  static_assert(N == 2 || N == 3, "2 or 3 pieces");
+  unsigned keep, d;
+  if constexpr (N == 3) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+        "s_add_u32 %1, %6, %7\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+        "s_add_u32 %1, %1, %7\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(d)
+        : "v"(v[0]), "v"(v[1]), "v"(v[N - 1]), "s"(sbase), "s"(lds_dst0), "s"(lds_step)
+        : "memory", "scc");
+  } else {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+        "s_add_u32 %1, %5, %6\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(d)
+        : "v"(v[0]), "v"(v[1]), "s"(sbase), "s"(lds_dst0), "s"(lds_step)
+        : "memory", "scc");
+  }
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {   // 32-bit LDS byte address of a __shared__ pointer
   return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;
 }

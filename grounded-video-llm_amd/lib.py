@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgvl.so")
+LIB_PATH = os.environ.get("GVL_LIB_PATH") or os.path.join(_HERE, "libgvl.so")   # override: A/B of two builds on one GPU box (tools/)
 
 F32, BF16, I32, I64 = 0, 1, 2, 3
 LLM_PHI3, LLM_LLAMA = 0, 1

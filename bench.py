@@ -268,7 +268,8 @@ def main():
     traffic = None   # HBM-side bytes per GEMM launch from the PMC passes of the same command (profiles/r01_pmc_traffic.json)
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fpm:
-            traffic = json.load(fpm)["families"]["gemm"]["traffic_bytes_per_launch"]
+            pm = json.load(fpm)
+            traffic = int(pm["families"]["gemm"]["total_traffic_bytes"] / (pm["clips_in_trace"] * max(1, g["launches"])))   # per LOGICAL GEMM launch
     except Exception:
         pass
     roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)", "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS,

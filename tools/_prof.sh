@@ -1,7 +1,7 @@
 R=$GRAFT_REPO_ROOT
 [ -z "$R" ] && R=/root/repo
 cd /tmp; export TMPDIR=/tmp
-O=$R/gpurun_out/prof6
+O=$R/gpurun_out/prof7
 mkdir -p $O
 rocprofv3 --kernel-trace --stats -d $O/trace -o run -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/trace.log 2>&1
 rocprofv3 --kernel-trace -d $O/serial -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode serial > $O/serial.log 2>&1
@@ -14,3 +14,5 @@ python tools/rocpd_stats.py $(find $O/serial -name "*.db" | head -1) $O/kernel_s
 python tools/pmc_traffic.py $(find $O/fetch -name "*.db" | head -1) $(find $O/write -name "*.db" | head -1) $O/pmc_traffic.json > $O/pmc.log 2>&1
 find $O -name "*.db" -size +20M -delete
 find $O -name "*.db" | head > $O/kept.txt
+cd $R
+python bench.py > $O/bench_default.log 2>&1

@@ -1,6 +1,6 @@
 """HBM-side traffic per kernel family from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) -> profiles/rNN_pmc_traffic.json.
 
-usage: python tools/pmc_traffic.py <fetch.db> <write.db> <out.json>
+usage: python tools/pmc_traffic.py <fetch.db> <write.db> <out.json> [clips_in_trace]
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 64 B per 128-B request for wide coalesced reads, so
 read bytes = 2 x FETCH_SIZE; both counters are in KiB-like units of 1 KB?  -- rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB."""
 import json
@@ -22,7 +22,7 @@ def per_family(path, counter):
     return out
 
 
-def main(fetch_db, write_db, out):
+def main(fetch_db, write_db, out, clips=7):
     f = per_family(fetch_db, "FETCH_SIZE")
     w = per_family(write_db, "WRITE_SIZE")
     fams = {}
@@ -32,13 +32,16 @@ def main(fetch_db, write_db, out):
             continue
         rd = 2.0 * f[fam][1] * 1024 / n          # KB -> bytes, x2 (gfx950 correction)
         wr = w[fam][1] * 1024 / max(1, w[fam][0])
-        fams[fam] = {"launches": n, "read_bytes_per_launch": int(rd), "write_bytes_per_launch": int(wr), "traffic_bytes_per_launch": int(rd + wr)}
+        fams[fam] = {"launches": n, "read_bytes_per_launch": int(rd), "write_bytes_per_launch": int(wr), "traffic_bytes_per_launch": int(rd + wr),
+                     "total_traffic_bytes": int((rd + wr) * n)}
     doc = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --mode serial",
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> read bytes = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM); fabric-side traffic incl. Infinity-Cache hits; counter unit KB",
+           "clips_in_trace": int(clips),   # bench.py --steps 1 --warmup 1 + 5 untimed extra clips (latency x2, decode x2, profile x1)
+           "note": "`launches` counts KERNELS (a logical GEMM may run as two kernels after the wave-quantisation split); bench.py divides total_traffic_bytes by clips x logical launches per clip",
            "families": fams}
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])

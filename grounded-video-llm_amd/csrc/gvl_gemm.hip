@@ -330,7 +330,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x16_t
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS, int EPI, int STG = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAG, int EPI, int STG = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
   constexpr int NWAVES = WAVES_M * WAVES_N;
   constexpr int NT = NWAVES * 64;
@@ -383,18 +383,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
     }
   }
 
-  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   auto stage = [&](int buf, int k0) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int c = i * NWAVES + wave;
-      if constexpr (NS == 0) {
-        char* dst = smem + buf * STAGE_BYTES + c * 1024;  // wave-uniform; the DMA adds lane*16
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      } else {
-        glds16(src[i] + k0, smem_base + buf * STAGE_BYTES + c * 1024);   // not counted by hipcc: waits are ours
-      }
+      char* dst = smem + buf * STAGE_BYTES + (i * NWAVES + wave) * 1024;  // wave-uniform; the DMA adds lane*16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   };
 
@@ -413,73 +407,30 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
   const int a_row_off = BN * 128 + (wm * TM + l31) * 128;
 
   const int nk = a.K / BK;
-  // STAG 1: waves w and w+4 (same SIMD) use different slots out of 4; STAG 2: everybody after the first k-step;
-  // STAG 3: slots {0,1} only (more flight time for the DMA)
-  const int dma_slot = STAG == 1 ? ((((wave >> 2) << 1) + (wave & 1)) & 3) : (STAG == 2 ? 1 : ((wave >> 2) & 1));
-  constexpr int RING = NS == 0 ? 2 : NS;       // LDS ring depth; tile t+RING-1 is requested while tile t is consumed
+  // 2-slot LDS ring: k-tile t+1 is requested while k-tile t is consumed.  STAG = 1: the waves request it at DIFFERENT k-steps
+  // (slot = f(wave)), so that on every SIMD some wave always has MFMAs to issue while another pays the ~8 x 60-cycle
+  // global_load_lds issue cost; STAG = 0: everybody at the top of the iteration (baseline, cfg 1).
+  const int dma_slot = (((wave >> 2) << 1) + (wave & 1)) & 3;
   stage(0, 0);
-  if (RING == 3 && nk > 1) stage(1, BK);
-  int cur = 0;
   for (int t = 0; t < nk; ++t) {
-    if constexpr (NS == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's DMA pieces of tile t have landed
-      __syncthreads();  // ... and everybody's; all waves are also done reading the slot that is refilled next
-    } else {
-      if (RING == 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");   // tile t+1 may stay in flight
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    }
-    const int tn = t + RING - 1;                // tile requested during this iteration
-    int nbuf = cur + RING - 1; if (nbuf >= RING) nbuf -= RING;
-    if constexpr (STAG == 0) { if (tn < nk) stage(nbuf, tn * BK); }
-    const int tb = cur;
-    cur = cur + 1 == RING ? 0 : cur + 1;
-    const char* sb = smem + tb * STAGE_BYTES;
-    if constexpr (PIPE == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's DMA pieces of tile t have landed
+    __syncthreads();  // ... and everybody's; all waves are also done reading the slot that is refilled next
+    const bool more = t + 1 < nk;
+    if constexpr (STAG == 0) { if (more) stage((t + 1) & 1, (t + 1) * BK); }
+    const char* sb = smem + (t & 1) * STAGE_BYTES;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        // staggered DMA issue: the two waves that share a SIMD request tile t+1 at different k-steps, so one of
-        // them always has MFMAs to issue while the other pays the ~8 x 60-cycle global_load_lds issue cost
-        if constexpr (STAG != 0) { if (kk == dma_slot && tn < nk) stage(nbuf, tn * BK); }
-        const int coff = ((kk * 2 + h) ^ swz) << 4;
-        bf16x8_t wf[NB], af[MB];
+    for (int kk = 0; kk < 4; ++kk) {
+      if constexpr (STAG != 0) { if (kk == dma_slot && more) stage((t + 1) & 1, (t + 1) * BK); }
+      const int coff = ((kk * 2 + h) ^ swz) << 4;
+      bf16x8_t wf[NB], af[MB];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
+      for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
 #pragma unroll
-        for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
+      for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+      for (int i = 0; i < NB; ++i)
 #pragma unroll
-          for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-      }
-    } else {
-      // register double buffer: the ds_reads of k-step kk+1 are in flight while the MFMAs of kk issue
-      bf16x8_t wf[2][NB], af[2][MB];
-      {
-        const int coff = ((0 * 2 + h) ^ swz) << 4;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) wf[0][i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
-#pragma unroll
-        for (int j = 0; j < MB; ++j) af[0][j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
-      }
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        if constexpr (STAG != 0) { if (kk == dma_slot && tn < nk) stage(nbuf, tn * BK); }
-        if (kk < 3) {
-          const int coff = (((kk + 1) * 2 + h) ^ swz) << 4;
-#pragma unroll
-          for (int i = 0; i < NB; ++i) wf[(kk + 1) & 1][i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
-#pragma unroll
-          for (int j = 0; j < MB; ++j) af[(kk + 1) & 1][j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
-        }
-        if constexpr (PIPE == 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-          for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][i], af[kk & 1][j], acc[i][j], 0, 0, 0);
-        if constexpr (PIPE == 1) __builtin_amdgcn_s_setprio(0);
-      }
+        for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -760,12 +711,12 @@ static int launch_pp(const GemmArgs& a_in, hipStream_t st) {
 //  vmcnt(8) -- was built and measured 10-15 % SLOWER than gemm_pp_kernel on every hot-path shape (64-byte DMA rows fetch
 //  each 128-byte line twice); it was removed.  See DESIGN.md §3.1 and profiles/r01_gemm_microbench_pp.txt.)
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE, int STAG, int NS, int EPI = -1, int STG = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAG, int EPI = -1, int STG = 0>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int LDS = (NS == 0 ? 2 : NS) * (BM + BN) * 128;
+  constexpr int LDS = 2 * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, STAG, NS, EPI, STG>;
+  auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAG, EPI, STG>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
     attr_set = true;
@@ -822,19 +773,17 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
   const bool stg_ok = a.N % 16 == 0 && a.grp_rows == 0 && ((size_t)a.ldc * es) % 16 == 0 && ((uintptr_t)a.C & 15) == 0 &&
                       (!a.resid || (((size_t)a.ldr * es) % 16 == 0 && ((uintptr_t)a.resid & 15) == 0));
   switch (cfg) {
-    case 1: return launch_cfg<128, 128, 2, 2, 0, 0, 0>(a, st);
-    case 2: return launch_cfg<256, 256, 4, 2, 0, 0, 0>(a, st);
-    case 3: return launch_cfg<256, 128, 4, 2, 0, 0, 0>(a, st);
+    case 1: return launch_cfg<128, 128, 2, 2, 0>(a, st);            // plain lock-step baseline (tests / A-B)
     // cfg 21 / 82 run the LDS-staged whole-row epilogue (compile-time specialised per fused-epilogue code) whenever the
     // output rows are 16-byte aligned; anything else takes the generic per-lane epilogue (EPI = -1).
     case 21: {
       if (stg_ok) switch (epi) {
-#define S_CASE(E) case E: return launch_cfg<128, 128, 2, 2, 0, 1, 0, E, 1>(a, st);
+#define S_CASE(E) case E: return launch_cfg<128, 128, 2, 2, 1, E, 1>(a, st);
         S_CASE(0) S_CASE(32) S_CASE(33) S_CASE(34) S_CASE(3) S_CASE(44) S_CASE(56) S_CASE(8) S_CASE(4) S_CASE(36)
 #undef S_CASE
         default: break;
       }
-      return launch_cfg<128, 128, 2, 2, 0, 1, 0, -1>(a, st);
+      return launch_cfg<128, 128, 2, 2, 1, -1>(a, st);
     }
     case 82: {
       if (stg_ok) switch (epi) {
@@ -846,10 +795,6 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
       return launch_pp<-1>(a, st);
     }
     case 85: return launch_pp<-1>(a, st);                   // ping-pong with the per-lane epilogue (A/B only)
-    case 72: return launch_cfg<256, 256, 4, 2, 0, 3, 2>(a, st);   // cfg 52 with the un-counted (asm) DMA
-    case 73: return launch_cfg<256, 128, 4, 2, 0, 3, 3>(a, st);   // 3-deep ring, 144 KB
-    case 74: return launch_cfg<128, 256, 2, 4, 0, 3, 3>(a, st);
-    case 52: return launch_cfg<256, 256, 4, 2, 0, 3, 0>(a, st);
     default: return -1;
   }
 }

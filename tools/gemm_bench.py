@@ -19,7 +19,7 @@ SHAPES = [  # (name, M, N, K)
 EPI = {"clip.qkv": "bias", "clip.out": "bias_resid32", "clip.fc1": "bias_qgelu", "clip.fc2": "bias_resid32",
        "iv2.qkv": "plain", "iv2.proj": "bias_gamma_resid", "iv2.fc1": "bias_gelu", "iv2.fc2": "bias_gamma_resid",
        "phi.qkv": "plain", "phi.o": "resid", "phi.gu": "silu", "phi.down": "resid"}
-CFGS = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,3,11,12,13,14,15".split(","))]
+CFGS = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,21,82".split(","))]
 
 
 def main():

@@ -297,9 +297,13 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
   __shared__ int last_s;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int head = blockIdx.x, split = blockIdx.y;
+  const int head = blockIdx.x, split = blockIdx.y, bz = blockIdx.z;   // bz: sequence of the decode batch
   const int hkv = head / (a.H / a.KV);
-  const int pos = *a.pos_ptr + 1;                   // tokens in the cache, new one included
+  const int* __restrict__ block_table = a.tables[bz];
+  const bf16_t* qb = a.q + (size_t)bz * a.q_stride;
+  float* part_b = a.part + (size_t)bz * a.H * a.nsplit * (D + 2);
+  int* counters_b = a.counters + bz * a.H;
+  const int pos = *a.pos_ptrs[bz] + 1;              // tokens in the cache, new one included
   const int npages = (pos + 63) >> 6;
   const int pps = (npages + a.nsplit - 1) / a.nsplit;
   const int p_begin = split * pps;
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
   // the lane's q chunks (chunk index (it*64+lane) % CPR): 16-byte L2 hits, no LDS staging / block barrier
   u32x4_t qv[QP];
 #pragma unroll
-  for (int it = 0; it < QP; ++it) qv[it] = *(const u32x4_t*)(a.q + head * D + ((it * 64 + lane) % CPR) * 8);
+  for (int it = 0; it < QP; ++it) qv[it] = *(const u32x4_t*)(qb + head * D + ((it * 64 + lane) % CPR) * 8);
 
   const float sc = a.scale * 1.4426950408889634f;
   float m_run = -1e30f, l_run = 0.f;
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
   for (int i = 0; i < NIT; ++i) oacc[i] = 0.f;
 
   for (int pg = p_begin + wave; pg < p_end; pg += 4) {
-    const size_t pb = ((size_t)a.block_table[pg] * a.KV + hkv) * (size_t)(64 * D);
+    const size_t pb = ((size_t)block_table[pg] * a.KV + hkv) * (size_t)(64 * D);
     const bf16_t* kp = a.Kt + pb;
     const bf16_t* vp = a.Vt + pb;
     // the whole page (K and V^T) is requested up front: 2*NIT fully coalesced 16-byte loads in flight per lane
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
   // ---- publish this block's partial with write-through (sc1) stores, take a ticket; the last block of the head
   //      merges the partials reading them with sc1 loads (bypass the stale L1): no release/acquire fences needed
   //      (guide G16 recipe R1; placement independent) ---------------------------------------------------------
-  float* outp = a.part + ((size_t)head * a.nsplit + split) * (D + 2);
+  float* outp = part_b + ((size_t)head * a.nsplit + split) * (D + 2);
   const float mm = fmaxf(fmaxf(red_s[0][D], red_s[1][D]), fmaxf(red_s[2][D], red_s[3][D]));
   if (tid < D) {
     float acc = 0.f;
@@ -390,14 +394,14 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores
   __syncthreads();
   if (tid == 0) {
-    const int t = __hip_atomic_fetch_add(a.counters + head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int t = __hip_atomic_fetch_add(counters_b + head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_s = (t == a.nsplit - 1);
   }
   __syncthreads();
   if (!last_s) return;
   // one round trip: every thread fetches its share of the nsplit*(D+2) partial words (sc1 loads, all independent)
   // into LDS (the score scratch is free by now), then the merge runs out of LDS
-  const float* pp = a.part + (size_t)head * a.nsplit * (D + 2);
+  const float* pp = part_b + (size_t)head * a.nsplit * (D + 2);
   float* mg = &part_s[0][0];
   const int nword = a.nsplit * (D + 2);
   for (int i = tid; i < nword; i += 256) mg[i] = __hip_atomic_load(pp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -410,17 +414,20 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
     l += mg[s2 * (D + 2) + D + 1] * w;
     if (tid < D) acc += mg[s2 * (D + 2) + tid] * w;
   }
-  if (tid < a.Dout) a.out[head * a.Dout + tid] = f2bf(acc / l);
-  if (tid == 0) __hip_atomic_store(a.counters + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+  if (tid < a.Dout) a.out[(size_t)bz * a.out_stride + head * a.Dout + tid] = f2bf(acc / l);
+  if (tid == 0) __hip_atomic_store(counters_b + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
 }
 
 template <int D>
 static int launch_decode(const DecodeAttnArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(decode_attn_kernel<D>, dim3(a.H, a.nsplit), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(decode_attn_kernel<D>, dim3(a.H, a.nsplit, a.batch), dim3(256), 0, st, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int gvl_launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st) {
+int gvl_launch_decode_attention(const DecodeAttnArgs& a_in, hipStream_t st) {
+  DecodeAttnArgs a = a_in;
+  if (a.batch <= 0) a.batch = 1;
+  if (a.batch > GVL_MAX_DECODE_BATCH) return -1;
   switch (a.D) {
     case 64: return launch_decode<64>(a, st);
     case 96: return launch_decode<96>(a, st);

@@ -509,11 +509,14 @@ int gvl_launch_strip_cls(const void* x, void* y, int n, int S, int C, int elem_b
 // Weights go straight to VGPRs with 16-byte loads (no LDS round trip: each byte is used once), R rows per
 // wave in flight; x (optionally RMS-normalised on the fly) lives in LDS as bf16.
 // =====================================================================================================
-template <int R>
+// B = sequences decoded together: every weight chunk is loaded ONCE and multiplied into B activation
+// vectors, so the per-sequence HBM cost of a decode step falls as 1/B.  Per (row, sequence) the accumulation order is the
+// one of the B = 1 kernel: a batched decode produces bit-identical logits to B separate decodes.
+template <int R, int B>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* xs = (bf16_t*)smem;
-  __shared__ float red[4];
+  bf16_t* xs = (bf16_t*)smem;                 // [B][K]
+  __shared__ float red[B][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K8 = a.K >> 3;
   const int n0 = (blockIdx.x * 4 + wave) * R;
@@ -534,91 +537,113 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   for (int r = 0; r < R; ++r) w0[r] = __builtin_nontemporal_load((const u32x4_t*)(wp[r] + (lane < K8 ? lane : 0) * 8));
 
   if (a.norm_w) {
-    float s = 0.f;
-    for (int c = tid; c < K8; c += 256) {
-      const u32x4_t v = *(const u32x4_t*)(a.x + c * 8);
+    float s[B];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float p = lo_bf(v[e]), q = hi_bf(v[e]); s += p * p + q * q; }
+    for (int b = 0; b < B; ++b) {
+      s[b] = 0.f;
+      for (int c = tid; c < K8; c += 256) {
+        const u32x4_t v = *(const u32x4_t*)(a.x + (size_t)b * a.x_stride + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float p = lo_bf(v[e]), q = hi_bf(v[e]); s[b] += p * p + q * q; }
+      }
+      s[b] = wave_sum(s[b]);
+      if (lane == 0) red[b][wave] = s[b];
     }
-    s = wave_sum(s);
-    if (lane == 0) red[wave] = s;
     __syncthreads();
-    const float rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / a.K + a.eps);
-    for (int c = tid; c < K8; c += 256) {
-      const u32x4_t v = *(const u32x4_t*)(a.x + c * 8);
-      const u32x4_t w = *(const u32x4_t*)(a.norm_w + c * 8);
-      u32x4_t o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = pack2bf(lo_bf(w[e]) * rbf(lo_bf(v[e]) * rs), hi_bf(w[e]) * rbf(hi_bf(v[e]) * rs));
-      *(u32x4_t*)(xs + c * 8) = o;
+    for (int b = 0; b < B; ++b) {
+      const float rs = rsqrtf((red[b][0] + red[b][1] + red[b][2] + red[b][3]) / a.K + a.eps);
+      for (int c = tid; c < K8; c += 256) {
+        const u32x4_t v = *(const u32x4_t*)(a.x + (size_t)b * a.x_stride + c * 8);
+        const u32x4_t w = *(const u32x4_t*)(a.norm_w + c * 8);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2bf(lo_bf(w[e]) * rbf(lo_bf(v[e]) * rs), hi_bf(w[e]) * rbf(hi_bf(v[e]) * rs));
+        *(u32x4_t*)(xs + (size_t)b * a.K + c * 8) = o;
+      }
     }
   } else {
-    for (int c = tid; c < K8; c += 256) *(u32x4_t*)(xs + c * 8) = *(const u32x4_t*)(a.x + c * 8);
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+      for (int c = tid; c < K8; c += 256) *(u32x4_t*)(xs + (size_t)b * a.K + c * 8) = *(const u32x4_t*)(a.x + (size_t)b * a.x_stride + c * 8);
   }
   __syncthreads();
   if (n0 >= a.N) return;
 
-  float acc[R];
+  float acc[R][B];
 #pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
   if (lane < K8) {
-    const u32x4_t xv = *(const u32x4_t*)(xs + lane * 8);
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+    for (int b = 0; b < B; ++b) {
+      const u32x4_t xv = *(const u32x4_t*)(xs + (size_t)b * a.K + lane * 8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[r] += lo_bf(w0[r][e]) * lo_bf(xv[e]) + hi_bf(w0[r][e]) * hi_bf(xv[e]);
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[r][b] += lo_bf(w0[r][e]) * lo_bf(xv[e]) + hi_bf(w0[r][e]) * hi_bf(xv[e]);
+    }
   }
-#pragma unroll (R >= 6 ? 2 : 4)
+#pragma unroll (R * B >= 6 ? 2 : 4)
   for (int c = lane + 64; c < K8; c += 64) {
     u32x4_t wv[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) wv[r] = __builtin_nontemporal_load((const u32x4_t*)(wp[r] + c * 8));
-    const u32x4_t xv = *(const u32x4_t*)(xs + c * 8);
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+    for (int b = 0; b < B; ++b) {
+      const u32x4_t xv = *(const u32x4_t*)(xs + (size_t)b * a.K + c * 8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[r] += lo_bf(wv[r][e]) * lo_bf(xv[e]) + hi_bf(wv[r][e]) * hi_bf(xv[e]);
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[r][b] += lo_bf(wv[r][e]) * lo_bf(xv[e]) + hi_bf(wv[r][e]) * hi_bf(xv[e]);
+    }
   }
 #pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-  if (lane == 0 && a.rope_on) {
-    if constexpr ((R & 1) == 0) {
-      const int pos = *a.pos_ptr;
-      const float* cosp = a.cos_s; const float* sinp = a.sin_s;
-      if (a.rope_switch > 0 && pos + 1 > a.rope_switch) { cosp = a.cos_l; sinp = a.sin_l; }
-      const int page = a.block_table[pos >> 6], slot = pos & 63;
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int r = 0; r < R; r += 2) {
-        const int i = n0 + r;
-        if (i + 1 < a.N) {
-          const int j = i >> 1;
-          if (j < npair_qk) {
-            const int hd = j / halfd, d = j - hd * halfd;
-            const float x1 = rbf(acc[r]), x2 = rbf(acc[r + 1]);
-            const float c = cosp[(size_t)pos * halfd + d], sn = sinp[(size_t)pos * halfd + d];
-            const bf16_t o1 = f2bf(rbf(x1 * c) + rbf(-x2 * sn)), o2 = f2bf(rbf(x2 * c) + rbf(x1 * sn));
-            bf16_t* dst = hd < a.H ? a.Q + (size_t)hd * a.D + d
-                                   : a.Kt + (((size_t)page * a.KV + (hd - a.H)) * 64 + slot) * a.D + d;
-            dst[0] = o1; dst[halfd] = o2;
-          } else {
-            const int vi = i - 2 * npair_qk, hv = vi / a.Dr, d = vi - hv * a.Dr;
-            bf16_t* dst = a.Vt + (((size_t)page * a.KV + hv) * a.D + d) * 64 + slot;
-            dst[0] = f2bf(acc[r]); dst[64] = f2bf(acc[r + 1]);
+    for (int b = 0; b < B; ++b) acc[r][b] = wave_sum(acc[r][b]);
+  if (lane != 0) return;
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    if (a.rope_on) {
+      if constexpr ((R & 1) == 0) {
+        const int pos = *a.pos_ptrs[b];
+        const float* cosp = a.cos_s; const float* sinp = a.sin_s;
+        if (a.rope_switch > 0 && pos + 1 > a.rope_switch) { cosp = a.cos_l; sinp = a.sin_l; }
+        const int page = a.tables[b][pos >> 6], slot = pos & 63;
+        bf16_t* Qb = a.Q + (size_t)b * a.q_stride;
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+          const int i = n0 + r;
+          if (i + 1 < a.N) {
+            const int j = i >> 1;
+            if (j < npair_qk) {
+              const int hd = j / halfd, d = j - hd * halfd;
+              const float x1 = rbf(acc[r][b]), x2 = rbf(acc[r + 1][b]);
+              const float c = cosp[(size_t)pos * halfd + d], sn = sinp[(size_t)pos * halfd + d];
+              const bf16_t o1 = f2bf(rbf(x1 * c) + rbf(-x2 * sn)), o2 = f2bf(rbf(x2 * c) + rbf(x1 * sn));
+              bf16_t* dst = hd < a.H ? Qb + (size_t)hd * a.D + d
+                                     : a.Kt + (((size_t)page * a.KV + (hd - a.H)) * 64 + slot) * a.D + d;
+              dst[0] = o1; dst[halfd] = o2;
+            } else {
+              const int vi = i - 2 * npair_qk, hv = vi / a.Dr, d = vi - hv * a.Dr;
+              bf16_t* dst = a.Vt + (((size_t)page * a.KV + hv) * a.D + d) * 64 + slot;
+              dst[0] = f2bf(acc[r][b]); dst[64] = f2bf(acc[r + 1][b]);
+            }
           }
         }
       }
-    }
-  } else if (lane == 0) {
-    if (a.act == GVL_ACT_SILU_MUL) {
+    } else if (a.act == GVL_ACT_SILU_MUL) {
       if constexpr ((R & 1) == 0) {
 #pragma unroll
         for (int r = 0; r < R; r += 2) {
           const int n = n0 + r;
           if (n + 1 < a.N) {
-            const float g = rbf(acc[r]), u = rbf(acc[r + 1]);
+            const float g = rbf(acc[r][b]), u = rbf(acc[r + 1][b]);
             const float o = u * rbf(g * fast_sigmoid(g));
-            if (a.out_bf16) a.out_bf16[n >> 1] = f2bf(o);
-            if (a.out_f32) a.out_f32[n >> 1] = o;
+            if (a.out_bf16) a.out_bf16[(size_t)b * a.out_stride + (n >> 1)] = f2bf(o);
+            if (a.out_f32) a.out_f32[(size_t)b * a.out_stride + (n >> 1)] = o;
           }
         }
       }
@@ -627,45 +652,63 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       for (int r = 0; r < R; ++r) {
         const int n = n0 + r;
         if (n < a.N) {
-          float v = acc[r];
+          float v = acc[r][b];
           if (a.bias) v += a.bias[n];
-          if (a.resid) v = bf2f(a.resid[n]) + rbf(v);
-          if (a.out_bf16) a.out_bf16[n] = f2bf(v);
-          if (a.out_f32) a.out_f32[n] = v;
+          if (a.resid) v = bf2f(a.resid[(size_t)b * a.out_stride + n]) + rbf(v);
+          if (a.out_bf16) a.out_bf16[(size_t)b * a.out_stride + n] = f2bf(v);
+          if (a.out_f32) a.out_f32[(size_t)b * a.out_stride + n] = v;
         }
       }
     }
   }
 }
 
-int gvl_launch_gemv(const GemvArgs& a, hipStream_t st) {
-  if (a.K % 8 || a.K > 32768) return -1;
-  const size_t lds = (size_t)a.K * 2;
+template <int B>
+static int launch_gemv_b(const GemvArgs& a, int R, int blocks, size_t lds, hipStream_t st) {
+  switch (R) {
+#define GEMV_CASE(RR) case RR: { auto k = gemv_kernel<RR, B>; \
+      if (lds > 48 * 1024) { static bool set_ = false; if (!set_) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -3; set_ = true; } } \
+      hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, a); break; }
+    GEMV_CASE(1) GEMV_CASE(2) GEMV_CASE(3) GEMV_CASE(4) GEMV_CASE(6)
+    default: { auto k = gemv_kernel<8, B>;
+      if (lds > 48 * 1024) { static bool set_ = false; if (!set_) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -3; set_ = true; } }
+      hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, a); break; }
+#undef GEMV_CASE
+  }
+  return CHECK_LAUNCH();
+}
+
+int gvl_launch_gemv(const GemvArgs& a_in, hipStream_t st) {
+  GemvArgs a = a_in;
+  if (a.batch <= 0) a.batch = 1;
+  if (a.K % 8 || a.K > 32768 || a.batch > GVL_MAX_DECODE_BATCH || a.batch == 3) return -1;
+  if (a.batch == 1) { a.x_stride = 0; a.out_stride = 0; a.q_stride = 0; }
+  const size_t lds = (size_t)a.K * 2 * a.batch;
+  if (lds > 159 * 1024) return -1;
   // rows per wave: aim at ~768-1024 blocks (3-4 per CU, all co-resident) so the weight stream has no tail
   int R = (a.N + 4 * 1024 - 1) / (4 * 1024);
   if (R < 1) R = 1;
   if (R == 5) R = 6;
   if (R == 7 || R > 8) R = 8;
+  if (a.batch > 1 && R > 4) R = 4;            // R x B accumulators and R x 4 weight registers per lane
   if (a.rope_on) { if ((a.Dr & 1) || (a.N & 1)) return -1; R = 2; }
   if (a.act == GVL_ACT_SILU_MUL && (R & 1)) R += 1;
   const int blocks = (a.N + 4 * R - 1) / (4 * R);
-  switch (R) {
-    case 1: hipLaunchKernelGGL(gemv_kernel<1>, dim3(blocks), dim3(256), lds, st, a); break;
-    case 2: hipLaunchKernelGGL(gemv_kernel<2>, dim3(blocks), dim3(256), lds, st, a); break;
-    case 3: hipLaunchKernelGGL(gemv_kernel<3>, dim3(blocks), dim3(256), lds, st, a); break;
-    case 4: hipLaunchKernelGGL(gemv_kernel<4>, dim3(blocks), dim3(256), lds, st, a); break;
-    case 6: hipLaunchKernelGGL(gemv_kernel<6>, dim3(blocks), dim3(256), lds, st, a); break;
-    default: hipLaunchKernelGGL(gemv_kernel<8>, dim3(blocks), dim3(256), lds, st, a); break;
+  switch (a.batch) {
+    case 1: return launch_gemv_b<1>(a, R, blocks, lds, st);
+    case 2: return launch_gemv_b<2>(a, R, blocks, lds, st);
+    default: return launch_gemv_b<4>(a, R, blocks, lds, st);
   }
-  return CHECK_LAUNCH();
 }
 
-// greedy sampling: first index of the maximum (torch.argmax tie rule) -> *out_tok and out_list[*step_ptr]
-__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int n, int* out_tok, int* out_list, const int* step_ptr) {
+// greedy sampling: first index of the maximum (torch.argmax tie rule); one block per logit row
+__global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a) {
   __shared__ float bv[16];
   __shared__ int bi[16];
+  const int b = blockIdx.x;
+  const float* logits = a.logits + (size_t)b * a.n;
   float best = -3.4e38f; int idx = 0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += 1024) {
+  for (int i = threadIdx.x; i < a.n; i += 1024) {
     const float v = logits[i];
     if (v > best) { best = v; idx = i; }
   }
@@ -678,12 +721,30 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-    *out_tok = idx;
-    if (out_list) out_list[step_ptr ? *step_ptr : 0] = idx;
+    *a.tok_ptrs[b] = idx;
+    if (a.out_lists[b]) a.out_lists[b][a.steps[b]] = idx;
   }
 }
-int gvl_launch_argmax(const float* logits, int n, int* out_tok, int* out_list, const int* step_ptr, hipStream_t st) {
-  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, logits, n, out_tok, out_list, step_ptr);
+int gvl_launch_argmax(const ArgmaxArgs& a, hipStream_t st) {
+  if (a.batch < 1 || a.batch > GVL_MAX_DECODE_BATCH) return -1;
+  hipLaunchKernelGGL(argmax_kernel, dim3(a.batch), dim3(1024), 0, st, a);
+  return CHECK_LAUNCH();
+}
+__global__ void gather_tok_rows_kernel(const bf16_t* __restrict__ table, const TokPtrs toks, bf16_t* __restrict__ dst, int cols) {
+  const int r = blockIdx.y;
+  const int tok = *toks.p[r];
+  for (int c = (blockIdx.x * blockDim.x + threadIdx.x) * 8; c < cols; c += gridDim.x * blockDim.x * 8)
+    *(u32x4_t*)(dst + (size_t)r * cols + c) = *(const u32x4_t*)(table + (size_t)tok * cols + c);
+}
+int gvl_launch_gather_tok_rows(const bf16_t* table, const TokPtrs& toks, bf16_t* dst, int cols, hipStream_t st) {
+  if (cols % 8 || toks.n < 1 || toks.n > GVL_MAX_DECODE_BATCH) return -1;
+  hipLaunchKernelGGL(gather_tok_rows_kernel, dim3((cols / 8 + 255) / 256, toks.n), dim3(256), 0, st, table, toks, dst, cols);
+  return CHECK_LAUNCH();
+}
+__global__ void inc_many_kernel(const IntPtrs ptrs) { if (threadIdx.x < ptrs.n) (*ptrs.p[threadIdx.x])++; }
+int gvl_launch_inc_many(const IntPtrs& ptrs, hipStream_t st) {
+  if (ptrs.n < 1 || ptrs.n > GVL_MAX_DECODE_BATCH) return -1;
+  hipLaunchKernelGGL(inc_many_kernel, dim3(1), dim3(64), 0, st, ptrs);
   return CHECK_LAUNCH();
 }
 __global__ void inc_kernel(int* p) { if (threadIdx.x == 0) (*p)++; }

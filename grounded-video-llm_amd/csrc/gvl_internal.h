@@ -148,14 +148,14 @@ double gvl_attn_flops(const AttnArgs& a);
 
 // ---- decode attention -----------------------------------------------------------------------------
 struct DecodeAttnArgs {
-  const bf16_t* q;        // [H][D]
+  const bf16_t* q;        // [batch][H][D], q_stride elements apart
   const bf16_t* Kt; const bf16_t* Vt;   // page pools (one layer)
-  const int* block_table; // [max_pages]
-  const int* pos_ptr;     // device: index of the new token (the cache holds *pos_ptr + 1 tokens, new one included)
-  float* part;            // workspace [H][nsplit][D+2]
-  int* counters;          // [H] arrival tickets, zero between launches (the merging block re-arms them)
-  bf16_t* out;            // [H*Dout]
-  int H, KV, D, Dout, nsplit;
+  const int* tables[4];   // per sequence: [max_pages]
+  const int* pos_ptrs[4]; // per sequence, device: index of the new token (the cache holds *pos + 1 tokens, new one included)
+  float* part;            // workspace [batch][H][nsplit][D+2]
+  int* counters;          // [batch][H] arrival tickets, zero between launches (the merging block re-arms them)
+  bf16_t* out;            // [batch][H*Dout], out_stride elements apart
+  int H, KV, D, Dout, nsplit, batch, q_stride, out_stride;
   float scale;
 };
 int gvl_launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st);
@@ -198,21 +198,31 @@ int gvl_launch_bcast_row(const bf16_t* row, bf16_t* dst, int n, int stride_rows,
 int gvl_launch_gather_rows(const bf16_t* table, const int* ids, bf16_t* dst, int n, int cols, hipStream_t st);
 int gvl_launch_strip_cls(const void* x, void* y, int n, int S, int C, int elem_bytes, hipStream_t st);
 // decode-side
+constexpr int GVL_MAX_DECODE_BATCH = 4;   // sequences decoded together: the weight stream is read ONCE for all of them
 struct GemvArgs {
   const bf16_t* W; int N, K;      // [N][K]
-  const bf16_t* x;                // [K] bf16
+  const bf16_t* x;                // [batch][K] bf16, rows x_stride elements apart
   const bf16_t* norm_w; float eps;  // non-null: x <- rmsnorm(x)*norm_w (bf16 roundings as the reference)
   const float* bias;              // [N] or null
-  const bf16_t* resid;            // [N'] or null: out = bf16(resid + bf16(y))
+  const bf16_t* resid;            // [batch][N'] or null: out = bf16(resid + bf16(y)); rows out_stride apart
   int act;                        // GVL_ACT_NONE or GVL_ACT_SILU_MUL (interleaved gate/up rows, N' = N/2)
-  bf16_t* out_bf16;               // [N'] or null
-  float* out_f32;                 // [N'] or null
-  // fused decode epilogue of the qkv projection (rope_on): RoPE on q/k at position *pos_ptr, q -> Q[H][D], k/v appended to
-  // the paged cache.  Rows are visited in (d, d+Dr/2) partner pairs so one lane owns both halves of a rotation.
-  int rope_on; const float *cos_s, *sin_s, *cos_l, *sin_l; int rope_switch; const int* pos_ptr; const int* block_table;
-  bf16_t *Q, *Kt, *Vt; int H, KV, Dr, D;
+  bf16_t* out_bf16;               // [batch][N'] or null, rows out_stride apart
+  float* out_f32;                 // [batch][N'] or null, rows out_stride apart
+  int batch, x_stride, out_stride;   // batch 0/1 = one vector (strides ignored)
+  // fused decode epilogue of the qkv projection (rope_on): RoPE on q/k at the sequence's position, q -> Q[b][H][D], k/v appended
+  // to that sequence's pages.  Rows are visited in (d, d+Dr/2) partner pairs so one lane owns both halves of a rotation.
+  int rope_on; const float *cos_s, *sin_s, *cos_l, *sin_l; int rope_switch;
+  const int* pos_ptrs[GVL_MAX_DECODE_BATCH]; const int* tables[GVL_MAX_DECODE_BATCH];   // per sequence of the batch
+  bf16_t *Q, *Kt, *Vt; int H, KV, Dr, D; int q_stride;
 };
 int gvl_launch_gemv(const GemvArgs& a, hipStream_t st);
-int gvl_launch_argmax(const float* logits, int n, int* out_tok, int* out_list, const int* step_ptr, hipStream_t st);
+// greedy sampling for `batch` logit rows (stride n): token -> *tok_ptrs[b] and out_lists[b][steps[b]]
+struct ArgmaxArgs { const float* logits; int n, batch; int* tok_ptrs[GVL_MAX_DECODE_BATCH]; int* out_lists[GVL_MAX_DECODE_BATCH]; int steps[GVL_MAX_DECODE_BATCH]; };
+int gvl_launch_argmax(const ArgmaxArgs& a, hipStream_t st);
+// x[b][:] = table[*tok_ptrs[b]][:]  and  (*pos_ptrs[b])++ helpers of the batched decode loop
+struct TokPtrs { const int* p[GVL_MAX_DECODE_BATCH]; int n; };
+int gvl_launch_gather_tok_rows(const bf16_t* table, const TokPtrs& toks, bf16_t* dst, int cols, hipStream_t st);
+struct IntPtrs { int* p[GVL_MAX_DECODE_BATCH]; int n; };
+int gvl_launch_inc_many(const IntPtrs& ptrs, hipStream_t st);
 int gvl_launch_inc(int* p, hipStream_t st);
 int gvl_launch_set_int(int* p, int v, hipStream_t st);

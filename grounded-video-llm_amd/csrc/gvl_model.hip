@@ -32,6 +32,8 @@ struct LlmLayerW { const bf16_t *ln1, *ln2, *qkvw, *ow, *guw, *downw; };
 struct Seq {
   bool used = false; int max_tokens = 0, n_pages = 0; std::vector<int> pages;
   int* d_block_table = nullptr; int* d_pos = nullptr; int pos = 0; int n_gen = 0;
+  int* d_tok = nullptr;   // the sequence's latest greedy token (input of its next decode step)
+  int* d_out = nullptr;   // [outlist_cap] generated ids, index = generation step
 };
 
 struct ProfRec { int cat; hipEvent_t e0, e1; double work; };
@@ -68,7 +70,8 @@ struct gvl_ctx {
   int* d_seq_tables = nullptr; int* d_seq_pos = nullptr; int seq_table_cap = 0;   // [kMaxSeqs][seq_table_cap], [kMaxSeqs]
   // decode buffers
   bf16_t *d_x = nullptr, *d_qkv = nullptr, *d_q = nullptr, *d_attn = nullptr, *d_act = nullptr;
-  float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_tok = nullptr, *d_step = nullptr, *d_outlist = nullptr, *d_ids = nullptr;
+  // (all decode work buffers hold GVL_MAX_DECODE_BATCH rows: one per sequence of a batched decode step)
+  float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_seq_tok = nullptr, *d_seq_out = nullptr, *d_ids = nullptr;
   int nsplit = 16, outlist_cap = 8192, ids_cap = 16384;
   // profiling
   bool prof = false; std::vector<ProfRec> recs;
@@ -310,37 +313,83 @@ int llm_prefill(gvl_ctx* ctx, Seq& sq, const bf16_t* embeds, int S, hipStream_t 
   return 0;
 }
 
-int decode_step(gvl_ctx* ctx, Seq& sq, hipStream_t st) {
+// One greedy decode step for B = 1, 2 or 4 sequences together: each weight matrix is streamed ONCE for the whole batch
+// (HBM-bound GEMVs: the per-sequence cost falls as 1/B), attention / RoPE / KV append run per sequence on its own pages.
+int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
   const gvl_config& f = ctx->cfg;
   const int Hd = f.hidden, H = f.heads, KV = f.kv_heads, Dr = ctx->l_Dr, D = ctx->l_D, I = f.inter;
   const int qkvw = (H + 2 * KV) * Dr;
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_rows(ctx->l_embed, ctx->d_tok, ctx->d_x, 1, Hd, st));
+  if (B != 1 && B != 2 && B != 4) return fail(ctx, GVL_ERR_ARG, "decode_step: batch must be 1, 2 or 4");
+  { TokPtrs tp; memset(&tp, 0, sizeof(tp)); tp.n = B; for (int b = 0; b < B; ++b) tp.p[b] = sqs[b]->d_tok;
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_tok_rows(ctx->l_embed, tp, ctx->d_x, Hd, st)); }
+  double ctx_tokens = 0; for (int b = 0; b < B; ++b) ctx_tokens += sqs[b]->pos + 1;
   for (int l = 0; l < f.layers; ++l) {
     const LlmLayerW& w = ctx->ll[l];
     bf16_t* Kt = ctx->kpool + (size_t)l * ctx->layer_stride; bf16_t* Vt = ctx->vpool + (size_t)l * ctx->layer_stride;
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.qkvw; g.N = qkvw; g.K = Hd; g.x = ctx->d_x; g.norm_w = w.ln1; g.eps = f.rms_eps;
+      g.batch = B; g.x_stride = Hd;
       // fused epilogue: RoPE + Q write + paged-KV append (replaces a separate qkv_post launch per layer per token)
       g.rope_on = 1; g.cos_s = ctx->cos_s; g.sin_s = ctx->sin_s; g.cos_l = ctx->cos_l; g.sin_l = ctx->sin_l;
-      g.rope_switch = ctx->cos_l ? f.rope_orig_max_pos : 0; g.pos_ptr = sq.d_pos; g.block_table = sq.d_block_table;
-      g.Q = ctx->d_q; g.Kt = Kt; g.Vt = Vt; g.H = H; g.KV = KV; g.Dr = Dr; g.D = D;
+      g.rope_switch = ctx->cos_l ? f.rope_orig_max_pos : 0;
+      for (int b = 0; b < B; ++b) { g.pos_ptrs[b] = sqs[b]->d_pos; g.tables[b] = sqs[b]->d_block_table; }
+      g.Q = ctx->d_q; g.q_stride = H * D; g.Kt = Kt; g.Vt = Vt; g.H = H; g.KV = KV; g.Dr = Dr; g.D = D;
       RUN(GVL_PROF_GEMV, 2.0 * qkvw * Hd, gvl_launch_gemv(g, st)); }
-    { DecodeAttnArgs a; memset(&a, 0, sizeof(a)); a.q = ctx->d_q; a.Kt = Kt; a.Vt = Vt; a.block_table = sq.d_block_table; a.pos_ptr = sq.d_pos; a.part = ctx->d_part; a.counters = ctx->d_counters;
-      a.out = ctx->d_attn; a.H = H; a.KV = KV; a.D = D; a.Dout = Dr; a.nsplit = ctx->nsplit; a.scale = 1.0f / sqrtf((float)Dr);
-      RUN(GVL_PROF_DECODE_ATTN, 4.0 * (sq.pos + 1) * (double)KV * D, gvl_launch_decode_attention(a, st)); }
+    { DecodeAttnArgs a; memset(&a, 0, sizeof(a)); a.q = ctx->d_q; a.q_stride = H * D; a.Kt = Kt; a.Vt = Vt;
+      for (int b = 0; b < B; ++b) { a.tables[b] = sqs[b]->d_block_table; a.pos_ptrs[b] = sqs[b]->d_pos; }
+      a.part = ctx->d_part; a.counters = ctx->d_counters; a.batch = B;
+      a.out = ctx->d_attn; a.out_stride = H * Dr; a.H = H; a.KV = KV; a.D = D; a.Dout = Dr; a.nsplit = ctx->nsplit; a.scale = 1.0f / sqrtf((float)Dr);
+      RUN(GVL_PROF_DECODE_ATTN, 4.0 * ctx_tokens * (double)KV * D, gvl_launch_decode_attention(a, st)); }
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.ow; g.N = Hd; g.K = H * Dr; g.x = ctx->d_attn; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
+      g.batch = B; g.x_stride = H * Dr; g.out_stride = Hd;
       RUN(GVL_PROF_GEMV, 2.0 * Hd * H * Dr, gvl_launch_gemv(g, st)); }
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.guw; g.N = 2 * I; g.K = Hd; g.x = ctx->d_x; g.norm_w = w.ln2; g.eps = f.rms_eps; g.act = GVL_ACT_SILU_MUL; g.out_bf16 = ctx->d_act;
+      g.batch = B; g.x_stride = Hd; g.out_stride = I;
       RUN(GVL_PROF_GEMV, 4.0 * I * Hd, gvl_launch_gemv(g, st)); }
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.downw; g.N = Hd; g.K = I; g.x = ctx->d_act; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
+      g.batch = B; g.x_stride = I; g.out_stride = Hd;
       RUN(GVL_PROF_GEMV, 2.0 * Hd * I, gvl_launch_gemv(g, st)); }
   }
   { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = ctx->l_headw; g.N = f.vocab; g.K = Hd; g.x = ctx->d_x; g.norm_w = ctx->l_norm; g.eps = f.rms_eps; g.bias = ctx->l_headb;
+    g.batch = B; g.x_stride = Hd; g.out_stride = f.vocab;
     g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, gvl_launch_gemv(g, st)); }
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(ctx->d_logits, f.vocab, ctx->d_tok, ctx->d_outlist, ctx->d_step, st));
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_inc(sq.d_pos, st));
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_inc(ctx->d_step, st));
-  sq.pos += 1; sq.n_gen += 1;
+  { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = f.vocab; am.batch = B;
+    for (int b = 0; b < B; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.steps[b] = sqs[b]->n_gen; }
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(am, st)); }
+  { IntPtrs ip; memset(&ip, 0, sizeof(ip)); ip.n = B; for (int b = 0; b < B; ++b) ip.p[b] = sqs[b]->d_pos;
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_inc_many(ip, st)); }
+  for (int b = 0; b < B; ++b) { sqs[b]->pos += 1; sqs[b]->n_gen += 1; }
   return 0;
+}
+
+// greedy decode of one group (B = 1, 2 or 4 prefilled sequences) until every member hit eos / max_new / its capacity
+int decode_group(gvl_ctx* ctx, Seq* const* sqs, int B, int max_new, int eos_id, int32_t* const* out_ids, int* const* n_out, hipStream_t st) {
+  const int CHECK_EVERY = 16;
+  int checked = 0;                       // steps already inspected for eos (all members advance together)
+  bool done[GVL_MAX_DECODE_BATCH] = {false, false, false, false};
+  const int start_gen = sqs[0]->n_gen;   // members of a group must be in the same generation step
+  for (int b = 1; b < B; ++b) if (sqs[b]->n_gen != start_gen) return fail(ctx, GVL_ERR_STATE, "decode batch: sequences are at different generation steps");
+  for (;;) {
+    const int n_gen = sqs[0]->n_gen;
+    bool full = n_gen >= max_new;
+    for (int b = 0; b < B; ++b) full = full || sqs[b]->pos >= sqs[b]->max_tokens;
+    if (full || (eos_id >= 0 && n_gen - checked >= CHECK_EVERY) || (eos_id >= 0 && checked == 0)) {
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      bool all_done = true;
+      for (int b = 0; b < B; ++b) {
+        if (done[b]) continue;
+        HIPCHK(ctx, hipMemcpy(out_ids[b] + checked, sqs[b]->d_out + checked, (size_t)(n_gen - checked) * 4, hipMemcpyDeviceToHost));
+        if (eos_id >= 0)
+          for (int i = checked; i < n_gen; ++i)
+            if (out_ids[b][i] == eos_id) { *n_out[b] = i + 1; done[b] = true; break; }
+        if (!done[b] && full) { *n_out[b] = n_gen < max_new ? n_gen : max_new; done[b] = true; }
+        all_done = all_done && done[b];
+      }
+      checked = n_gen;
+      if (all_done) return 0;
+    }
+    int rc = decode_step(ctx, sqs, B, st);
+    if (rc) return rc;
+  }
 }
 
 }  // namespace
@@ -425,16 +474,17 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
     for (int p = pages - 1; p >= 0; --p) ctx->free_pages.push_back(p);
     const int qkvw = (f.heads + 2 * f.kv_heads) * ctx->l_Dr;
     bool ok = true;
-    ok &= hipMalloc((void**)&ctx->d_x, (size_t)f.hidden * 2) == hipSuccess;
+    const size_t NB = GVL_MAX_DECODE_BATCH;
+    ok &= hipMalloc((void**)&ctx->d_x, NB * f.hidden * 2) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_qkv, (size_t)qkvw * 2) == hipSuccess;
-    ok &= hipMalloc((void**)&ctx->d_q, (size_t)f.heads * ctx->l_D * 2) == hipSuccess && hipMemset(ctx->d_q, 0, (size_t)f.heads * ctx->l_D * 2) == hipSuccess;
-    ok &= hipMalloc((void**)&ctx->d_attn, (size_t)f.heads * ctx->l_Dr * 2) == hipSuccess;
-    ok &= hipMalloc((void**)&ctx->d_act, (size_t)f.inter * 2) == hipSuccess;
-    ok &= hipMalloc((void**)&ctx->d_logits, (size_t)f.vocab * 4) == hipSuccess;
-    ok &= hipMalloc((void**)&ctx->d_part, (size_t)f.heads * ctx->nsplit * (ctx->l_D + 2) * 4) == hipSuccess;
-    ok &= hipMalloc((void**)&ctx->d_counters, (size_t)f.heads * 4) == hipSuccess && hipMemset(ctx->d_counters, 0, (size_t)f.heads * 4) == hipSuccess;
-    ok &= hipMalloc((void**)&ctx->d_tok, 4) == hipSuccess && hipMalloc((void**)&ctx->d_step, 4) == hipSuccess;
-    ok &= hipMalloc((void**)&ctx->d_outlist, (size_t)ctx->outlist_cap * 4) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_q, NB * f.heads * ctx->l_D * 2) == hipSuccess && hipMemset(ctx->d_q, 0, NB * f.heads * ctx->l_D * 2) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_attn, NB * f.heads * ctx->l_Dr * 2) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_act, NB * f.inter * 2) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_logits, NB * f.vocab * 4) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_part, NB * f.heads * ctx->nsplit * (ctx->l_D + 2) * 4) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_counters, NB * f.heads * 4) == hipSuccess && hipMemset(ctx->d_counters, 0, NB * f.heads * 4) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_seq_tok, (size_t)gvl_ctx::kMaxSeqs * 4) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_seq_out, (size_t)gvl_ctx::kMaxSeqs * ctx->outlist_cap * 4) == hipSuccess;
     ctx->seq_table_cap = (f.max_seq + 63) / 64;
     ok &= hipMalloc((void**)&ctx->d_seq_tables, (size_t)gvl_ctx::kMaxSeqs * ctx->seq_table_cap * 4) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_seq_pos, (size_t)gvl_ctx::kMaxSeqs * 4) == hipSuccess;
@@ -449,7 +499,7 @@ int gvl_destroy(gvl_ctx* ctx) {
   if (!ctx) return 0;
   hipDeviceSynchronize();
   for (auto& kv : ctx->w) if (kv.second.p) hipFree(kv.second.p);
-  void* ptrs[] = {ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_tok, ctx->d_step, ctx->d_outlist, ctx->d_ids, ctx->d_seq_tables, ctx->d_seq_pos};
+  void* ptrs[] = {ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_out, ctx->d_ids, ctx->d_seq_tables, ctx->d_seq_pos};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& r : ctx->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   delete ctx;
@@ -614,6 +664,8 @@ int gvl_seq_alloc(gvl_ctx* ctx, int max_tokens, int* seq_id) {
   // for the LLM path -- the reference is single-stream too).
   s.d_block_table = ctx->d_seq_tables + (size_t)id * ctx->seq_table_cap;
   s.d_pos = ctx->d_seq_pos + id;
+  s.d_tok = ctx->d_seq_tok + id;
+  s.d_out = ctx->d_seq_out + (size_t)id * ctx->outlist_cap;
   HIPCHK(ctx, hipMemcpy(s.d_block_table, s.pages.data(), (size_t)np * 4, hipMemcpyHostToDevice));   // blocking; d_pos is set by gvl_prefill on ITS stream
   *seq_id = id;
   return 0;
@@ -636,37 +688,40 @@ int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int S, float* 
   int rc = llm_prefill(ctx, sq, embeds, S, st);
   if (rc) return rc;
   if (last_logits) HIPCHK(ctx, hipMemcpyAsync(last_logits, ctx->d_logits, (size_t)ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(ctx->d_step, 0, st));
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(ctx->d_logits, ctx->cfg.vocab, ctx->d_tok, ctx->d_outlist, ctx->d_step, st));
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(ctx->d_step, 1, st));
+  { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = ctx->cfg.vocab; am.batch = 1;
+    am.tok_ptrs[0] = sq.d_tok; am.out_lists[0] = sq.d_out; am.steps[0] = 0;      // first generated token = argmax of the prefill logits
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(am, st)); }
   RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sq.d_pos, S, st));
   sq.pos = S; sq.n_gen = 1;
   return 0;
 }
 
 int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t* out_ids, int* n_out, void* stream) {
-  REQUIRE_READY(ctx->has_llm, "gvl_decode_greedy");
-  if (seq_id < 0 || seq_id >= (int)ctx->seqs.size() || !ctx->seqs[seq_id].used) return fail(ctx, GVL_ERR_ARG, "gvl_decode_greedy: bad seq");
-  Seq& sq = ctx->seqs[seq_id];
-  if (!out_ids || !n_out || max_new <= 0 || max_new > ctx->outlist_cap) return fail(ctx, GVL_ERR_ARG, "gvl_decode_greedy: bad arguments");
-  if (sq.n_gen < 1) return fail(ctx, GVL_ERR_STATE, "gvl_decode_greedy: call gvl_prefill first");
-  hipStream_t st = (hipStream_t)stream;
-  const int CHECK_EVERY = 16;
-  int checked = 0;   // tokens already inspected for eos
-  for (;;) {
-    const bool full = sq.n_gen >= max_new || sq.pos >= sq.max_tokens;
-    if (full || (eos_id >= 0 && sq.n_gen - checked >= CHECK_EVERY) || (eos_id >= 0 && checked == 0)) {
-      HIPCHK(ctx, hipStreamSynchronize(st));
-      HIPCHK(ctx, hipMemcpy(out_ids + checked, ctx->d_outlist + checked, (size_t)(sq.n_gen - checked) * 4, hipMemcpyDeviceToHost));
-      if (eos_id >= 0)
-        for (int i = checked; i < sq.n_gen; ++i)
-          if (out_ids[i] == eos_id) { *n_out = i + 1; return 0; }
-      checked = sq.n_gen;
-      if (full) { *n_out = sq.n_gen < max_new ? sq.n_gen : max_new; return 0; }
-    }
-    int rc = decode_step(ctx, sq, st);
-    if (rc) return rc;
+  return gvl_decode_greedy_batch(ctx, &seq_id, 1, max_new, eos_id, out_ids, n_out, stream);
+}
+
+int gvl_decode_greedy_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, int max_new, int eos_id, int32_t* out_ids, int* n_out, void* stream) {
+  REQUIRE_READY(ctx->has_llm, "gvl_decode_greedy_batch");
+  if (!seq_ids || n_seqs <= 0 || n_seqs > gvl_ctx::kMaxSeqs || !out_ids || !n_out || max_new <= 0 || max_new > ctx->outlist_cap)
+    return fail(ctx, GVL_ERR_ARG, "gvl_decode_greedy_batch: bad arguments");
+  for (int i = 0; i < n_seqs; ++i) {
+    const int id = seq_ids[i];
+    if (id < 0 || id >= (int)ctx->seqs.size() || !ctx->seqs[id].used) return fail(ctx, GVL_ERR_ARG, "gvl_decode_greedy_batch: bad seq");
+    if (ctx->seqs[id].n_gen != 1) return fail(ctx, GVL_ERR_STATE, "gvl_decode_greedy_batch: every sequence must be freshly prefilled (gvl_prefill)");
+    for (int j = 0; j < i; ++j) if (seq_ids[j] == id) return fail(ctx, GVL_ERR_ARG, "gvl_decode_greedy_batch: duplicate seq");
   }
+  hipStream_t st = (hipStream_t)stream;
+  // groups of 4, then 2, then 1: a group streams the weights once per step for all of its members
+  int i = 0;
+  while (i < n_seqs) {
+    const int left = n_seqs - i, B = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+    Seq* sqs[GVL_MAX_DECODE_BATCH]; int32_t* outs[GVL_MAX_DECODE_BATCH]; int* nouts[GVL_MAX_DECODE_BATCH];
+    for (int b = 0; b < B; ++b) { sqs[b] = &ctx->seqs[seq_ids[i + b]]; outs[b] = out_ids + (size_t)(i + b) * max_new; nouts[b] = n_out + i + b; }
+    const int rc = decode_group(ctx, sqs, B, max_new, eos_id, outs, nouts, st);
+    if (rc) return rc;
+    i += B;
+  }
+  return 0;
 }
 
 int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, void* stream) {
@@ -675,8 +730,9 @@ int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, voi
   Seq& sq = ctx->seqs[seq_id];
   if (tok < 0 || tok >= ctx->cfg.vocab || sq.pos >= sq.max_tokens || sq.pos == 0) return fail(ctx, GVL_ERR_ARG, "gvl_decode_step_logits: bad token / sequence full / not prefilled");
   hipStream_t st = (hipStream_t)stream;
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(ctx->d_tok, tok, st));
-  int rc = decode_step(ctx, sq, st);
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sq.d_tok, tok, st));
+  Seq* one[1] = {&sq};
+  int rc = decode_step(ctx, one, 1, st);
   if (rc) return rc;
   if (logits) HIPCHK(ctx, hipMemcpyAsync(logits, ctx->d_logits, (size_t)ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
   return 0;

@@ -211,6 +211,16 @@ class Engine:
                   "gvl_decode_greedy")
         return [int(buf[i]) for i in range(n.value)]
 
+    def decode_greedy_batch(self, seqs: Sequence[int], max_new: int, eos_id: Optional[int]) -> List[List[int]]:
+        """Greedy decode of several freshly prefilled sequences together (weights streamed once per step per group of 4/2/1)."""
+        n = len(seqs)
+        ids = (C.c_int * n)(*[int(s) for s in seqs])
+        buf = (C.c_int32 * (n * max_new))()
+        nout = (C.c_int * n)()
+        self._chk(self.lib.gvl_decode_greedy_batch(self.ctx, ids, n, int(max_new), -1 if eos_id is None else int(eos_id), buf, nout, self.stream),
+                  "gvl_decode_greedy_batch")
+        return [[int(buf[i * max_new + j]) for j in range(nout[i])] for i in range(n)]
+
     def decode_step_logits(self, seq: int, tok: int) -> torch.Tensor:
         logits = torch.empty((self.geo.vocab,), dtype=torch.float32, device=self.device)
         self._chk(self.lib.gvl_decode_step_logits(self.ctx, seq, int(tok), _ptr(logits), self.stream), "gvl_decode_step_logits")

@@ -114,6 +114,13 @@ int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int seq_len, f
                 void* stream);
 int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t* out_ids_host,
                       int* n_out, void* stream);
+/* Batched greedy decode of n_seqs freshly prefilled sequences (the reference batches clips in generate() with
+ * left padding, llava_next_video.py:622-647 -- here every sequence keeps its own pages and length, no padding).  Groups of
+ * 4 / 2 / 1 sequences advance together: every weight matrix is streamed ONCE per step for the whole group, so the HBM cost per
+ * sequence falls as 1/group; the per-sequence arithmetic (and therefore the ids) is bit-identical to gvl_decode_greedy.
+ * out_ids_host int32 [n_seqs][max_new]; n_out [n_seqs].  A group runs until all of its members hit eos / max_new. */
+int gvl_decode_greedy_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, int max_new, int eos_id,
+                            int32_t* out_ids_host, int* n_out, void* stream);
 /* teacher-forced single step (parity tests): appends token `tok`, returns logits f32 [vocab]. */
 int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, void* stream);
 

@@ -153,3 +153,48 @@ def test_phi3_full_width_layer():
     check(lg, ref, 1e-2, "phi3 full-width decode step (GEMV + paged attention)")
     eng.seq_free(seq)
     eng.close()
+
+
+@pytest.mark.parametrize("which", ["phi3_tiny", "llama_tiny"])
+def test_decode_batch_is_bit_identical_to_single(which):
+    """sequences of DIFFERENT lengths decoded together (groups of 4 / 2 / 1 sharing one weight stream per step)
+    must generate exactly the ids of the one-at-a-time decode: the per-sequence arithmetic order is unchanged."""
+    meta, g = load_golden(which)
+    c = meta["cfg"]
+    if which == "phi3_tiny":
+        geo = _phi_geo(c)
+        W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
+    else:
+        geo = tiny_geo(llm="llama3", hidden=c["hidden"], inter=c["inter"], layers=c["layers"], heads=c["heads"], kv_heads=c["kv_heads"], vocab=c["vocab"],
+                       rope_theta=c["rope_theta"], rope_orig_max_pos=0)
+        W = synth.llm_weights("llama", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
+    eng = llm_engine(geo, W)
+    lens = [9, 70, 33, 129, 5, 64, 17]                       # crosses the 64-token page size both ways
+    xs = [synth.det_tensor(f"batch.{which}.{i}", (n, c["hidden"]), 0.5).to(DEV).to(bf) for i, n in enumerate(lens)]
+    new = 12
+    single = [eng.generate_ids(x, new, None) for x in xs]
+    assert all(len(s) == new for s in single)
+    for n in (2, 3, 4, 7):                                   # 2; 2+1; 4; 4+2+1
+        seqs = []
+        for x in xs[:n]:
+            s = eng.seq_alloc(x.shape[0] + new)
+            eng.prefill(s, x)
+            seqs.append(s)
+        got = eng.decode_greedy_batch(seqs, new, None)
+        for s in seqs:
+            eng.seq_free(s)
+        assert got == single[:n], f"{which}: batched decode of {n} sequences differs from the single-sequence decode"
+    # eos: a member that stops early reports only its ids up to eos; the others are unaffected
+    eos = single[1][3]
+    seqs = []
+    for x in xs[:2]:
+        s = eng.seq_alloc(x.shape[0] + new)
+        eng.prefill(s, x)
+        seqs.append(s)
+    got = eng.decode_greedy_batch(seqs, new, eos)
+    for s in seqs:
+        eng.seq_free(s)
+    for ids, ref in zip(got, single[:2]):
+        cut = ref.index(eos) + 1 if eos in ref else new
+        assert ids == ref[:cut]
+    eng.close()

@@ -1,10 +1,14 @@
 """bench.py -- the reference's headline metric on MI355X: end-to-end clips/s (and grounding-answer
 tokens/s) for the 96-frame Phi-3.5-3.8B configuration (BASELINE.json configs[1]).
 
-A "step" = one pass of the hot path over one batch of synthetic input: for every rank one 96-frame clip
-(12 x 336^2 spatial frames + 96 x 224^2 temporal frames, already resident in HBM) -> CLIP ViT-L/14-336
+A "step" = one pass of the hot path over one batch of synthetic input: for every rank `--clips-per-step` (default 4)
+96-frame clips, each (12 x 336^2 spatial frames + 96 x 224^2 temporal frames, already resident in HBM) -> CLIP ViT-L/14-336
 (23 layers) + InternVideo2-1B (39 blocks) -> merge/pool + projectors -> 3420 visual tokens spliced into a
 ~100-token prompt -> Phi-3.5 prefill (S ~ 3520) -> greedy decode of 12 new tokens through the paged KV cache.
+The clips of a step are prefilled one after the other and decoded TOGETHER (gvl_decode_greedy_batch: every weight matrix is
+streamed once per token for all of them -- the reference batches clips in generate() too, llava_next_video.py:622-647), while
+the vision encode of the next step's clips runs on a second stream.  `single_clip_latency_ms` (one clip, stages back to back)
+and `clips_per_s_at_1_clip_per_step` are reported next to `value`.
 Random-init weights of the real architecture, synthetic pixels (no network for checkpoints/datasets).
 
 N > 1 (one process per GPU, RCCL): N clips in flight per step; every clip's 12-segment frame batch is
@@ -37,8 +41,8 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
 
-def build_engine(dev, frames_per_seg=8, max_segs=12, new_tokens=12):
-    geo = E.TowerGeometry(llm="phi3.5", frames_per_seg=frames_per_seg, max_segs=max_segs, max_seq=4096, max_prefill=3712, kv_pages=64)
+def build_engine(dev, frames_per_seg=8, max_segs=12, new_tokens=12, clips_per_step=1):
+    geo = E.TowerGeometry(llm="phi3.5", frames_per_seg=frames_per_seg, max_segs=max_segs, max_seq=4096, max_prefill=3712, kv_pages=64 * clips_per_step)
     geo.rope_short, geo.rope_long = synth.longrope_factors(96)
     eng = E.Engine(geo, dev)
     d = str(dev)
@@ -129,6 +133,33 @@ class Stepper:
             self.vis_next = self.encode()
             self.evV.record(self.sV)
 
+    def pipe_start_multi(self, cps):
+        self.cps = cps
+        self.sV, self.sL = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        self.evV, self.evL = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(self.sV):
+            self.vis_next = [self.encode() for _ in range(cps)]
+            self.evV.record(self.sV)
+
+    def pipe_step_multi(self):
+        """Completes `cps` clips (prefill each, then ONE batched greedy decode: the LLM weights are streamed once per token for all
+        of them -- continuous batching) and launches the vision encode of the next `cps` clips beside them."""
+        with torch.cuda.stream(self.sL):
+            self.sL.wait_event(self.evV)
+            seqs, S = [], 0
+            for vis in self.vis_next:
+                vis.record_stream(self.sL)
+                seq, S = self.llm(vis)
+                seqs.append(seq)
+        with torch.cuda.stream(self.sV):
+            self.vis_next = [self.encode() for _ in range(self.cps)]
+            self.evV.record(self.sV)
+        with torch.cuda.stream(self.sL):
+            outs = self.eng.decode_greedy_batch(seqs, self.new_tokens, None)   # synchronises its stream
+            for seq in seqs:
+                self.eng.seq_free(seq)
+        return outs[-1], S
+
     def pipe_step(self):
         """Completes ONE clip (prefill + decode) and launches ONE clip's vision encode for the next step."""
         with torch.cuda.stream(self.sL):
@@ -190,6 +221,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--new-tokens", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clips-per-step", type=int, default=int(os.environ.get("GVL_BENCH_CPS", "4")),
+                    help="pipelined mode: clips per GPU per step; their greedy decode is batched (one weight stream per token for all of them)")
     ap.add_argument("--mode", choices=["pipelined", "serial"], default="pipelined",
                     help="pipelined: 2 clips in flight per GPU (vision of clip k+1 overlaps decode of clip k); serial: one clip at a time")
     args = ap.parse_args()
@@ -211,7 +244,8 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
-    eng, geo = build_engine(dev, new_tokens=args.new_tokens)
+    cps = args.clips_per_step if args.mode == "pipelined" else 1
+    eng, geo = build_engine(dev, new_tokens=args.new_tokens, clips_per_step=cps)
     st = Stepper(eng, geo, rank, world, args.new_tokens)
 
     def barrier():
@@ -220,7 +254,10 @@ def main():
         torch.cuda.synchronize()
 
     S = 0
-    if args.mode == "pipelined":
+    if args.mode == "pipelined" and cps > 1:
+        st.pipe_start_multi(cps)
+        stepfn = st.pipe_step_multi
+    elif args.mode == "pipelined":
         st.pipe_start()
         stepfn = st.pipe_step
     else:
@@ -238,7 +275,7 @@ def main():
         tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    clips_per_s = world * args.steps / dt
+    clips_per_s = world * args.steps * cps / dt
 
     # ---- untimed extras: single-clip latency, decode-only rate, per-kernel-family profile, CPU baseline -----
     torch.cuda.synchronize()
@@ -256,6 +293,27 @@ def main():
         st.step()
     decode_tok_s = 2 * (args.new_tokens - 1) / st.decode_s if st.decode_s > 0 else None
     st.time_decode = False
+    # batched decode alone (cps sequences share one weight stream per token), and the 1-clip-per-step pipeline for reference
+    decode_tok_s_batched = None
+    value_1cps = None
+    if cps > 1:
+        vis = st.encode()
+        seqs = [st.llm(vis)[0] for _ in range(cps)]
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        eng.decode_greedy_batch(seqs, args.new_tokens, None)
+        decode_tok_s_batched = cps * (args.new_tokens - 1) / (time.perf_counter() - tb)
+        for q in seqs:
+            eng.seq_free(q)
+        st.pipe_start()
+        for _ in range(2):
+            st.pipe_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(4):
+            st.pipe_step()
+        torch.cuda.synchronize()
+        value_1cps = 4 / (time.perf_counter() - t1)
     eng.prof_enable(True)
     st.step()
     prof = {}
@@ -292,9 +350,14 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights at full shape, N(0,1) pixels)",
                "config": {"workload": "Phi-3.5-3.8B, 96 frames (12 segs x 8), 336^2 spatial + 224^2 temporal, ~100-token prompt, "
-                                      f"{args.new_tokens} greedy tokens, 1 clip per GPU per step" + (" (2 clips in flight per GPU: vision encode of clip k+1 overlaps the decode of clip k)" if args.mode == "pipelined" else ""), "prefill_len": S, "visual_tokens": 12 * st.L,
+                                      f"{args.new_tokens} greedy tokens, {cps} clip{'s' if cps > 1 else ''} per GPU per step" +
+                                      ((f" ({2 * cps} clips in flight per GPU: the vision encode of the next {cps} overlaps the prefill + " +
+                                        ("batched greedy decode" if cps > 1 else "decode") + f" of the current {cps})") if args.mode == "pipelined" else ""),
+                          "clips_per_step": cps, "ms_per_clip": round(1e3 * dt / (args.steps * cps), 2), "prefill_len": S, "visual_tokens": 12 * st.L,
                           "parallelism": "1 GPU" if world == 1 else f"frame-batch sharded over {world} GPUs + all-gather of visual tokens, LLM replica per clip"},
                "decode_tokens_per_s": None if decode_tok_s is None else round(world * decode_tok_s, 1),
+               "decode_tokens_per_s_batched": None if decode_tok_s_batched is None else round(world * decode_tok_s_batched, 1),
+               "clips_per_s_at_1_clip_per_step": None if value_1cps is None else round(world * value_1cps, 4),
                "single_clip_latency_ms": round(latency_ms, 2), "mode": args.mode, "ids_match_serial": same_ids,
                "roofline": roofline, "stages": stages}
         if world == 1 and not args.no_cpu_baseline:

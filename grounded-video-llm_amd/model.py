@@ -165,12 +165,25 @@ class LLAVA_NEXT_VIDEO:
 
     def generate_ids(self, ids_arr, mask, feats, max_new: int) -> List[List[int]]:
         eos = getattr(self.tokenizer, "eos_token_id", None)
-        out = []
+        eng = self.engine
+        if ids_arr.shape[0] == 1:
+            row = [int(t) for t, m in zip(ids_arr[0], mask[0]) if m]
+            return [eng.generate_ids(eng.splice(row, feats[0]), max_new, eos)]
+        # bs > 1 (the reference left-pads the batch, llava_next_video.py:622-647): every sample keeps its own paged KV and its
+        # un-padded length -- identical maths to the masked left-padded batch -- and the greedy decode of the whole batch runs
+        # together (gvl_decode_greedy_batch: one weight stream per token for groups of 4 / 2 / 1 sequences)
+        seqs = []
         for b in range(ids_arr.shape[0]):
-            row = [int(t) for t, m in zip(ids_arr[b], mask[b]) if m]       # un-padded: identical maths to the left-padded batch
-            emb = self.engine.splice(row, feats[b])
-            out.append(self.engine.generate_ids(emb, max_new, eos))
-        return out
+            row = [int(t) for t, m in zip(ids_arr[b], mask[b]) if m]
+            emb = eng.splice(row, feats[b])
+            seq = eng.seq_alloc(emb.shape[0] + max_new)
+            eng.prefill(seq, emb)
+            seqs.append(seq)
+        try:
+            return eng.decode_greedy_batch(seqs, max_new, eos)
+        finally:
+            for seq in seqs:
+                eng.seq_free(seq)
 
 
 def load_reference_checkpoints(llm: str, pretrained_video_path: str, pretrained_vision_proj_llm_path: str):

@@ -58,4 +58,14 @@ def test_generate_matches_oracle(llm):
     with pytest.raises(NotImplementedError):
         model.generate(samples, do_sample=True)
     print(f"[parity] generate({llm}) ids {got} oracle {ref_ids}; text {texts[0]!r}")
+    # batch of 3 samples with DIFFERENT prompts (the reference left-pads, llava_next_video.py:622-647): the batched decode must give,
+    # sample by sample, exactly what the one-sample generate() gives
+    prompts = [prompt, P.build_prompt(llm, "grounding", "When does the dog jump?"), P.build_prompt(llm, "qa", "Describe the video in detail please.")]
+    sp3 = torch.cat([sp, synth.det_tensor("gen.sp2", (2, 2, 3, 336, 336))], 0).to(DEV)
+    tp3 = torch.cat([tp, synth.det_tensor("gen.tp2", (2, 4, 3, 224, 224))], 0).to(DEV)
+    batch = {"prompts": prompts, "spatial_pixel_values": sp3, "temporal_pixel_values": tp3, "video_ids": ["a", "b", "c"]}
+    texts3 = model.generate(batch, do_sample=False, num_beams=1, max_new_tokens=10)
+    singles = [model.generate({"prompts": [prompts[i]], "spatial_pixel_values": sp3[i:i + 1], "temporal_pixel_values": tp3[i:i + 1], "video_ids": ["x"]},
+                              do_sample=False, num_beams=1, max_new_tokens=10)[0] for i in range(3)]
+    assert texts3 == singles and texts3[0] == texts[0]
     model.engine.close()

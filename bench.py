@@ -8,7 +8,7 @@ A "step" = one pass of the hot path over one batch of synthetic input: for every
 The clips of a step are prefilled one after the other and decoded TOGETHER (gvl_decode_greedy_batch: every weight matrix is
 streamed once per token for all of them -- the reference batches clips in generate() too, llava_next_video.py:622-647), while
 the vision encode of the next step's clips runs on a second stream.  `single_clip_latency_ms` (one clip, stages back to back)
-and `clips_per_s_at_1_clip_per_step` are reported next to `value`.
+is reported next to `value`; `--clips-per-step 1` gives the one-clip-per-step pipeline (8.6 clips/s).
 Random-init weights of the real architecture, synthetic pixels (no network for checkpoints/datasets).
 
 N > 1 (one process per GPU, RCCL): N clips in flight per step; every clip's 12-segment frame batch is
@@ -293,9 +293,8 @@ def main():
         st.step()
     decode_tok_s = 2 * (args.new_tokens - 1) / st.decode_s if st.decode_s > 0 else None
     st.time_decode = False
-    # batched decode alone (cps sequences share one weight stream per token), and the 1-clip-per-step pipeline for reference
+    # batched decode alone (cps sequences share one weight stream per token)
     decode_tok_s_batched = None
-    value_1cps = None
     if cps > 1:
         vis = st.encode()
         seqs = [st.llm(vis)[0] for _ in range(cps)]
@@ -305,15 +304,6 @@ def main():
         decode_tok_s_batched = cps * (args.new_tokens - 1) / (time.perf_counter() - tb)
         for q in seqs:
             eng.seq_free(q)
-        st.pipe_start()
-        for _ in range(2):
-            st.pipe_step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(4):
-            st.pipe_step()
-        torch.cuda.synchronize()
-        value_1cps = 4 / (time.perf_counter() - t1)
     eng.prof_enable(True)
     st.step()
     prof = {}
@@ -357,7 +347,6 @@ def main():
                           "parallelism": "1 GPU" if world == 1 else f"frame-batch sharded over {world} GPUs + all-gather of visual tokens, LLM replica per clip"},
                "decode_tokens_per_s": None if decode_tok_s is None else round(world * decode_tok_s, 1),
                "decode_tokens_per_s_batched": None if decode_tok_s_batched is None else round(world * decode_tok_s_batched, 1),
-               "clips_per_s_at_1_clip_per_step": None if value_1cps is None else round(world * value_1cps, 4),
                "single_clip_latency_ms": round(latency_ms, 2), "mode": args.mode, "ids_match_serial": same_ids,
                "roofline": roofline, "stages": stages}
         if world == 1 and not args.no_cpu_baseline:

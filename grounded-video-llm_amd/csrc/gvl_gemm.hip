@@ -746,27 +746,64 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
   if ((cfg == 82 || cfg == 85) && ((size_t)a.N * a.K * 2 >= (1ull << 32) || (size_t)a.M * a.lda * 2 >= (1ull << 32))) cfg = 21;   // 32-bit DMA offsets
   const int epi = (a.act & 3) | ((a.out_f32 ? 1 : 0) << 2) | ((a.resid ? 1 : 0) << 3) | ((a.gamma ? 1 : 0) << 4) | ((a.bias ? 1 : 0) << 5);
   if (cfg == 82 && a.tile_cfg == 0 && env_cfg == 0 && a.m_begin == 0) {
-    // Wave-quantisation split: the 256x256 kernel runs one block per CU, so a launch costs ceil(tiles / 256) full tile
-    // times.  Give it only whole rounds (a row band of M whose tile count is <= rounds*256) and run the remaining rows on
-    // the 128x128 kernel (512 resident blocks, 4x cheaper tiles) -- e.g. InternVideo2 proj/fc2: 582 tiles = 3 rounds
-    // becomes 2 rounds + 253 small tiles (measured -25 %).
+    // Wave-quantisation planner.  The persistent 256x256 kernel runs one block per CU, so a launch costs ceil(tiles / CUs)
+    // tile times, and a partial last tile column (N = 1408 = 5.5 x 256) wastes half of its MFMA work.  Candidate plans, costed
+    // in units of one 256x256 tile time (the 128x128 kernel: 512 resident blocks, a full round of them = 0.66 units --
+    // half the FLOPs at ~0.76x the rate -- and half a round = 0.33):
+    //   W  whole GEMM on the big kernel;
+    //   M  whole rounds of tile ROWS on the big kernel, the remaining rows on the small kernel;
+    //   N  the full 256-wide tile columns through W or M, the N % 256 tail columns on the small kernel.
+    // e.g. InternVideo2 proj/fc2 (M = 24588, N = 1408): W = 3, M = 2.66, N = 2.33 (485 big tiles in 2 rounds + 193 small).
     static const int n_cu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
-    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
-    const long tiles = (long)tiles_m * tiles_n;
-    const long rounds = tiles / n_cu;
-    if (rounds >= 1 && tiles % n_cu != 0) {
-      const int big_rows = (int)((rounds * n_cu) / tiles_n);          // m-tile rows given to the big kernel
-      // cost model in units of one 256x256 tile time: a round of 512 small tiles carries half the FLOPs of a big round and
-      // runs at ~0.76x its rate (measured 900 vs 1190 TFLOP/s) -> 0.66; split only when it beats ceil(tiles / CUs)
-      const long small_tiles = (long)((a.M - big_rows * 256 + 127) / 128) * ((a.N + 127) / 128);
-      const double cost_split = (double)rounds + 0.66 * (double)((small_tiles + 2 * n_cu - 1) / (2 * n_cu));
-      const double cost_whole = (double)((tiles + n_cu - 1) / n_cu);
-      if (big_rows >= 1 && big_rows < tiles_m && cost_split < cost_whole - 0.1) {
-        GemmArgs big = a; big.M = big_rows * 256; big.tile_cfg = 82;
-        GemmArgs rest = a; rest.m_begin = big_rows * 256; rest.tile_cfg = 21;
-        const int rc = gvl_launch_gemm(big, st);
-        return rc ? rc : gvl_launch_gemm(rest, st);
+    auto small_cost = [&](long t) { const long halves = (t + n_cu - 1) / n_cu; return t > 0 ? 0.33 * (double)halves : 0.0; };
+    struct Plan { double cost; int big_rows; };   // big_rows = tile rows given to the big kernel (all of them: no M split)
+    auto plan_mw = [&](int M, int N) {            // best of W and M for an [M, N] problem
+      const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+      const long tiles = (long)tiles_m * tiles_n, rounds = tiles / n_cu;
+      Plan best{(double)((tiles + n_cu - 1) / n_cu), tiles_m};
+      if (rounds >= 1 && tiles % n_cu != 0) {
+        const int br = (int)((rounds * n_cu) / tiles_n);
+        if (br >= 1 && br < tiles_m) {
+          const double c = (double)rounds + small_cost((long)((M - br * 256 + 127) / 128) * ((N + 127) / 128));
+          if (c < best.cost - 0.1) best = Plan{c, br};
+        }
       }
+      return best;
+    };
+    const Plan whole = plan_mw(a.M, a.N);
+    int n_big = a.N;
+    Plan chosen = whole;
+    if (a.N % 256 != 0 && a.N > 256 && a.act != GVL_ACT_SILU_MUL) {
+      const int nb = (a.N / 256) * 256;
+      const Plan p = plan_mw(a.M, nb);
+      const double c = p.cost + small_cost((long)((a.M + 127) / 128) * ((a.N - nb + 127) / 128));
+      if (c < whole.cost - 0.1) { chosen = Plan{c, p.big_rows}; n_big = nb; }
+    }
+    const int tiles_m = (a.M + 255) / 256;
+    if (n_big != a.N || chosen.big_rows < tiles_m) {
+      const int es_ = a.out_f32 ? 4 : 2;
+      auto cols = [&](const GemmArgs& g, int n0, int n1) {       // sub-problem on output columns [n0, n1): pointer offsets only
+        GemmArgs r = g;
+        r.W = g.W + (size_t)n0 * g.K; r.N = n1 - n0;
+        r.C = (char*)g.C + (size_t)n0 * es_;
+        if (g.resid) r.resid = (const char*)g.resid + (size_t)n0 * es_;
+        if (g.bias) r.bias = g.bias + n0;
+        if (g.gamma) r.gamma = g.gamma + n0;
+        return r;
+      };
+      GemmArgs left = cols(a, 0, n_big);
+      int rc = 0;
+      if (chosen.big_rows < tiles_m) {
+        GemmArgs big = left; big.M = chosen.big_rows * 256; big.tile_cfg = 82;
+        GemmArgs rest = left; rest.m_begin = chosen.big_rows * 256; rest.tile_cfg = 21;
+        rc = gvl_launch_gemm(big, st);
+        if (!rc) rc = gvl_launch_gemm(rest, st);
+      } else {
+        left.tile_cfg = 82;
+        rc = gvl_launch_gemm(left, st);
+      }
+      if (!rc && n_big != a.N) { GemmArgs tail = cols(a, n_big, a.N); tail.tile_cfg = 21; rc = gvl_launch_gemm(tail, st); }
+      return rc;
     }
   }
   const int es = a.out_f32 ? 4 : 2;

@@ -124,3 +124,26 @@ def test_gemv(eng, N, K):
     x = _rand(f"gx{K}", (K,), 1.0).to(bf)
     b = _rand(f"gb{N}", (N,), 0.3)
     check(eng.op_gemv(W, x, b), W.float() @ x.float() + b, 2e-4, f"gemv {N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(24588, 1408, 1408, "bias_gamma_resid"), (24588, 4224, 1408, "plain"), (24588, 1408, 6144, "bias_gamma_resid"),
+                                       (3519, 3072, 3072, "resid")])
+def test_gemm_planner_full_shapes(eng, M, N, K, epi):
+    """The launcher's wave-quantisation planner at the real InternVideo2 / Phi shapes: tile-row split (M), N % 256 tail columns on the
+    128x128 kernel (N), persistent 256x256 kernel for the rest -- every output element must come from exactly one of the launches."""
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K)
+    A = torch.randn((M, K), device=DEV, generator=g).to(bf)
+    W = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).to(bf)
+    acc = A.float() @ W.float().T
+    rb = lambda t: t.to(bf).float()
+    if epi == "plain":
+        got, ref = eng.op_gemm(A, W), acc
+    elif epi == "resid":
+        res = torch.randn((M, N), device=DEV, generator=g).to(bf)
+        got, ref = eng.op_gemm(A, W, resid=res), res.float() + rb(acc)
+    else:
+        bias = torch.randn((N,), device=DEV, generator=g) * 0.5
+        gam = torch.randn((N,), device=DEV, generator=g) * 0.05 + 0.1
+        res = torch.randn((M, N), device=DEV, generator=g).to(bf)
+        got, ref = eng.op_gemm(A, W, bias=bias, gamma=gam, resid=res), res.float() + rb(rb(acc + bias) * gam)
+    check(got, ref, 8e-3, f"gemm planner {M}x{N}x{K} {epi}")

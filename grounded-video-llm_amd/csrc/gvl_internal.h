@@ -226,3 +226,9 @@ struct IntPtrs { int* p[GVL_MAX_DECODE_BATCH]; int n; };
 int gvl_launch_inc_many(const IntPtrs& ptrs, hipStream_t st);
 int gvl_launch_inc(int* p, hipStream_t st);
 int gvl_launch_set_int(int* p, int v, hipStream_t st);
+
+// ---- frame pre-processing (gvl_pre.hip) -------------------------------------------------------------------------
+// frames uint8, layout 0 = [n][H][W][3] / 1 = [n][3][H][W] -> out f32 [n][3][size][size]; *scratch grows on demand (caller-owned).
+int gvl_launch_preprocess(const unsigned char* frames, int n, int H, int W, int layout, int size, const float* mean, const float* stdv, float* out,
+                          void** scratch, size_t* scratch_bytes, hipStream_t st);
+

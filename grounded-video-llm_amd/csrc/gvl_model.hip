@@ -73,6 +73,8 @@ struct gvl_ctx {
   // (all decode work buffers hold GVL_MAX_DECODE_BATCH rows: one per sequence of a batched decode step)
   float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_seq_tok = nullptr, *d_seq_out = nullptr, *d_ids = nullptr;
   int nsplit = 16, outlist_cap = 8192, ids_cap = 16384;
+  // frame pre-processing scratch (tmp image + tap tables), grown on demand
+  void* pre_scratch = nullptr; size_t pre_scratch_bytes = 0;
   // profiling
   bool prof = false; std::vector<ProfRec> recs;
   double prof_ms[GVL_PROF_NCAT] = {0}, prof_work[GVL_PROF_NCAT] = {0}; int64_t prof_n[GVL_PROF_NCAT] = {0};
@@ -499,7 +501,7 @@ int gvl_destroy(gvl_ctx* ctx) {
   if (!ctx) return 0;
   hipDeviceSynchronize();
   for (auto& kv : ctx->w) if (kv.second.p) hipFree(kv.second.p);
-  void* ptrs[] = {ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_out, ctx->d_ids, ctx->d_seq_tables, ctx->d_seq_pos};
+  void* ptrs[] = {ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_out, ctx->d_ids, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& r : ctx->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   delete ctx;
@@ -735,6 +737,18 @@ int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, voi
   int rc = decode_step(ctx, one, 1, st);
   if (rc) return rc;
   if (logits) HIPCHK(ctx, hipMemcpyAsync(logits, ctx->d_logits, (size_t)ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int gvl_preprocess_frames(gvl_ctx* ctx, const uint8_t* frames, int n, int height, int width, int layout, int size,
+                          const float* mean, const float* stdv, float* out, void* stream) {
+  if (!ctx) return GVL_ERR_ARG;
+  if (!frames || !out || !mean || !stdv || n <= 0 || height <= 0 || width <= 0 || size <= 0 || (layout != 0 && layout != 1))
+    return fail(ctx, GVL_ERR_ARG, "gvl_preprocess_frames: bad arguments");
+  for (int c = 0; c < 3; ++c) if (!(stdv[c] != 0.f)) return fail(ctx, GVL_ERR_ARG, "gvl_preprocess_frames: zero std");
+  const int rc = gvl_launch_preprocess(frames, n, height, width, layout, size, mean, stdv, out, &ctx->pre_scratch, &ctx->pre_scratch_bytes, (hipStream_t)stream);
+  if (rc == -2) return fail(ctx, GVL_ERR_OOM, "gvl_preprocess_frames: hipMalloc(scratch) failed");
+  if (rc) return fail(ctx, rc == -1 ? GVL_ERR_ARG : GVL_ERR_HIP, "gvl_preprocess_frames: launch failed");
   return 0;
 }
 

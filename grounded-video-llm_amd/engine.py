@@ -180,6 +180,20 @@ class Engine:
         self._chk(self.lib.gvl_encode_segments(self.ctx, _ptr(sp), _ptr(tp), n, _ptr(out), self.stream), "gvl_encode_segments")
         return out
 
+    def preprocess_frames(self, frames_u8: torch.Tensor, size: int, mean, std) -> torch.Tensor:
+        """frame_transform of the reference on the GPU (bit-exact to PIL bicubic + torchvision glue): uint8 frames [n,H,W,3]
+        (decoder order) or [n,3,H,W] -> f32 [n,3,size,size].  mm_utils/utils.py:153-183."""
+        assert frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4
+        if frames_u8.shape[-1] == 3 and frames_u8.shape[1] != 3:
+            layout, (n, H, W) = 0, (frames_u8.shape[0], frames_u8.shape[1], frames_u8.shape[2])
+        else:
+            layout, (n, H, W) = 1, (frames_u8.shape[0], frames_u8.shape[2], frames_u8.shape[3])
+        fr = frames_u8.to(self.device).contiguous()
+        out = torch.empty((n, 3, size, size), dtype=torch.float32, device=self.device)
+        m = (C.c_float * 3)(*[float(v) for v in mean]); s = (C.c_float * 3)(*[float(v) for v in std])
+        self._chk(self.lib.gvl_preprocess_frames(self.ctx, _ptr(fr), n, H, W, layout, int(size), m, s, _ptr(out), self.stream), "gvl_preprocess_frames")
+        return out
+
     # ---- LLM -------------------------------------------------------------------------------------
     def splice(self, input_ids: Sequence[int], visual: torch.Tensor) -> torch.Tensor:
         ids = (C.c_int64 * len(input_ids))(*[int(i) for i in input_ids])

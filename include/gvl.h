@@ -124,6 +124,16 @@ int gvl_decode_greedy_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, int ma
 /* teacher-forced single step (parity tests): appends token `tok`, returns logits f32 [vocab]. */
 int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, void* stream);
 
+/* ---- frame pre-processing ---------------------------------------------------- */
+/* frame_transform(image_size = size, mean, std) of the reference (mm_utils/utils.py:153-183, called per frame from
+ * inference.py:69-88) for n uint8 RGB frames of one video: torchvision Resize(size, BICUBIC) [shortest edge -> size;
+ * = PIL.Image.resize, Pillow Resample.c] -> CenterCrop(size) -> ToTensor -> Normalize, bit-exact to the CPU chain
+ * (8-bit two-pass fixed-point resampler; three IEEE f32 operations for ToTensor/Normalize).
+ * frames: device uint8, layout 0 = [n][H][W][3] (decoder order, mm_utils/video_utils.py:82) or 1 = [n][3][H][W]
+ * (after the reference's permute, :91); out: device f32 [n][3][size][size].  Needs no weights (any ctx). */
+int gvl_preprocess_frames(gvl_ctx* ctx, const uint8_t* frames, int n, int height, int width, int layout, int size,
+                          const float* mean, const float* std3, float* out, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* When enabled, every launch of a kernel family is bracketed by hipEvents on the caller's stream
  * (slow; bench.py uses it for ONE profiled step after the timed region). */

@@ -554,3 +554,128 @@ def frame_normalize(frames_u8: torch.Tensor, mean, std) -> torch.Tensor:
     m = torch.tensor(mean).view(1, 3, 1, 1)
     s = torch.tensor(std).view(1, 3, 1, 1)
     return (x - m) / s
+
+
+# --------------------------------------------------------------------------------------
+# frame pre-processing: frame_transform = ToPILImage -> Resize(S, BICUBIC) -> CenterCrop(S) -> ToTensor -> Normalize
+# (mm_utils/utils.py:153-183; call sites inference.py:69-88).  The arithmetic lives in two third-party packages that are NOT
+# under /root/reference: torchvision==0.16.2 (requirements.txt:18; size / crop rules, ToTensor, Normalize) and Pillow==11.1.0
+# (requirements.txt:13; Image.resize -> src/libImaging/Resample.c).  Both are restated here from their published algorithms.
+# PINNED against Pillow itself: oracle/make_golden.py ("pre") resizes seeded images with the Pillow installed in the build
+# container (12.2.0 -- the 8-bit two-pass resampler has been stable across these releases) and tests/golden/preprocess.npz holds
+# its outputs.  torchvision is absent here: its three integer rules (shortest-edge size, crop offsets with Python round(),
+# ToTensor /255) are "parity unpinned", restated from the 0.16.2 sources.
+# --------------------------------------------------------------------------------------
+PIL_PRECISION_BITS = 32 - 8 - 2      # Resample.c: #define PRECISION_BITS (32 - 8 - 2)
+
+
+def _pil_bicubic(x: float) -> float:
+    """Resample.c bicubic_filter, a = -0.5."""
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_resample_coeffs(in_size: int, out_size: int):
+    """Resample.c precompute_coeffs + normalize_coeffs_8bpc for the full-image box: (bounds [out,2] = (xmin, count), kk [out,ksize] int32).
+    Every operation is a separately rounded IEEE double operation, as in the C source compiled without FMA contraction."""
+    scale = float(in_size) / out_size
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 2.0 * filterscale                       # bicubic support = 2.0
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        w = [_pil_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        if ww != 0.0:
+            w = [v / ww for v in w]
+        for x, v in enumerate(w):
+            kk[xx, x] = int(-0.5 + v * (1 << PIL_PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << PIL_PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def _pil_pass(img: np.ndarray, bounds: np.ndarray, kk: np.ndarray, axis: int) -> np.ndarray:
+    """One 8-bit pass (ImagingResampleHorizontal_8bpc / Vertical_8bpc): int32 accumulator starting at 1 << (PRECISION_BITS - 1),
+    arithmetic shift, clip8.  img uint8 [H, W, C]."""
+    src = img.astype(np.int64)
+    n_out = bounds.shape[0]
+    shape = list(img.shape)
+    shape[axis] = n_out
+    out = np.empty(shape, np.uint8)
+    for o in range(n_out):
+        x0, n = int(bounds[o, 0]), int(bounds[o, 1])
+        k = kk[o, :n].astype(np.int64)
+        if axis == 1:
+            acc = (1 << (PIL_PRECISION_BITS - 1)) + (src[:, x0:x0 + n, :] * k[None, :, None]).sum(1)
+            out[:, o, :] = np.clip(acc >> PIL_PRECISION_BITS, 0, 255)
+        else:
+            acc = (1 << (PIL_PRECISION_BITS - 1)) + (src[x0:x0 + n, :, :] * k[:, None, None]).sum(0)
+            out[o, :, :] = np.clip(acc >> PIL_PRECISION_BITS, 0, 255)
+    return out
+
+
+def pil_resize_bicubic(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+    """PIL.Image.resize((out_w, out_h), BICUBIC) for an RGB uint8 image [H, W, 3] (Resample.c ImagingResampleInner: horizontal pass,
+    then vertical pass on its 8-bit result; a pass is skipped when the size does not change)."""
+    h, w = img.shape[:2]
+    out = img
+    if out_w != w:
+        out = _pil_pass(out, *pil_resample_coeffs(w, out_w), axis=1)
+    if out_h != h:
+        out = _pil_pass(out, *pil_resample_coeffs(h, out_h), axis=0)
+    return out
+
+
+def tv_resized_size(h: int, w: int, size: int) -> Tuple[int, int]:
+    """torchvision 0.16.2 transforms/functional.py _compute_resized_output_size for an int size (shortest edge -> size): (new_h, new_w)."""
+    short, long = (w, h) if w <= h else (h, w)
+    new_short, new_long = size, int(size * long / short)
+    return (new_long, new_short) if w <= h else (new_short, new_long)
+
+
+def tv_center_crop_offsets(h: int, w: int, size: int) -> Tuple[int, int]:
+    """torchvision 0.16.2 functional.center_crop: (top, left) = int(round((h - S) / 2.0)), int(round((w - S) / 2.0)) -- Python round()."""
+    return int(round((h - size) / 2.0)), int(round((w - size) / 2.0))
+
+
+def frame_transform(frame_chw_u8: np.ndarray, size: int, mean, std) -> np.ndarray:
+    """mm_utils/utils.py:153-183 for one uint8 frame [3, H, W] (as read_frames_decord hands it over, mm_utils/video_utils.py:91) ->
+    float32 [3, size, size].  ToTensor: uint8 -> float32, / 255; Normalize: (x - mean) / std, all in float32."""
+    img = np.ascontiguousarray(np.transpose(frame_chw_u8, (1, 2, 0)))          # ToPILImage: HWC RGB
+    h, w = img.shape[:2]
+    nh, nw = tv_resized_size(h, w, size)
+    if (nh, nw) != (h, w):
+        img = pil_resize_bicubic(img, nw, nh)
+    top, left = tv_center_crop_offsets(nh, nw, size)
+    img = img[top:top + size, left:left + size]
+    x = np.transpose(img, (2, 0, 1)).astype(np.float32) / np.float32(255)
+    m = np.asarray(mean, np.float32).reshape(3, 1, 1)
+    s = np.asarray(std, np.float32).reshape(3, 1, 1)
+    return (x - m) / s
+
+
+def synthetic_frame(name: str, h: int, w: int) -> np.ndarray:
+    """Seeded uint8 RGB test frame [h, w, 3] (smooth pattern + strong noise: exercises both the antialiasing taps and the clip8
+    saturation of the resampler).  Shared by oracle/make_golden.py and the tests so that fixtures hold outputs only."""
+    rs = np.random.RandomState(sum(map(ord, name)))
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([127 + 120 * np.sin(xx / 7.0 + c) * np.cos(yy / 11.0 - c) for c in range(3)], -1)
+    return np.clip(base + rs.randint(-90, 91, (h, w, 3)), 0, 255).astype(np.uint8)

@@ -265,8 +265,31 @@ def g_int(ns):
     print("wrote integer_paths.json")
 
 
+def g_pre(ns):
+    """Frame pre-processing goldens: PIL.Image.resize(BICUBIC) -- the library the reference's frame_transform calls
+    (mm_utils/utils.py:172-174 through torchvision) -- on seeded uint8 frames.  torchvision itself is not installed: the size / crop
+    rules around the resize are the oracle's restatement.  Stored: the resized + centre-cropped uint8 image per case."""
+    from PIL import Image
+    import gvl_oracle as O
+    cases = [("360p_224", 360, 640, 224), ("portrait_224", 400, 226, 224), ("up_336", 150, 200, 336), ("odd_224", 253, 381, 224),
+             ("square_224", 224, 224, 224), ("hd_224", 720, 1280, 224), ("tiny_32", 37, 51, 32)]
+    arrays, meta = {}, {}
+    for name, h, w, size in cases:
+        img = O.synthetic_frame(name, h, w)
+        nh, nw = O.tv_resized_size(h, w, size)
+        pil = Image.fromarray(img, mode="RGB")
+        if (nh, nw) != (h, w):
+            pil = pil.resize((nw, nh), Image.BICUBIC)
+        top, left = O.tv_center_crop_offsets(nh, nw, size)
+        out = np.asarray(pil)[top:top + size, left:left + size]
+        arrays[name] = out
+        meta[name] = dict(h=h, w=w, size=size)
+    import PIL
+    save("preprocess", dict(cases=meta, pillow=PIL.__version__), **arrays)
+
+
 if __name__ == "__main__":
-    ns = ref_shims.load_reference()
-    which = sys.argv[1:] or ["int", "clip", "iv2", "phi3", "llama", "glue"]
+    which = sys.argv[1:] or ["int", "clip", "iv2", "phi3", "llama", "glue", "pre"]
+    ns = ref_shims.load_reference() if any(w != "pre" for w in which) else None
     for w in which:
-        {"int": g_int, "clip": g_clip, "iv2": g_iv2, "phi3": g_phi3, "llama": g_llama, "glue": g_glue}[w](ns)
+        {"int": g_int, "clip": g_clip, "iv2": g_iv2, "phi3": g_phi3, "llama": g_llama, "glue": g_glue, "pre": g_pre}[w](ns)

@@ -162,3 +162,22 @@ def test_glue_phi35():
 
 def test_glue_llama3():
     _glue("glue_llama3")        # 2 segments x 193 tokens
+
+
+def test_preprocess_oracle_matches_pillow():
+    """the numpy restatement of Pillow's 8-bit two-pass bicubic resampler (+ torchvision's size / crop rules) must be
+    BIT-EXACT against the images Pillow itself produced (tests/golden/preprocess.npz, oracle/make_golden.py pre)."""
+    meta, g = load_golden("preprocess")
+    for name, c in meta["cases"].items():
+        img = O.synthetic_frame(name, c["h"], c["w"])
+        nh, nw = O.tv_resized_size(c["h"], c["w"], c["size"])
+        out = O.pil_resize_bicubic(img, nw, nh) if (nh, nw) != (c["h"], c["w"]) else img
+        top, left = O.tv_center_crop_offsets(nh, nw, c["size"])
+        out = out[top:top + c["size"], left:left + c["size"]]
+        assert out.shape == g[name].shape and np.array_equal(out, g[name]), f"{name}: {int((out != g[name]).sum())} bytes differ from Pillow"
+        x = O.frame_transform(np.transpose(img, (2, 0, 1)), c["size"], O.INTERNVIDEO_MEAN, O.INTERNVIDEO_STD)
+        ref = (np.transpose(g[name], (2, 0, 1)).astype(np.float32) / np.float32(255) - np.asarray(O.INTERNVIDEO_MEAN, np.float32).reshape(3, 1, 1)) / \
+            np.asarray(O.INTERNVIDEO_STD, np.float32).reshape(3, 1, 1)
+        assert x.dtype == np.float32 and np.array_equal(x, ref)
+    assert O.tv_resized_size(360, 640, 224) == (224, 398) and O.tv_resized_size(400, 226, 224) == (396, 224)
+    assert O.tv_center_crop_offsets(224, 398, 224) == (0, 87) and O.tv_center_crop_offsets(229, 224, 224) == (2, 0)   # round-half-even: 2.5 -> 2

@@ -78,32 +78,32 @@ struct PreArgs {
   float* out;                                              // [n][3][size][size]
 };
 
-// horizontal pass: one thread per (frame, source row, output column), all three channels
-__global__ __launch_bounds__(256) void pre_h_kernel(const PreArgs a) {
-  const long total = (long)a.n * a.R * a.size;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int ox = (int)(i % a.size);
-    const long t = i / a.size;
-    const int r = (int)(t % a.R), f = (int)(t / a.R);
-    const int y = a.r0 + r;
+// horizontal pass: one block per (frame, source row): the span of the row that the S output columns read is staged in LDS with
+// coalesced 4-byte loads (once), then one thread per output column runs its taps out of LDS for the three channels
+__global__ __launch_bounds__(256) void pre_h_kernel(const PreArgs a, int x_lo, int x_hi) {
+  extern __shared__ unsigned char srow[];           // [3][span] (planar) -- span = x_hi - x_lo source pixels
+  const int r = blockIdx.x % a.R, f = blockIdx.x / a.R;
+  const int y = a.r0 + r, span = x_hi - x_lo;
+  if (a.layout == 0) {
+    const unsigned char* p = a.src + (((size_t)f * a.H + y) * a.W + x_lo) * 3;      // interleaved RGB: de-interleave into planes
+    for (int i = threadIdx.x; i < span * 3; i += 256) { const int x = i / 3, c = i - 3 * x; srow[c * span + x] = p[i]; }
+  } else {
+    for (int c = 0; c < 3; ++c) {
+      const unsigned char* p = a.src + (((size_t)f * 3 + c) * a.H + y) * a.W + x_lo;
+      for (int i = threadIdx.x; i < span; i += 256) srow[c * span + i] = p[i];
+    }
+  }
+  __syncthreads();
+  for (int ox = threadIdx.x; ox < a.size; ox += 256) {
     int px[3];
     if (a.h_identity) {
-      const int x = a.left + ox;
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        px[c] = a.layout == 0 ? a.src[(((size_t)f * a.H + y) * a.W + x) * 3 + c] : a.src[(((size_t)f * 3 + c) * a.H + y) * a.W + x];
+      for (int c = 0; c < 3; ++c) px[c] = srow[c * span + a.left + ox - x_lo];
     } else {
-      const int xmin = a.hb[2 * ox], cnt = a.hb[2 * ox + 1];
+      const int xmin = a.hb[2 * ox] - x_lo, cnt = a.hb[2 * ox + 1];
       const int* k = a.hk + (size_t)ox * a.hks;
       int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
-      if (a.layout == 0) {
-        const unsigned char* p = a.src + (((size_t)f * a.H + y) * a.W + xmin) * 3;
-        for (int x = 0; x < cnt; ++x) { const int kv = k[x]; s0 += p[3 * x] * kv; s1 += p[3 * x + 1] * kv; s2 += p[3 * x + 2] * kv; }
-      } else {
-        const unsigned char* p0 = a.src + (((size_t)f * 3) * a.H + y) * a.W + xmin;
-        const size_t plane = (size_t)a.H * a.W;
-        for (int x = 0; x < cnt; ++x) { const int kv = k[x]; s0 += p0[x] * kv; s1 += p0[plane + x] * kv; s2 += p0[2 * plane + x] * kv; }
-      }
+      for (int x = 0; x < cnt; ++x) { const int kv = k[x]; s0 += srow[xmin + x] * kv; s1 += srow[span + xmin + x] * kv; s2 += srow[2 * span + xmin + x] * kv; }
       px[0] = clip8(s0); px[1] = clip8(s1); px[2] = clip8(s2);
     }
 #pragma unroll
@@ -111,8 +111,44 @@ __global__ __launch_bounds__(256) void pre_h_kernel(const PreArgs a) {
   }
 }
 
-// vertical pass + ToTensor + Normalize: one thread per output element
+// vertical pass + ToTensor + Normalize: one thread per 4 adjacent output columns (4-byte loads of the 8-bit intermediate)
 __global__ __launch_bounds__(256) void pre_v_kernel(const PreArgs a) {
+  const int q = a.size >> 2;                         // size % 4 == 0 on this path
+  const long total = (long)a.n * 3 * a.size * q;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ox = (int)(i % q) * 4;
+    long t = i / q;
+    const int oy = (int)(t % a.size); t /= a.size;
+    const int c = (int)(t % 3), f = (int)(t / 3);
+    const unsigned char* col = a.tmp + (((size_t)f * 3 + c) * a.R) * a.size + ox;
+    int u[4];
+    if (a.v_identity) {
+      const unsigned w = *(const unsigned*)(col + (size_t)(a.top + oy - a.r0) * a.size);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) u[e] = (w >> (8 * e)) & 255;
+    } else {
+      const int ymin = a.vb[2 * oy], cnt = a.vb[2 * oy + 1];
+      const int* k = a.vk + (size_t)oy * a.vks;
+      int s[4] = {1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1)};
+      for (int y = 0; y < cnt; ++y) {
+        const unsigned w = *(const unsigned*)(col + (size_t)(ymin + y - a.r0) * a.size);
+        const int kv = k[y];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += (int)((w >> (8 * e)) & 255) * kv;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) u[e] = clip8(s[e]);
+    }
+    // ToTensor: uint8 -> f32, / 255 ; Normalize: (x - mean) / std   (three separately rounded IEEE f32 operations, as torch does)
+    f32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)u[e], 255.0f), a.mean[c]), a.stdv[c]);
+    *(f32x4_t*)(a.out + ((((size_t)f * 3 + c) * a.size + oy) * a.size + ox)) = o;
+  }
+}
+
+// generic vertical pass (size % 4 != 0): one thread per output element
+__global__ __launch_bounds__(256) void pre_v1_kernel(const PreArgs a) {
   const long total = (long)a.n * 3 * a.size * a.size;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int ox = (int)(i % a.size);
@@ -130,11 +166,7 @@ __global__ __launch_bounds__(256) void pre_v_kernel(const PreArgs a) {
       for (int y = 0; y < cnt; ++y) s += col[(size_t)(ymin + y - a.r0) * a.size] * k[y];
       u = clip8(s);
     }
-    // ToTensor: uint8 -> f32, / 255 ; Normalize: (x - mean) / std   (three separately rounded IEEE f32 operations, as torch does)
-    float v = __fdiv_rn((float)u, 255.0f);
-    v = __fsub_rn(v, a.mean[c]);
-    v = __fdiv_rn(v, a.stdv[c]);
-    a.out[i] = v;
+    a.out[i] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)u, 255.0f), a.mean[c]), a.stdv[c]);
   }
 }
 
@@ -187,14 +219,22 @@ int gvl_launch_preprocess(const unsigned char* frames, int n, int H, int W, int 
   if (tab_ints && hipMemcpyAsync(tab, host.data(), tab_ints * 4, hipMemcpyHostToDevice, st) != hipSuccess) return -3;
   if (tab_ints && hipStreamSynchronize(st) != hipSuccess) return -3;   // `host` dies with this frame; a few KB, once per call
   {
-    const long total = (long)n * a.R * size;
-    int blocks = (int)((total + 255) / 256); if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(pre_h_kernel, dim3(blocks), dim3(256), 0, st, a);
+    // source span [x_lo, x_hi) read by the S output columns of a row
+    int x_lo = left, x_hi = left + size;
+    if (!a.h_identity) {
+      x_lo = hb[0]; x_hi = 0;
+      for (int i = 0; i < size; ++i) { if (hb[2 * i] < x_lo) x_lo = hb[2 * i]; if (hb[2 * i] + hb[2 * i + 1] > x_hi) x_hi = hb[2 * i] + hb[2 * i + 1]; }
+    }
+    const size_t lds = (size_t)(x_hi - x_lo) * 3;
+    if (lds > 64 * 1024) return -1;                                    // > 21 k source pixels per row: not a video frame
+    hipLaunchKernelGGL(pre_h_kernel, dim3((unsigned)(n * a.R)), dim3(256), lds, st, a, x_lo, x_hi);
   }
   {
-    const long total = (long)n * 3 * size * size;
+    const bool vec = (size & 3) == 0 && (((uintptr_t)out) & 15) == 0;
+    const long total = vec ? (long)n * 3 * size * (size >> 2) : (long)n * 3 * size * size;
     int blocks = (int)((total + 255) / 256); if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(pre_v_kernel, dim3(blocks), dim3(256), 0, st, a);
+    if (vec) hipLaunchKernelGGL(pre_v_kernel, dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(pre_v1_kernel, dim3(blocks), dim3(256), 0, st, a);
   }
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -739,9 +739,9 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
     // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_microbench*.txt):
     //  * cfg 82 = 256x256 ping-pong kernel: best whenever K is long enough to amortise its un-overlapped
     //    prologue/epilogue (one block / CU) and there are enough tiles;
-    //  * cfg 21 = 128x128, 2 blocks / CU: short K (CLIP's K = 1024) or few tiles.
+    //  * cfg 21 = 128x128, 2 blocks / CU: short K or few tiles (CLIP out / fc2: 112 tiles).
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    cfg = (a.K >= 1408 && t256 >= 128) ? 82 : 21;
+    cfg = (a.K >= 1024 && t256 >= 128) ? 82 : 21;   // CLIP qkv / fc1 (K = 1024, 336 / 448 tiles): 82 measured +8...17 % over 21
   }
   if ((cfg == 82 || cfg == 85) && ((size_t)a.N * a.K * 2 >= (1ull << 32) || (size_t)a.M * a.lda * 2 >= (1ull << 32))) cfg = 21;   // 32-bit DMA offsets
   const int epi = (a.act & 3) | ((a.out_f32 ? 1 : 0) << 2) | ((a.resid ? 1 : 0) << 3) | ((a.gamma ? 1 : 0) << 4) | ((a.bias ? 1 : 0) << 5);

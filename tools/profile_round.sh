@@ -1,3 +1,5 @@
+# Produces the committed profiles/ artefacts of a round on the GPU box: rocprofv3 kernel traces (default bench + serial mode),
+# separate FETCH_SIZE / WRITE_SIZE PMC passes, and the default bench JSON.  Run: gpurun -- bash tools/profile_round.sh
 R=$GRAFT_REPO_ROOT
 [ -z "$R" ] && R=/root/repo
 cd /tmp; export TMPDIR=/tmp

@@ -42,7 +42,8 @@ PEAK_HBM_GBS = 8000.0
 
 
 def build_engine(dev, frames_per_seg=8, max_segs=12, new_tokens=12, clips_per_step=1):
-    geo = E.TowerGeometry(llm="phi3.5", frames_per_seg=frames_per_seg, max_segs=max_segs, max_seq=4096, max_prefill=3712, kv_pages=64 * clips_per_step)
+    geo = E.TowerGeometry(llm="phi3.5", frames_per_seg=frames_per_seg, max_segs=max_segs, max_seq=4096, max_prefill=3712 * clips_per_step,
+                          kv_pages=64 * clips_per_step)
     geo.rope_short, geo.rope_long = synth.longrope_factors(96)
     eng = E.Engine(geo, dev)
     d = str(dev)
@@ -146,11 +147,17 @@ class Stepper:
         of them -- continuous batching) and launches the vision encode of the next `cps` clips beside them."""
         with torch.cuda.stream(self.sL):
             self.sL.wait_event(self.evV)
-            seqs, S = [], 0
+            embs = []
             for vis in self.vis_next:
                 vis.record_stream(self.sL)
-                seq, S = self.llm(vis)
-                seqs.append(seq)
+                embs.append(self.eng.splice(self.ids, vis))
+            S = embs[0].shape[0]
+            seqs = [self.eng.seq_alloc(S + self.new_tokens) for _ in embs]
+            if self.batch_prefill:
+                self.eng.prefill_batch(seqs, embs)       # the decoder GEMMs run over the rows of all clips of the step at once
+            else:
+                for seq, emb in zip(seqs, embs):
+                    self.eng.prefill(seq, emb)
         with torch.cuda.stream(self.sV):
             self.vis_next = [self.encode() for _ in range(self.cps)]
             self.evV.record(self.sV)
@@ -178,6 +185,7 @@ class Stepper:
         return out, S
 
     time_decode = False
+    batch_prefill = os.environ.get("GVL_BENCH_BATCH_PREFILL", "1") != "0"
     overlap = os.environ.get("GVL_BENCH_OVERLAP", "full")
 
 

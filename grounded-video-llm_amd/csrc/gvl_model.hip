@@ -281,36 +281,62 @@ int build_visual(gvl_ctx* ctx, const float* clip_feats, const bf16_t* iv2_feats,
   return 0;
 }
 
-// one decoder layer stack over S rows starting at position 0 (prefill)
-int llm_prefill(gvl_ctx* ctx, Seq& sq, const bf16_t* embeds, int S, hipStream_t st) {
+// one decoder layer stack over S rows starting at position 0 (prefill) for nb sequences of EQUAL length S together: the GEMMs see
+// nb*S rows (better tile fill: Phi's o / down projections have 168 tiles at S = 3519), attention / RoPE / KV writes stay per sequence
+// (qkv_post and the attention kernel take a [nb][pages] block table).  Row-wise arithmetic is unchanged, so the result per sequence
+// is bit-identical to nb separate prefills.
+struct IntList { int v[GVL_MAX_DECODE_BATCH * 64]; int n; };
+__global__ void fill_ints_kernel(int* dst, const IntList l) { for (int i = threadIdx.x; i < l.n; i += blockDim.x) dst[i] = l.v[i]; }
+
+int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embeds, int S, hipStream_t st) {
   const gvl_config& f = ctx->cfg;
   const int Hd = f.hidden, H = f.heads, KV = f.kv_heads, Dr = ctx->l_Dr, D = ctx->l_D, I = f.inter;
   const int qkvw = (H + 2 * KV) * Dr;
+  const int M = nb * S, P = (S + 63) / 64;
+  if (nb < 1 || nb > GVL_MAX_DECODE_BATCH || nb == 3 || (nb > 1 && nb * P > GVL_MAX_DECODE_BATCH * 64))
+    return fail(ctx, GVL_ERR_ARG, "llm_prefill: batch must be 1, 2 or 4 sequences (batched: <= 4096 tokens each)");
   const size_t mark = ctx->arena_l_off;
-  LALLOC(x, bf16_t, (size_t)S * Hd); LALLOC(h, bf16_t, (size_t)S * Hd); LALLOC(qkv, bf16_t, (size_t)S * qkvw);
-  LALLOC(att, bf16_t, (size_t)S * H * Dr); LALLOC(act, bf16_t, (size_t)S * I); LALLOC(Q, bf16_t, (size_t)H * S * D);
-  HIPCHK(ctx, hipMemcpyAsync(x, embeds, (size_t)S * Hd * 2, hipMemcpyDeviceToDevice, st));
+  LALLOC(x, bf16_t, (size_t)M * Hd); LALLOC(h, bf16_t, (size_t)M * Hd); LALLOC(qkv, bf16_t, (size_t)M * qkvw);
+  LALLOC(att, bf16_t, (size_t)M * H * Dr); LALLOC(act, bf16_t, (size_t)M * I); LALLOC(Q, bf16_t, (size_t)nb * H * S * D);
+  const int* table = sqs[0]->d_block_table;
+  int table_stride = sqs[0]->n_pages;
+  if (nb > 1) {   // [nb][P] page ids of the batch, written by a stream-ordered kernel (ids passed by value: no host buffer lifetime)
+    LALLOC(tb, int, (size_t)nb * P);
+    IntList l; l.n = nb * P;
+    for (int b = 0; b < nb; ++b) for (int p = 0; p < P; ++p) l.v[b * P + p] = sqs[b]->pages[p];
+    hipLaunchKernelGGL(fill_ints_kernel, dim3(1), dim3(256), 0, st, tb, l);
+    table = tb; table_stride = P;
+  }
+  for (int b = 0; b < nb; ++b) HIPCHK(ctx, hipMemcpyAsync(x + (size_t)b * S * Hd, embeds[b], (size_t)S * Hd * 2, hipMemcpyDeviceToDevice, st));
   const bool use_long = f.rope_orig_max_pos > 0 && S > f.rope_orig_max_pos && ctx->cos_l;
   const float* cs = use_long ? ctx->cos_l : ctx->cos_s; const float* sn = use_long ? ctx->sin_l : ctx->sin_s;
   for (int l = 0; l < f.layers; ++l) {
     const LlmLayerW& w = ctx->ll[l];
     bf16_t* Kt = ctx->kpool + (size_t)l * ctx->layer_stride; bf16_t* Vt = ctx->vpool + (size_t)l * ctx->layer_stride;
-    RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln1, h, S, Hd, f.rms_eps, st));
-    { GemmArgs g = gemm(h, Hd, w.qkvw, qkv, qkvw, S, qkvw, Hd); RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
-    { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv; q.ld = qkvw; q.Q = Q; q.Kt = Kt; q.Vt = Vt; q.block_table = sq.d_block_table; q.max_pages = sq.n_pages;
-      q.B = 1; q.S = S; q.H = H; q.KV = KV; q.Dr = Dr; q.D = D; q.mode = 2; q.cos = cs; q.sin = sn; q.pos0 = 0;
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln1, h, M, Hd, f.rms_eps, st));
+    { GemmArgs g = gemm(h, Hd, w.qkvw, qkv, qkvw, M, qkvw, Hd); RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv; q.ld = qkvw; q.Q = Q; q.Kt = Kt; q.Vt = Vt; q.block_table = table; q.max_pages = table_stride;
+      q.B = nb; q.S = S; q.H = H; q.KV = KV; q.Dr = Dr; q.D = D; q.mode = 2; q.cos = cs; q.sin = sn; q.pos0 = 0;
       RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
-    { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; a.O = att; a.block_table = sq.d_block_table; a.max_pages = sq.n_pages;
-      a.B = 1; a.H = H; a.KV = KV; a.S = S; a.D = D; a.Dout = Dr; a.scale = 1.0f / sqrtf((float)Dr); a.causal = 1;
+    { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; a.O = att; a.block_table = table; a.max_pages = table_stride;
+      a.B = nb; a.H = H; a.KV = KV; a.S = S; a.D = D; a.Dout = Dr; a.scale = 1.0f / sqrtf((float)Dr); a.causal = 1;
       RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
-    { GemmArgs g = gemm(att, H * Dr, w.ow, x, Hd, S, Hd, H * Dr); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
-    RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln2, h, S, Hd, f.rms_eps, st));
-    { GemmArgs g = gemm(h, Hd, w.guw, act, I, S, 2 * I, Hd); g.act = GVL_ACT_SILU_MUL; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
-    { GemmArgs g = gemm(act, I, w.downw, x, Hd, S, Hd, I); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    { GemmArgs g = gemm(att, H * Dr, w.ow, x, Hd, M, Hd, H * Dr); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln2, h, M, Hd, f.rms_eps, st));
+    { GemmArgs g = gemm(h, Hd, w.guw, act, I, M, 2 * I, Hd); g.act = GVL_ACT_SILU_MUL; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    { GemmArgs g = gemm(act, I, w.downw, x, Hd, M, Hd, I); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
   }
-  // last-row-only lm_head: final RMSNorm fused into the GEMV
+  // last-row-only lm_head: final RMSNorm fused into the GEMV; one weight stream for the nb last rows
   { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = ctx->l_headw; g.N = f.vocab; g.K = Hd; g.x = x + (size_t)(S - 1) * Hd; g.norm_w = ctx->l_norm; g.eps = f.rms_eps;
+    g.batch = nb; g.x_stride = S * Hd; g.out_stride = f.vocab;
     g.bias = ctx->l_headb; g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, gvl_launch_gemv(g, st)); }
+  { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = f.vocab; am.batch = nb;
+    for (int b = 0; b < nb; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.steps[b] = 0; }   // first generated token
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(am, st)); }
+  for (int b = 0; b < nb; ++b) {
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sqs[b]->d_pos, S, st));
+    sqs[b]->pos = S; sqs[b]->n_gen = 1;
+  }
   ctx->arena_l_off = mark;
   return 0;
 }
@@ -687,14 +713,37 @@ int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int S, float* 
   if (!embeds || S <= 0 || S > sq.max_tokens || S > ctx->cfg.max_prefill) return fail(ctx, GVL_ERR_ARG, "gvl_prefill: bad length");
   if (sq.pos != 0) return fail(ctx, GVL_ERR_STATE, "gvl_prefill: sequence already holds tokens");
   hipStream_t st = (hipStream_t)stream;
-  int rc = llm_prefill(ctx, sq, embeds, S, st);
+  Seq* one[1] = {&sq}; const bf16_t* e1[1] = {embeds};
+  int rc = llm_prefill(ctx, one, 1, e1, S, st);
   if (rc) return rc;
   if (last_logits) HIPCHK(ctx, hipMemcpyAsync(last_logits, ctx->d_logits, (size_t)ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
-  { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = ctx->cfg.vocab; am.batch = 1;
-    am.tok_ptrs[0] = sq.d_tok; am.out_lists[0] = sq.d_out; am.steps[0] = 0;      // first generated token = argmax of the prefill logits
-    RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(am, st)); }
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sq.d_pos, S, st));
-  sq.pos = S; sq.n_gen = 1;
+  return 0;
+}
+
+int gvl_prefill_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, const uint16_t* const* embeds, int S, void* stream) {
+  REQUIRE_READY(ctx->has_llm, "gvl_prefill_batch");
+  if (!seq_ids || !embeds || n_seqs <= 0 || n_seqs > gvl_ctx::kMaxSeqs || S <= 0) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_batch: bad arguments");
+  for (int i = 0; i < n_seqs; ++i) {
+    const int id = seq_ids[i];
+    if (id < 0 || id >= (int)ctx->seqs.size() || !ctx->seqs[id].used || !embeds[i]) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_batch: bad seq / embeds");
+    if (S > ctx->seqs[id].max_tokens) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_batch: bad length");
+    if (ctx->seqs[id].pos != 0) return fail(ctx, GVL_ERR_STATE, "gvl_prefill_batch: sequence already holds tokens");
+    for (int j = 0; j < i; ++j) if (seq_ids[j] == id) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_batch: duplicate seq");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  // groups of 4, 2, 1 sequences -- as many as the prefill workspace (cfg.max_prefill rows) and the 64-page table limit allow
+  int i = 0;
+  while (i < n_seqs) {
+    const int left = n_seqs - i;
+    int B = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+    while (B > 1 && ((long)B * S > ctx->cfg.max_prefill || B * ((S + 63) / 64) > GVL_MAX_DECODE_BATCH * 64)) B >>= 1;
+    if (S > ctx->cfg.max_prefill) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_batch: seq_len exceeds cfg.max_prefill");
+    Seq* sqs[GVL_MAX_DECODE_BATCH]; const bf16_t* es[GVL_MAX_DECODE_BATCH];
+    for (int b = 0; b < B; ++b) { sqs[b] = &ctx->seqs[seq_ids[i + b]]; es[b] = embeds[i + b]; }
+    const int rc = llm_prefill(ctx, sqs, B, es, S, st);
+    if (rc) return rc;
+    i += B;
+  }
   return 0;
 }
 

@@ -225,6 +225,16 @@ class Engine:
                   "gvl_decode_greedy")
         return [int(buf[i]) for i in range(n.value)]
 
+    def prefill_batch(self, seqs: Sequence[int], embeds: Sequence[torch.Tensor]) -> None:
+        """Prefill several sequences of EQUAL length together (one pass of the decoder GEMMs over all their rows)."""
+        es = [e.contiguous() for e in embeds]
+        S = es[0].shape[0]
+        assert all(e.shape[0] == S for e in es), "prefill_batch needs equal lengths (use prefill per sequence otherwise)"
+        n = len(seqs)
+        ids = (C.c_int * n)(*[int(s) for s in seqs])
+        ptrs = (C.c_void_p * n)(*[e.data_ptr() for e in es])
+        self._chk(self.lib.gvl_prefill_batch(self.ctx, ids, n, ptrs, int(S), self.stream), "gvl_prefill_batch")
+
     def decode_greedy_batch(self, seqs: Sequence[int], max_new: int, eos_id: Optional[int]) -> List[List[int]]:
         """Greedy decode of several freshly prefilled sequences together (weights streamed once per step per group of 4/2/1)."""
         n = len(seqs)

@@ -52,6 +52,7 @@ _SIGS = {
     "gvl_prefill": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gvl_decode_greedy": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.c_void_p]),
     "gvl_preprocess_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
+    "gvl_prefill_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "gvl_decode_greedy_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.c_void_p]),
     "gvl_decode_step_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gvl_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -114,6 +114,11 @@ int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int seq_len, f
                 void* stream);
 int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t* out_ids_host,
                       int* n_out, void* stream);
+/* Prefill of n_seqs sequences of EQUAL length seq_len together (groups of 4 / 2 / 1 that fit cfg.max_prefill rows): the decoder
+ * GEMMs run over all rows of a group at once (better tile fill), attention / RoPE / KV writes stay per sequence on its own pages;
+ * per sequence bit-identical to gvl_prefill.  embeds: host array of n_seqs device pointers (bf16 [seq_len, hidden] each). */
+int gvl_prefill_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, const uint16_t* const* embeds, int seq_len,
+                      void* stream);
 /* Batched greedy decode of n_seqs freshly prefilled sequences (the reference batches clips in generate() with
  * left padding, llava_next_video.py:622-647 -- here every sequence keeps its own pages and length, no padding).  Groups of
  * 4 / 2 / 1 sequences advance together: every weight matrix is streamed ONCE per step for the whole group, so the HBM cost per

@@ -198,3 +198,31 @@ def test_decode_batch_is_bit_identical_to_single(which):
         cut = ref.index(eos) + 1 if eos in ref else new
         assert ids == ref[:cut]
     eng.close()
+
+
+@pytest.mark.parametrize("which", ["phi3_tiny", "llama_tiny"])
+def test_prefill_batch_is_bit_identical_to_single(which):
+    """gvl_prefill_batch: equal-length sequences prefilled TOGETHER (decoder GEMMs over all their rows, attention per sequence on its
+    own pages) must leave every sequence in exactly the state of its own gvl_prefill: same first token, same continuation."""
+    meta, g = load_golden(which)
+    c = meta["cfg"]
+    if which == "phi3_tiny":
+        geo = _phi_geo(c)
+        W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
+    else:
+        geo = tiny_geo(llm="llama3", hidden=c["hidden"], inter=c["inter"], layers=c["layers"], heads=c["heads"], kv_heads=c["kv_heads"], vocab=c["vocab"],
+                       rope_theta=c["rope_theta"], rope_orig_max_pos=0)
+        W = synth.llm_weights("llama", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
+    eng = llm_engine(geo, W)
+    new = 10
+    for S in (7, 64, 61):                                     # below / exactly / just under one 64-token page
+        xs = [synth.det_tensor(f"pbatch.{which}.{S}.{i}", (S, c["hidden"]), 0.5).to(DEV).to(bf) for i in range(4)]
+        single = [eng.generate_ids(x, new, None) for x in xs]
+        for n in (2, 3, 4):
+            seqs = [eng.seq_alloc(S + new) for _ in range(n)]
+            eng.prefill_batch(seqs, xs[:n])
+            got = eng.decode_greedy_batch(seqs, new, None)
+            for s in seqs:
+                eng.seq_free(s)
+            assert got == single[:n], f"{which} S={S}: prefill_batch({n}) + batched decode differs from the single-sequence path"
+    eng.close()

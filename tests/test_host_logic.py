@@ -125,3 +125,50 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "gvl_oracle" not in src and "oracle/" not in src.replace("the oracle", ""), f"{f} references the oracle"
+
+
+@pytest.mark.parametrize("llm", ["phi3.5", "llama3"])
+def test_reference_checkpoint_layout_roundtrip(tmp_path, llm):
+    """SURVEY §8 f3 (real-checkpoint tooling): a directory laid out like the reference's weights (models/llava_next_video.py:117-151:
+    vision_model.pth, image_newline(s).pth, multi_modal_projector.pth, language_model_seperated/*.safetensors, InternVideo2 .pt) plus an
+    inference.py-style fine-tuned ckpt overlay (:156-162) must load and pack to exactly the tensors the in-memory state dicts give."""
+    from safetensors.torch import save_file
+    from grounded_video_llm_amd import model as M, synth, weights as Wt
+    kind = "phi3" if llm == "phi3.5" else "llama"
+    hid, vocab, kvh = 64, 128, 4 if llm == "phi3.5" else 2
+    sd = {"vision_tower": synth.clip_weights(64, 128, 3, seed="ck.clip"), "video_encoder": synth.iv2_weights(64, 128, 3, 2, seed="ck.iv2"),
+          "projectors": synth.projector_weights(llm, hid, 64, 64, seed="ck.proj"),
+          "language_model": synth.llm_weights(kind, hid, 128, 2, 4, kvh, vocab, True, seed="ck.llm")}
+    d = tmp_path / "Phi-3.5-vision-instruct-seperated"
+    (d / "language_model_seperated").mkdir(parents=True)
+    torch.save(sd["vision_tower"], d / "vision_model.pth")
+    torch.save({k.split(".", 1)[1]: v for k, v in sd["projectors"].items() if k.startswith("multi_modal_projector.")}, d / "multi_modal_projector.pth")
+    if llm == "phi3.5":
+        torch.save({"glb_GN": sd["projectors"]["glb_GN"], "sub_GN": sd["projectors"]["sub_GN"]}, d / "image_newlines.pth")
+    else:
+        torch.save({"image_newline": sd["projectors"]["image_newline"]}, d / "image_newline.pth")
+    lm = {k: v.contiguous() for k, v in sd["language_model"].items()}
+    keys = sorted(lm)
+    save_file({k: lm[k] for k in keys[: len(keys) // 2]}, str(d / "language_model_seperated" / "model-00001-of-00002.safetensors"))
+    save_file({k: lm[k] for k in keys[len(keys) // 2:]}, str(d / "language_model_seperated" / "model-00002-of-00002.safetensors"))
+    iv2_path = tmp_path / "vision-encoder-InternVideo2.pt"
+    torch.save(sd["video_encoder"], iv2_path)
+    base = M.load_reference_checkpoints(llm, str(iv2_path), str(d))
+    # the video projector is a trained group: absent from the base directory (zeros until the fine-tuned ckpt arrives, inference.py:159-160)
+    assert torch.count_nonzero(base["projectors"]["video_projecter.up_proj.weight"]) == 0
+    ckpt = {"video_projecter": {k.split(".", 1)[1]: v for k, v in sd["projectors"].items() if k.startswith("video_projecter.")},
+            "multi_modal_projector": {k.split(".", 1)[1]: v for k, v in sd["projectors"].items() if k.startswith("multi_modal_projector.")}}
+    proj = dict(base["projectors"])
+    for grp in ("multi_modal_projector", "video_projecter"):
+        for k, v in ckpt[grp].items():
+            proj[f"{grp}.{k}"] = v
+    for name, a, b in (("clip", Wt.pack_clip(base["vision_tower"], 2), Wt.pack_clip(sd["vision_tower"], 2)),
+                       ("iv2", Wt.pack_iv2(base["video_encoder"], 2, 2), Wt.pack_iv2(sd["video_encoder"], 2, 2)),
+                       ("proj", Wt.pack_projectors(proj, llm), Wt.pack_projectors(sd["projectors"], llm)),
+                       ("llm", Wt.pack_llm(base["language_model"], kind, 2, 4, kvh, 256, 10000.0, None, None),
+                        Wt.pack_llm(sd["language_model"], kind, 2, 4, kvh, 256, 10000.0, None, None))):
+        assert set(a) == set(b), name
+        for k in a:
+            assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), f"{name}:{k}"
+    with pytest.raises(FileNotFoundError):
+        M.load_reference_checkpoints(llm, str(tmp_path / "missing.pt"), str(d))

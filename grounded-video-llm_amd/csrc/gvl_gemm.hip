@@ -28,6 +28,26 @@
 // Epilogue.  EPI >= 0 encodes the flag set at compile time (act | out_f32<<2 | resid<<3 | gamma<<4 | bias<<5) so the
 // hot instantiations carry no per-element branching; EPI = -1 reads the flags at run time (tests, rare shapes).
 // A lane owns row m = ..+(lane&31) and, per 32x32 block, four groups of 4 consecutive columns n = ..+8*b+4*h.
+// ---- erf-GELU by table --------------------------------------------------------------------------------------------------
+// The GELU input is ALREADY rounded to bf16 (reference: nn.GELU on a bf16 tensor), so gelu(x) = x * Phi(x) needs Phi only at
+// bf16 points.  Phi(x) in f32 is tabulated for 2^-12 <= |x| <= 5.5 (1841 bf16 values per sign, 2 x 8 KiB, built on the host
+// in double precision); below 2^-12 Phi is 0.5 to 2e-4 relative, above 5.5 it is 1 (resp. < 2e-8) in f32 -- both ends clamp.
+// 7 full-rate VALU + one ds_read_b32 per element instead of ~16 issue slots with v_rcp + v_exp: the epilogue of
+// InternVideo2's fc1 tile drops from ~16 k to ~7 k cycles (tools/gemm_one.py, GVL_GEMM_TIMING=1).
+constexpr int GELU_LO = 0x3980, GELU_HI = 0x40B0, GELU_NE = GELU_HI - GELU_LO + 1;
+constexpr int GELU_NEG_OFF = 0x2000;               // byte offset of the negative half = sign << 13: no select needed
+constexpr int GELU_TAB_BYTES = 2 * GELU_NEG_OFF;
+static_assert(GELU_NE * 4 <= GELU_NEG_OFF, "positive half overlaps the negative half");
+// The same table read from GLOBAL memory (L1/L2 resident, 16 KiB): used by the 128x128 kernel and the generic epilogue, so that a
+// row gets the same value whichever kernel the launch planner hands it to (batch-invariance is asserted at full size).
+__device__ __forceinline__ float gelu_tab_global(const float* __restrict__ tab, float v) {
+  const unsigned bits = __float_as_uint(rbf(v)) >> 16;
+  int key = (int)(bits & 0x7fffu);
+  key = key < GELU_LO ? GELU_LO : (key > GELU_HI ? GELU_HI : key);
+  const int idx = (key - GELU_LO) + ((bits >> 15) ? GELU_NEG_OFF / 4 : 0);
+  return __uint_as_float(bits << 16) * tab[idx];
+}
+
 template <int TM, int TN, int MB, int NB, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16_t (&acc)[NB][MB], int m0, int n0, int wm, int wn, int l31, int h) {
   const int act = EPI >= 0 ? (EPI & 3) : a.act;
@@ -71,7 +91,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16_t (&acc)
           for (int e = 0; e < 4; ++e) { const float x = rbf(v[e]); v[e] = x * rbf(fast_sigmoid(rbf(1.702f * x))); }
         } else if (act == GVL_ACT_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(rbf(v[e]));
+          for (int e = 0; e < 4; ++e) v[e] = gelu_tab_global(a.act_table, v[e]);
         }
         if (has_gamma) {
           const f32x4_t gv = *(const f32x4_t*)(a.gamma + n);
@@ -110,16 +130,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16_t (&acc)
 // residual pieces are requested up front into registers, so a tile pays one memory round trip instead of one per piece
 // (hipcc serialises `load; s_waitcnt; use` chains inside the unrolled loops: measured 20-39 k cycles per tile before).
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// ---- erf-GELU by table (ping-pong kernel) -------------------------------------------------------------------------------
-// The GELU input is ALREADY rounded to bf16 (reference: nn.GELU on a bf16 tensor), so gelu(x) = x * Phi(x) needs Phi only at
-// bf16 points.  Phi(x) in f32 is tabulated for 2^-12 <= |x| <= 5.5 (1841 bf16 values per sign, 2 x 8 KiB, built on the host
-// in double precision); below 2^-12 Phi is 0.5 to 2e-4 relative, above 5.5 it is 1 (resp. < 2e-8) in f32 -- both ends clamp.
-// 7 full-rate VALU + one ds_read_b32 per element instead of ~16 issue slots with v_rcp + v_exp: the epilogue of
-// InternVideo2's fc1 tile drops from ~16 k to ~7 k cycles (tools/gemm_one.py, GVL_GEMM_TIMING=1).
-constexpr int GELU_LO = 0x3980, GELU_HI = 0x40B0, GELU_NE = GELU_HI - GELU_LO + 1;
-constexpr int GELU_NEG_OFF = 0x2000;               // byte offset of the negative half = sign << 13: no select needed
-constexpr int GELU_TAB_BYTES = 2 * GELU_NEG_OFF;
-static_assert(GELU_NE * 4 <= GELU_NEG_OFF, "positive half overlaps the negative half");
 // HI = 0: bf16 pattern in bits 0..15 of p; HI = 1: in bits 16..31.  Returns the LDS byte address of Phi(x); tab_adj is the
 // table's LDS address minus GELU_LO * 4 (uniform).  Five VALU ops, spelled out because hipcc's own selection needs seven.
 template <int HI>
@@ -272,7 +282,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x16_t
           for (int e = 0; e < 4; ++e) { const float x = rbf(v[e]); v[e] = x * rbf(fast_sigmoid(rbf(1.702f * x))); }
         } else if (act == GVL_ACT_GELU && TABLE == 0) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(rbf(v[e]));
+          for (int e = 0; e < 4; ++e) v[e] = gelu_tab_global(a.act_table, v[e]);
         }
         if (has_gamma) {
           const f32x4_t gv = gv4[b];
@@ -675,7 +685,6 @@ static int launch_pp(const GemmArgs& a_in, hipStream_t st) {
     attr_set = true;
   }
   GemmArgs a = a_in;
-  if constexpr (TAB) { a.act_table = gelu_table_device(); if (!a.act_table) return -3; }
   const int tiles_m = (a.M - a.m_begin + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const int tiles = tiles_m * tiles_n;
   static const bool no_persist = getenv("GVL_GEMM_NO_PERSIST") != nullptr;                // A/B only
@@ -728,8 +737,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t st) {
 
 double gvl_gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K; }
 
-int gvl_launch_gemm(const GemmArgs& a, hipStream_t st) {
+int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
+  GemmArgs a = a_in;
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return -1;
+  if (a.act == GVL_ACT_GELU && !a.act_table) { a.act_table = gelu_table_device(); if (!a.act_table) return -3; }   // every erf-GELU epilogue reads Phi from the table
   if (a.K % BK != 0 || a.N % 4 != 0 || a.lda % 8 != 0) return -1;   // K padded to 64 by the packer; 16-byte rows
   if (a.act == GVL_ACT_SILU_MUL && (a.out_f32 || a.resid || a.gamma)) return -1;
   int cfg = a.tile_cfg;

@@ -25,17 +25,6 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
 __device__ __forceinline__ float rbf(float f) { return (float)(__bf16)f; }  // round through bf16
 // fast transcendental helpers for epilogues (errors << bf16 resolution)
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float fast_erf(float x) {   // Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float r = 1.f - p * t * __expf(-ax * ax);
-  return copysignf(r, x);
-}
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + fast_erf(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float lo_bf(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_bf(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 

@@ -56,3 +56,39 @@ def test_llm_batched_paths_equal_single_at_full_size(full):
     for s in seqs:
         eng.seq_free(s)
     assert got == single, f"batched prefill + decode {got} != single {single}"
+
+
+def test_decode_step_matches_prefill_at_full_context(full):
+    """The paged-KV decode path (GEMV + split-KV decode attention + fused RoPE/append) against the prefill path (MFMA GEMM + flash
+    attention) at the BASELINE context (3519 tokens): logits of `prefill(S) ; decode(tok)` vs `prefill(S + 1 rows)` -- two different
+    kernel families computing the same function, bf16 class tolerance 1e-2 of the logit scale (north_star), same argmax."""
+    eng, geo = full
+    dev = torch.device(DEV)
+    sp, tp, ids = bench.make_inputs(dev, 0)
+    vis = eng.encode_segments(sp, tp)
+    tok = 1234
+    emb = eng.splice(ids, vis)
+    emb1 = eng.splice(list(ids) + [tok], vis)
+    assert emb1.shape[0] == emb.shape[0] + 1 and torch.equal(emb1[:-1], emb)
+    s1 = eng.seq_alloc(emb1.shape[0] + 2)
+    ref = eng.prefill(s1, emb1, want_logits=True).clone()
+    eng.seq_free(s1)
+    s0 = eng.seq_alloc(emb.shape[0] + 2)
+    eng.prefill(s0, emb)
+    got = eng.decode_step_logits(s0, tok)
+    eng.seq_free(s0)
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max()) / scale
+    # noise floor of THIS (random-init, 32-layer) network: the same prefill with every embedding element moved by at most one bf16 ulp
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    flip = (torch.randint(0, 2, emb1.shape, device=dev, generator=g) * 2 - 1).to(torch.float32)
+    emb_p = (emb1.float() * (1.0 + flip * 2.0 ** -7)).to(torch.bfloat16)     # ~1 ulp
+    s2 = eng.seq_alloc(emb1.shape[0] + 2)
+    pert = eng.prefill(s2, emb_p, want_logits=True).clone()
+    eng.seq_free(s2)
+    floor = float((pert - ref).abs().max()) / scale
+    print(f"[parity] full-size decode-vs-prefill logits rel err {err:.2e}; 1-ulp input perturbation moves the logits by {floor:.2e} (scale {scale:.2f})")
+    assert err < max(1e-2, 2.0 * floor), "decode path disagrees with the prefill path by more than the network's own bf16 noise"
+    top2 = torch.topk(ref, 2).values
+    if float(top2[0] - top2[1]) > 2e-2 * scale:
+        assert int(got.argmax()) == int(ref.argmax())

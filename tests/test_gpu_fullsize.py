@@ -92,3 +92,26 @@ def test_decode_step_matches_prefill_at_full_context(full):
     top2 = torch.topk(ref, 2).values
     if float(top2[0] - top2[1]) > 2e-2 * scale:
         assert int(got.argmax()) == int(ref.argmax())
+
+
+def test_llama3_8b_batched_paths_equal_single_at_full_size():
+    """BASELINE configs[3] (Llama-3-8B: GQA 32/8 heads of 128, separate q/k/v packed into one projection, plain RoPE) at its real size:
+    batched prefill + batched decode must reproduce the one-at-a-time ids; LLM only (synthetic visual prefix of the C3 length)."""
+    from grounded_video_llm_amd import engine as E, synth, weights as Wt
+    geo = E.TowerGeometry.llama3_8b(max_seq=4096, max_prefill=2 * 2432, kv_pages=80, max_segs=1)
+    eng = E.Engine(geo, DEV, towers=("llm",))
+    W = synth.llm_weights("llama", geo.hidden, geo.inter, geo.layers, geo.heads, geo.kv_heads, geo.vocab, True, seed="full.llama", device=DEV)
+    eng.load_packed(Wt.pack_llm(W, "llama", geo.layers, geo.heads, geo.kv_heads, geo.max_seq, geo.rope_theta, None, None)); del W
+    torch.cuda.empty_cache()
+    eng.finalize()
+    S, new = 2416, 6                                        # 12 x 193 visual tokens + ~100 text tokens (SURVEY §8 a12)
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    embs = [(torch.randn((S, geo.hidden), device=DEV, generator=g) * 0.5).to(torch.bfloat16) for _ in range(2)]
+    single = [eng.generate_ids(e, new, None) for e in embs]
+    seqs = [eng.seq_alloc(S + new) for _ in embs]
+    eng.prefill_batch(seqs, embs)
+    got = eng.decode_greedy_batch(seqs, new, None)
+    for s in seqs:
+        eng.seq_free(s)
+    eng.close()
+    assert got == single and single[0] != single[1]

@@ -758,7 +758,7 @@ int gvl_decode_greedy_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, int ma
   for (int i = 0; i < n_seqs; ++i) {
     const int id = seq_ids[i];
     if (id < 0 || id >= (int)ctx->seqs.size() || !ctx->seqs[id].used) return fail(ctx, GVL_ERR_ARG, "gvl_decode_greedy_batch: bad seq");
-    if (ctx->seqs[id].n_gen != 1) return fail(ctx, GVL_ERR_STATE, "gvl_decode_greedy_batch: every sequence must be freshly prefilled (gvl_prefill)");
+    if (ctx->seqs[id].n_gen < 1) return fail(ctx, GVL_ERR_STATE, "gvl_decode_greedy: call gvl_prefill first");   // members of a group must also be at the SAME step (checked per group)
     for (int j = 0; j < i; ++j) if (seq_ids[j] == id) return fail(ctx, GVL_ERR_ARG, "gvl_decode_greedy_batch: duplicate seq");
   }
   hipStream_t st = (hipStream_t)stream;

@@ -240,17 +240,36 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
   const int nq = a.H * cpr, nk = a.KV * cpr;
 
   float q_rs = 1.f, k_rs = 1.f;
-  if (a.mode == 1) {                                // full-width RMS statistics (WPR == 1: one wave owns the row)
+  // mode 1 (WPR == 1: one wave owns the row): the row's q and k chunks (<= 3 per lane each, i.e. rows up to 1536 wide) are
+  // requested up front and stay in registers between the full-width RMS statistics and the transform -- one pass over the row
+  constexpr int RC = 3;
+  u32x4_t qreg[RC], kreg[RC];
+  const bool in_regs = WPR == 1 && a.mode == 1 && nq <= RC * 64 && nk <= RC * 64;
+  if (a.mode == 1) {
     float sq = 0.f, sk = 0.f;
-    for (int c = lane; c < nq; c += 64) {
-      const u32x4_t v = *(const u32x4_t*)(qr + c * 8);
+    if (in_regs) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float x = lo_bf(v[e]), y = hi_bf(v[e]); sq += x * x + y * y; }
-    }
-    for (int c = lane; c < nk; c += 64) {
-      const u32x4_t v = *(const u32x4_t*)(kr + c * 8);
+      for (int i = 0; i < RC; ++i) { const int c = lane + 64 * i; qreg[i] = c < nq ? *(const u32x4_t*)(qr + c * 8) : u32x4_t{0u, 0u, 0u, 0u}; }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float x = lo_bf(v[e]), y = hi_bf(v[e]); sk += x * x + y * y; }
+      for (int i = 0; i < RC; ++i) { const int c = lane + 64 * i; kreg[i] = c < nk ? *(const u32x4_t*)(kr + c * 8) : u32x4_t{0u, 0u, 0u, 0u}; }
+#pragma unroll
+      for (int i = 0; i < RC; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = lo_bf(qreg[i][e]), y = hi_bf(qreg[i][e]); sq += x * x + y * y;
+          const float u = lo_bf(kreg[i][e]), w = hi_bf(kreg[i][e]); sk += u * u + w * w;
+        }
+    } else {
+      for (int c = lane; c < nq; c += 64) {
+        const u32x4_t v = *(const u32x4_t*)(qr + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float x = lo_bf(v[e]), y = hi_bf(v[e]); sq += x * x + y * y; }
+      }
+      for (int c = lane; c < nk; c += 64) {
+        const u32x4_t v = *(const u32x4_t*)(kr + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float x = lo_bf(v[e]), y = hi_bf(v[e]); sk += x * x + y * y; }
+      }
     }
     q_rs = rsqrtf(wave_sum(sq) / (a.H * a.Dr) + a.eps);
     k_rs = rsqrtf(wave_sum(sk) / (a.KV * a.Dr) + a.eps);
@@ -292,17 +311,33 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
     return o;
   };
   const u32x4_t zero = {0u, 0u, 0u, 0u};
+  auto norm_chunk = [&](const u32x4_t& v, int c, float rs, const bf16_t* nw) -> u32x4_t {   // mode 1 on an already loaded chunk
+    const u32x4_t w = *(const u32x4_t*)(nw + c * 8);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2bf(lo_bf(w[e]) * rbf(lo_bf(v[e]) * rs), hi_bf(w[e]) * rbf(hi_bf(v[e]) * rs));
+    return o;
+  };
   // Q [B][H][S][D]
   bf16_t* Qb = a.Q + ((size_t)b * a.H * a.S + s_in) * a.D;
-  for (int c = lt; c < nq; c += TEAM) {
-    const int hd = c / cpr, dc = c - hd * cpr;
-    *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + dc * 8) = xform(qr, c, q_rs, a.qn);
-  }
   // K page row [page][KV][64][D]
   bf16_t* Kb = a.Kt + ((size_t)page * a.KV) * (64 * a.D) + (size_t)slot * a.D;
-  for (int c = lt; c < nk; c += TEAM) {
-    const int hd = c / cpr, dc = c - hd * cpr;
-    *(u32x4_t*)(Kb + (size_t)hd * (64 * a.D) + dc * 8) = xform(kr, c, k_rs, a.kn);
+  if (in_regs) {
+#pragma unroll
+    for (int i = 0; i < RC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nq) { const int hd = c / cpr, dc = c - hd * cpr; *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + dc * 8) = norm_chunk(qreg[i], c, q_rs, a.qn); }
+      if (c < nk) { const int hd = c / cpr, dc = c - hd * cpr; *(u32x4_t*)(Kb + (size_t)hd * (64 * a.D) + dc * 8) = norm_chunk(kreg[i], c, k_rs, a.kn); }
+    }
+  } else {
+    for (int c = lt; c < nq; c += TEAM) {
+      const int hd = c / cpr, dc = c - hd * cpr;
+      *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + dc * 8) = xform(qr, c, q_rs, a.qn);
+    }
+    for (int c = lt; c < nk; c += TEAM) {
+      const int hd = c / cpr, dc = c - hd * cpr;
+      *(u32x4_t*)(Kb + (size_t)hd * (64 * a.D) + dc * 8) = xform(kr, c, k_rs, a.kn);
+    }
   }
   if (cpd > cpr) {                                   // zero the head-dim padding (88 -> 96)
     const int np = cpd - cpr;
@@ -319,9 +354,10 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
   }
 }
 
-// V rows of one 64-token tile -> V^T page [KV][D][64] through LDS (tokens >= S and d >= Dr are zero filled)
+// V rows of one 64-token tile -> V^T page [KV][D][64] through LDS (tokens >= S and d >= Dr are zero filled).
+// 16-byte global accesses both ways: 8 head-dim elements of a token in, 8 consecutive tokens of one head-dim row out.
 __global__ __launch_bounds__(256) void v_transpose_kernel(const QkvPostArgs a) {
-  __shared__ bf16_t tile[64][130];
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][136];          // 272-byte rows (16-byte aligned, bank-staggered)
   const int t = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x;
   const int s0 = a.pos0 + t * 64;                       // first token (sequence space) of this tile; pos0 is a multiple of 64
@@ -329,21 +365,24 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const QkvPostArgs a) {
   const int tile_idx = s0 >> 6;
   const int page = a.block_table ? a.block_table[b * a.max_pages + tile_idx] : b * n_tiles + tile_idx;
   const int voff = (a.H + a.KV) * a.Dr + hkv * a.Dr;
-  const int dq = a.Dr >> 1;
-  for (int i = tid; i < 64 * dq; i += 256) {
-    const int r = i / dq, d = (i - r * dq) * 2;
+  const int cpr = a.Dr >> 3;
+  for (int i = tid; i < 64 * cpr; i += 256) {
+    const int r = i / cpr, c = i - r * cpr;
     const int s_in = t * 64 + r;
-    unsigned v = 0;
-    if (s_in < a.S) v = *(const unsigned*)(a.qkv + ((size_t)b * a.S + s_in) * a.ld + voff + d);
-    tile[r][d] = (bf16_t)(v & 0xffff); tile[r][d + 1] = (bf16_t)(v >> 16);
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (s_in < a.S) v = *(const u32x4_t*)(a.qkv + ((size_t)b * a.S + s_in) * a.ld + voff + c * 8);
+    *(u32x4_t*)&tile[r][c * 8] = v;
   }
   __syncthreads();
   bf16_t* dst = a.Vt + ((size_t)page * a.KV + hkv) * (64 * a.D);
-  for (int i = tid; i < a.D * 32; i += 256) {
-    const int d = i >> 5, kp = (i & 31) * 2;
-    unsigned o = 0;
-    if (d < a.Dr) o = (unsigned)tile[kp][d] | ((unsigned)tile[kp + 1][d] << 16);
-    *(unsigned*)(dst + d * 64 + kp) = o;
+  for (int i = tid; i < a.D * 8; i += 256) {
+    const int d = i >> 3, k8 = (i & 7) * 8;
+    u32x4_t o = {0u, 0u, 0u, 0u};
+    if (d < a.Dr) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (unsigned)tile[k8 + 2 * e][d] | ((unsigned)tile[k8 + 2 * e + 1][d] << 16);
+    }
+    *(u32x4_t*)(dst + d * 64 + k8) = o;
   }
 }
 

@@ -281,61 +281,79 @@ int build_visual(gvl_ctx* ctx, const float* clip_feats, const bf16_t* iv2_feats,
   return 0;
 }
 
-// one decoder layer stack over S rows starting at position 0 (prefill) for nb sequences of EQUAL length S together: the GEMMs see
-// nb*S rows (better tile fill: Phi's o / down projections have 168 tiles at S = 3519), attention / RoPE / KV writes stay per sequence
-// (qkv_post and the attention kernel take a [nb][pages] block table).  Row-wise arithmetic is unchanged, so the result per sequence
-// is bit-identical to nb separate prefills.
+// page ids of a batch of equal-length sequences, passed by value to a stream-ordered fill (no host buffer lifetime)
 struct IntList { int v[GVL_MAX_DECODE_BATCH * 64]; int n; };
 __global__ void fill_ints_kernel(int* dst, const IntList l) { for (int i = threadIdx.x; i < l.n; i += blockDim.x) dst[i] = l.v[i]; }
 
-int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embeds, int S, hipStream_t st) {
+// Prefill of nb = 1, 2 or 4 sequences together (lens[b] tokens each).  The decoder GEMMs run over the rows of all of them
+// (packed back to back, no padding); RoPE / KV append / causal attention run per sequence on its own pages -- as ONE launch with a
+// batch dimension when the lengths are equal, as nb launches otherwise.  Every kernel is batch-invariant, so each sequence's
+// result is bit-identical to a prefill on its own.
+int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embeds, const int* lens, hipStream_t st) {
   const gvl_config& f = ctx->cfg;
   const int Hd = f.hidden, H = f.heads, KV = f.kv_heads, Dr = ctx->l_Dr, D = ctx->l_D, I = f.inter;
   const int qkvw = (H + 2 * KV) * Dr;
-  const int M = nb * S, P = (S + 63) / 64;
-  if (nb < 1 || nb > GVL_MAX_DECODE_BATCH || nb == 3 || (nb > 1 && nb * P > GVL_MAX_DECODE_BATCH * 64))
-    return fail(ctx, GVL_ERR_ARG, "llm_prefill: batch must be 1, 2 or 4 sequences (batched: <= 4096 tokens each)");
+  if (nb < 1 || nb > GVL_MAX_DECODE_BATCH || nb == 3) return fail(ctx, GVL_ERR_ARG, "llm_prefill: batch must be 1, 2 or 4 sequences");
+  int off[GVL_MAX_DECODE_BATCH + 1]; off[0] = 0;
+  bool uniform = true;
+  for (int b = 0; b < nb; ++b) { off[b + 1] = off[b] + lens[b]; uniform = uniform && lens[b] == lens[0]; }
+  const int M = off[nb], S0 = lens[0], P0 = (S0 + 63) / 64;
+  if (nb > 1 && uniform && nb * P0 > GVL_MAX_DECODE_BATCH * 64) uniform = false;   // page-id list below holds 256 entries
   const size_t mark = ctx->arena_l_off;
   LALLOC(x, bf16_t, (size_t)M * Hd); LALLOC(h, bf16_t, (size_t)M * Hd); LALLOC(qkv, bf16_t, (size_t)M * qkvw);
-  LALLOC(att, bf16_t, (size_t)M * H * Dr); LALLOC(act, bf16_t, (size_t)M * I); LALLOC(Q, bf16_t, (size_t)nb * H * S * D);
+  LALLOC(att, bf16_t, (size_t)M * H * Dr); LALLOC(act, bf16_t, (size_t)M * I); LALLOC(Q, bf16_t, (size_t)M * H * D);
   const int* table = sqs[0]->d_block_table;
   int table_stride = sqs[0]->n_pages;
-  if (nb > 1) {   // [nb][P] page ids of the batch, written by a stream-ordered kernel (ids passed by value: no host buffer lifetime)
-    LALLOC(tb, int, (size_t)nb * P);
-    IntList l; l.n = nb * P;
-    for (int b = 0; b < nb; ++b) for (int p = 0; p < P; ++p) l.v[b * P + p] = sqs[b]->pages[p];
+  if (nb > 1 && uniform) {   // [nb][P] page ids of the batch, written by a stream-ordered kernel (ids passed by value: no host buffer lifetime)
+    LALLOC(tb, int, (size_t)nb * P0);
+    IntList l; l.n = nb * P0;
+    for (int b = 0; b < nb; ++b) for (int p = 0; p < P0; ++p) l.v[b * P0 + p] = sqs[b]->pages[p];
     hipLaunchKernelGGL(fill_ints_kernel, dim3(1), dim3(256), 0, st, tb, l);
-    table = tb; table_stride = P;
+    table = tb; table_stride = P0;
   }
-  for (int b = 0; b < nb; ++b) HIPCHK(ctx, hipMemcpyAsync(x + (size_t)b * S * Hd, embeds[b], (size_t)S * Hd * 2, hipMemcpyDeviceToDevice, st));
-  const bool use_long = f.rope_orig_max_pos > 0 && S > f.rope_orig_max_pos && ctx->cos_l;
-  const float* cs = use_long ? ctx->cos_l : ctx->cos_s; const float* sn = use_long ? ctx->sin_l : ctx->sin_s;
+  for (int b = 0; b < nb; ++b) HIPCHK(ctx, hipMemcpyAsync(x + (size_t)off[b] * Hd, embeds[b], (size_t)lens[b] * Hd * 2, hipMemcpyDeviceToDevice, st));
+  // one (RoPE + KV append, attention) launch for the whole batch when the lengths agree, one per sequence otherwise
+  const int n_att = (nb == 1 || uniform) ? 1 : nb;
   for (int l = 0; l < f.layers; ++l) {
     const LlmLayerW& w = ctx->ll[l];
     bf16_t* Kt = ctx->kpool + (size_t)l * ctx->layer_stride; bf16_t* Vt = ctx->vpool + (size_t)l * ctx->layer_stride;
     RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln1, h, M, Hd, f.rms_eps, st));
     { GemmArgs g = gemm(h, Hd, w.qkvw, qkv, qkvw, M, qkvw, Hd); RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
-    { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv; q.ld = qkvw; q.Q = Q; q.Kt = Kt; q.Vt = Vt; q.block_table = table; q.max_pages = table_stride;
-      q.B = nb; q.S = S; q.H = H; q.KV = KV; q.Dr = Dr; q.D = D; q.mode = 2; q.cos = cs; q.sin = sn; q.pos0 = 0;
-      RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
-    { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; a.O = att; a.block_table = table; a.max_pages = table_stride;
-      a.B = nb; a.H = H; a.KV = KV; a.S = S; a.D = D; a.Dout = Dr; a.scale = 1.0f / sqrtf((float)Dr); a.causal = 1;
-      RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
+    for (int u = 0; u < n_att; ++u) {
+      const int S = lens[u], B = n_att == 1 ? nb : 1;
+      const int* tbl = n_att == 1 ? table : sqs[u]->d_block_table;
+      const int tstride = n_att == 1 ? table_stride : sqs[u]->n_pages;
+      // LongRoPE: short factors up to the original context, long factors past it (modeling_phi3.py:381-385), per sequence
+      const bool use_long = f.rope_orig_max_pos > 0 && S > f.rope_orig_max_pos && ctx->cos_l;
+      bf16_t* Qu = Q + (size_t)off[u] * H * D;
+      { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv + (size_t)off[u] * qkvw; q.ld = qkvw; q.Q = Qu; q.Kt = Kt; q.Vt = Vt; q.block_table = tbl; q.max_pages = tstride;
+        q.B = B; q.S = S; q.H = H; q.KV = KV; q.Dr = Dr; q.D = D; q.mode = 2; q.cos = use_long ? ctx->cos_l : ctx->cos_s; q.sin = use_long ? ctx->sin_l : ctx->sin_s; q.pos0 = 0;
+        RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
+      { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Qu; a.Kt = Kt; a.Vt = Vt; a.O = att + (size_t)off[u] * H * Dr; a.block_table = tbl; a.max_pages = tstride;
+        a.B = B; a.H = H; a.KV = KV; a.S = S; a.D = D; a.Dout = Dr; a.scale = 1.0f / sqrtf((float)Dr); a.causal = 1;
+        RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
+    }
     { GemmArgs g = gemm(att, H * Dr, w.ow, x, Hd, M, Hd, H * Dr); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
     RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln2, h, M, Hd, f.rms_eps, st));
     { GemmArgs g = gemm(h, Hd, w.guw, act, I, M, 2 * I, Hd); g.act = GVL_ACT_SILU_MUL; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
     { GemmArgs g = gemm(act, I, w.downw, x, Hd, M, Hd, I); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
   }
   // last-row-only lm_head: final RMSNorm fused into the GEMV; one weight stream for the nb last rows
-  { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = ctx->l_headw; g.N = f.vocab; g.K = Hd; g.x = x + (size_t)(S - 1) * Hd; g.norm_w = ctx->l_norm; g.eps = f.rms_eps;
-    g.batch = nb; g.x_stride = S * Hd; g.out_stride = f.vocab;
+  const bf16_t* last = x + (size_t)(S0 - 1) * Hd;
+  int last_stride = S0 * Hd;
+  if (n_att > 1) {                         // ragged: gather the nb last rows (h is free by now)
+    for (int b = 0; b < nb; ++b) HIPCHK(ctx, hipMemcpyAsync(h + (size_t)b * Hd, x + (size_t)(off[b + 1] - 1) * Hd, (size_t)Hd * 2, hipMemcpyDeviceToDevice, st));
+    last = h; last_stride = Hd;
+  }
+  { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = ctx->l_headw; g.N = f.vocab; g.K = Hd; g.x = last; g.norm_w = ctx->l_norm; g.eps = f.rms_eps;
+    g.batch = nb; g.x_stride = last_stride; g.out_stride = f.vocab;
     g.bias = ctx->l_headb; g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, gvl_launch_gemv(g, st)); }
   { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = f.vocab; am.batch = nb;
     for (int b = 0; b < nb; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.steps[b] = 0; }   // first generated token
     RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(am, st)); }
   for (int b = 0; b < nb; ++b) {
-    RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sqs[b]->d_pos, S, st));
-    sqs[b]->pos = S; sqs[b]->n_gen = 1;
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sqs[b]->d_pos, lens[b], st));
+    sqs[b]->pos = lens[b]; sqs[b]->n_gen = 1;
   }
   ctx->arena_l_off = mark;
   return 0;
@@ -714,37 +732,49 @@ int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int S, float* 
   if (sq.pos != 0) return fail(ctx, GVL_ERR_STATE, "gvl_prefill: sequence already holds tokens");
   hipStream_t st = (hipStream_t)stream;
   Seq* one[1] = {&sq}; const bf16_t* e1[1] = {embeds};
-  int rc = llm_prefill(ctx, one, 1, e1, S, st);
+  int rc = llm_prefill(ctx, one, 1, e1, &S, st);
   if (rc) return rc;
   if (last_logits) HIPCHK(ctx, hipMemcpyAsync(last_logits, ctx->d_logits, (size_t)ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
   return 0;
 }
 
-int gvl_prefill_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, const uint16_t* const* embeds, int S, void* stream) {
-  REQUIRE_READY(ctx->has_llm, "gvl_prefill_batch");
-  if (!seq_ids || !embeds || n_seqs <= 0 || n_seqs > gvl_ctx::kMaxSeqs || S <= 0) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_batch: bad arguments");
+int gvl_prefill_varlen(gvl_ctx* ctx, const int* seq_ids, int n_seqs, const uint16_t* const* embeds, const int* seq_lens, void* stream) {
+  REQUIRE_READY(ctx->has_llm, "gvl_prefill_varlen");
+  if (!seq_ids || !embeds || !seq_lens || n_seqs <= 0 || n_seqs > gvl_ctx::kMaxSeqs) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_varlen: bad arguments");
   for (int i = 0; i < n_seqs; ++i) {
     const int id = seq_ids[i];
-    if (id < 0 || id >= (int)ctx->seqs.size() || !ctx->seqs[id].used || !embeds[i]) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_batch: bad seq / embeds");
-    if (S > ctx->seqs[id].max_tokens) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_batch: bad length");
-    if (ctx->seqs[id].pos != 0) return fail(ctx, GVL_ERR_STATE, "gvl_prefill_batch: sequence already holds tokens");
-    for (int j = 0; j < i; ++j) if (seq_ids[j] == id) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_batch: duplicate seq");
+    if (id < 0 || id >= (int)ctx->seqs.size() || !ctx->seqs[id].used || !embeds[i]) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_varlen: bad seq / embeds");
+    if (seq_lens[i] <= 0 || seq_lens[i] > ctx->seqs[id].max_tokens) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_varlen: bad length");
+    if (seq_lens[i] > ctx->cfg.max_prefill) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_varlen: seq_len exceeds cfg.max_prefill");
+    if (ctx->seqs[id].pos != 0) return fail(ctx, GVL_ERR_STATE, "gvl_prefill_varlen: sequence already holds tokens");
+    for (int j = 0; j < i; ++j) if (seq_ids[j] == id) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_varlen: duplicate seq");
   }
   hipStream_t st = (hipStream_t)stream;
-  // groups of 4, 2, 1 sequences -- as many as the prefill workspace (cfg.max_prefill rows) and the 64-page table limit allow
+  // groups of 4, 2, 1 sequences in call order -- as many as the prefill workspace (cfg.max_prefill rows in total) allows
   int i = 0;
   while (i < n_seqs) {
     const int left = n_seqs - i;
     int B = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
-    while (B > 1 && ((long)B * S > ctx->cfg.max_prefill || B * ((S + 63) / 64) > GVL_MAX_DECODE_BATCH * 64)) B >>= 1;
-    if (S > ctx->cfg.max_prefill) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_batch: seq_len exceeds cfg.max_prefill");
+    for (;;) {
+      long rows = 0; for (int b = 0; b < B; ++b) rows += seq_lens[i + b];
+      if (B == 1 || rows <= ctx->cfg.max_prefill) break;
+      B >>= 1;
+    }
     Seq* sqs[GVL_MAX_DECODE_BATCH]; const bf16_t* es[GVL_MAX_DECODE_BATCH];
     for (int b = 0; b < B; ++b) { sqs[b] = &ctx->seqs[seq_ids[i + b]]; es[b] = embeds[i + b]; }
-    const int rc = llm_prefill(ctx, sqs, B, es, S, st);
+    const int rc = llm_prefill(ctx, sqs, B, es, seq_lens + i, st);
     if (rc) return rc;
     i += B;
   }
   return 0;
+}
+
+int gvl_prefill_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, const uint16_t* const* embeds, int S, void* stream) {
+  if (!ctx) return GVL_ERR_ARG;
+  if (n_seqs <= 0 || n_seqs > gvl_ctx::kMaxSeqs) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_batch: bad arguments");
+  int lens[gvl_ctx::kMaxSeqs];
+  for (int i = 0; i < n_seqs; ++i) lens[i] = S;
+  return gvl_prefill_varlen(ctx, seq_ids, n_seqs, embeds, lens, stream);
 }
 
 int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t* out_ids, int* n_out, void* stream) {
@@ -771,6 +801,48 @@ int gvl_decode_greedy_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, int ma
     const int rc = decode_group(ctx, sqs, B, max_new, eos_id, outs, nouts, st);
     if (rc) return rc;
     i += B;
+  }
+  return 0;
+}
+
+// ---- building blocks of a continuous-batching scheduler: sequences at DIFFERENT generation steps advance
+// together, the host decides between chunks who joins (gvl_prefill*) and who leaves (gvl_seq_free).
+int gvl_decode_steps(gvl_ctx* ctx, const int* seq_ids, int n_seqs, int n_steps, void* stream) {
+  REQUIRE_READY(ctx->has_llm, "gvl_decode_steps");
+  if (!seq_ids || n_seqs <= 0 || n_seqs > gvl_ctx::kMaxSeqs || n_steps <= 0) return fail(ctx, GVL_ERR_ARG, "gvl_decode_steps: bad arguments");
+  for (int i = 0; i < n_seqs; ++i) {
+    const int id = seq_ids[i];
+    if (id < 0 || id >= (int)ctx->seqs.size() || !ctx->seqs[id].used) return fail(ctx, GVL_ERR_ARG, "gvl_decode_steps: bad seq");
+    const Seq& sq = ctx->seqs[id];
+    if (sq.n_gen < 1) return fail(ctx, GVL_ERR_STATE, "gvl_decode_steps: call gvl_prefill first");
+    if (sq.pos + n_steps > sq.max_tokens || sq.n_gen + n_steps > ctx->outlist_cap) return fail(ctx, GVL_ERR_ARG, "gvl_decode_steps: sequence would exceed its capacity");
+    for (int j = 0; j < i; ++j) if (seq_ids[j] == id) return fail(ctx, GVL_ERR_ARG, "gvl_decode_steps: duplicate seq");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (int s = 0; s < n_steps; ++s) {
+    int i = 0;
+    while (i < n_seqs) {                   // groups of 4, 2, 1: one weight stream per step per group
+      const int left = n_seqs - i, B = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+      Seq* sqs[GVL_MAX_DECODE_BATCH];
+      for (int b = 0; b < B; ++b) sqs[b] = &ctx->seqs[seq_ids[i + b]];
+      const int rc = decode_step(ctx, sqs, B, st);
+      if (rc) return rc;
+      i += B;
+    }
+  }
+  return 0;
+}
+
+int gvl_seq_read(gvl_ctx* ctx, int seq_id, int first, int32_t* out_ids, int cap, int* n_gen, void* stream) {
+  REQUIRE_READY(ctx->has_llm, "gvl_seq_read");
+  if (seq_id < 0 || seq_id >= (int)ctx->seqs.size() || !ctx->seqs[seq_id].used || !n_gen || first < 0 || cap < 0 || (cap > 0 && !out_ids))
+    return fail(ctx, GVL_ERR_ARG, "gvl_seq_read: bad arguments");
+  const Seq& sq = ctx->seqs[seq_id];
+  *n_gen = sq.n_gen;
+  int n = sq.n_gen - first; if (n > cap) n = cap;
+  if (n > 0) {
+    HIPCHK(ctx, hipMemcpyAsync(out_ids, sq.d_out + first, (size_t)n * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream));
   }
   return 0;
 }

@@ -226,14 +226,13 @@ class Engine:
         return [int(buf[i]) for i in range(n.value)]
 
     def prefill_batch(self, seqs: Sequence[int], embeds: Sequence[torch.Tensor]) -> None:
-        """Prefill several sequences of EQUAL length together (one pass of the decoder GEMMs over all their rows)."""
+        """Prefill several sequences together -- equal or ragged lengths (one pass of the decoder GEMMs over all their rows)."""
         es = [e.contiguous() for e in embeds]
-        S = es[0].shape[0]
-        assert all(e.shape[0] == S for e in es), "prefill_batch needs equal lengths (use prefill per sequence otherwise)"
         n = len(seqs)
         ids = (C.c_int * n)(*[int(s) for s in seqs])
         ptrs = (C.c_void_p * n)(*[e.data_ptr() for e in es])
-        self._chk(self.lib.gvl_prefill_batch(self.ctx, ids, n, ptrs, int(S), self.stream), "gvl_prefill_batch")
+        lens = (C.c_int * n)(*[int(e.shape[0]) for e in es])
+        self._chk(self.lib.gvl_prefill_varlen(self.ctx, ids, n, ptrs, lens, self.stream), "gvl_prefill_varlen")
 
     def decode_greedy_batch(self, seqs: Sequence[int], max_new: int, eos_id: Optional[int]) -> List[List[int]]:
         """Greedy decode of several freshly prefilled sequences together (weights streamed once per step per group of 4/2/1)."""
@@ -244,6 +243,19 @@ class Engine:
         self._chk(self.lib.gvl_decode_greedy_batch(self.ctx, ids, n, int(max_new), -1 if eos_id is None else int(eos_id), buf, nout, self.stream),
                   "gvl_decode_greedy_batch")
         return [[int(buf[i * max_new + j]) for j in range(nout[i])] for i in range(n)]
+
+    def decode_steps(self, seqs: Sequence[int], n_steps: int) -> None:
+        """Advance every listed sequence by n_steps greedy tokens (mixed generation steps allowed; asynchronous)."""
+        n = len(seqs)
+        ids = (C.c_int * n)(*[int(s) for s in seqs])
+        self._chk(self.lib.gvl_decode_steps(self.ctx, ids, n, int(n_steps), self.stream), "gvl_decode_steps")
+
+    def seq_read(self, seq: int, first: int = 0, cap: int = 4096) -> List[int]:
+        """Ids generated so far by `seq`, from generation index `first` (synchronises the stream)."""
+        buf = (C.c_int32 * max(cap, 1))()
+        n = C.c_int(0)
+        self._chk(self.lib.gvl_seq_read(self.ctx, int(seq), int(first), buf, int(cap), C.byref(n), self.stream), "gvl_seq_read")
+        return [int(buf[i]) for i in range(max(0, min(n.value - first, cap)))]
 
     def decode_step_logits(self, seq: int, tok: int) -> torch.Tensor:
         logits = torch.empty((self.geo.vocab,), dtype=torch.float32, device=self.device)

@@ -53,6 +53,9 @@ _SIGS = {
     "gvl_decode_greedy": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.c_void_p]),
     "gvl_preprocess_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
     "gvl_prefill_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
+    "gvl_decode_steps": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p]),
+    "gvl_seq_read": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "gvl_prefill_varlen": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p]),
     "gvl_decode_greedy_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.c_void_p]),
     "gvl_decode_step_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gvl_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -91,11 +94,16 @@ def load():
     return lib
 
 
+ERR_ARG, ERR_STATE, ERR_HIP, ERR_OOM, ERR_NOGPU = -1, -2, -3, -4, -5   # include/gvl.h gvl_status
+
+
 class GvlError(RuntimeError):
-    pass
+    status = 0
 
 
 def check(lib, ctx, rc, what=""):
     if rc != 0:
         msg = lib.gvl_last_error(ctx)
-        raise GvlError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+        err = GvlError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+        err.status = rc
+        raise err

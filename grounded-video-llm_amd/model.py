@@ -170,16 +170,16 @@ class LLAVA_NEXT_VIDEO:
             row = [int(t) for t, m in zip(ids_arr[0], mask[0]) if m]
             return [eng.generate_ids(eng.splice(row, feats[0]), max_new, eos)]
         # bs > 1 (the reference left-pads the batch, llava_next_video.py:622-647): every sample keeps its own paged KV and its
-        # un-padded length -- identical maths to the masked left-padded batch -- and the greedy decode of the whole batch runs
-        # together (gvl_decode_greedy_batch: one weight stream per token for groups of 4 / 2 / 1 sequences)
-        seqs = []
-        for b in range(ids_arr.shape[0]):
-            row = [int(t) for t, m in zip(ids_arr[b], mask[b]) if m]
-            emb = eng.splice(row, feats[b])
-            seq = eng.seq_alloc(emb.shape[0] + max_new)
-            eng.prefill(seq, emb)
-            seqs.append(seq)
+        # un-padded length -- identical maths to the masked left-padded batch.  Prefill runs over the packed rows of the batch
+        # (gvl_prefill_varlen) and the greedy decode of the whole batch runs together (gvl_decode_greedy_batch: one weight stream
+        # per token for groups of 4 / 2 / 1 sequences)
+        seqs, embs = [], []
         try:
+            for b in range(ids_arr.shape[0]):
+                row = [int(t) for t, m in zip(ids_arr[b], mask[b]) if m]
+                embs.append(eng.splice(row, feats[b]))
+                seqs.append(eng.seq_alloc(embs[-1].shape[0] + max_new))
+            eng.prefill_batch(seqs, embs)
             return eng.decode_greedy_batch(seqs, max_new, eos)
         finally:
             for seq in seqs:

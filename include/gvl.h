@@ -114,9 +114,14 @@ int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int seq_len, f
                 void* stream);
 int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t* out_ids_host,
                       int* n_out, void* stream);
-/* Prefill of n_seqs sequences of EQUAL length seq_len together (groups of 4 / 2 / 1 that fit cfg.max_prefill rows): the decoder
- * GEMMs run over all rows of a group at once (better tile fill), attention / RoPE / KV writes stay per sequence on its own pages;
- * per sequence bit-identical to gvl_prefill.  embeds: host array of n_seqs device pointers (bf16 [seq_len, hidden] each). */
+/* Prefill of n_seqs sequences together, seq_lens[i] tokens each (ragged: prompts differ in length; the reference left-pads and
+ * masks, llava_next_video.py:622-647 -- here the rows are packed back to back, no padding).  Groups of 4 / 2 / 1 sequences whose
+ * rows fit cfg.max_prefill: the decoder GEMMs run over all rows of a group at once (better tile fill); RoPE / KV append / causal
+ * attention stay per sequence on its own pages (one launch with a batch dimension when the lengths agree, one per sequence
+ * otherwise).  Per sequence bit-identical to gvl_prefill.  embeds: host array of n_seqs device pointers (bf16 [len, hidden]). */
+int gvl_prefill_varlen(gvl_ctx* ctx, const int* seq_ids, int n_seqs, const uint16_t* const* embeds,
+                       const int* seq_lens, void* stream);
+/* gvl_prefill_varlen with every length == seq_len. */
 int gvl_prefill_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, const uint16_t* const* embeds, int seq_len,
                       void* stream);
 /* Batched greedy decode of n_seqs freshly prefilled sequences (the reference batches clips in generate() with
@@ -126,6 +131,14 @@ int gvl_prefill_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, const uint16
  * out_ids_host int32 [n_seqs][max_new]; n_out [n_seqs].  A group runs until all of its members hit eos / max_new. */
 int gvl_decode_greedy_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, int max_new, int eos_id,
                             int32_t* out_ids_host, int* n_out, void* stream);
+/* Continuous batching: the two calls a scheduler needs besides prefill / seq_alloc / seq_free.
+ * gvl_decode_steps advances every listed sequence by n_steps greedy tokens -- the sequences may be at DIFFERENT generation
+ * steps (joined at different times); groups of 4 / 2 / 1 share one weight stream per step; asynchronous on `stream`, no eos
+ * test (the host inspects the ids between chunks; tokens after an eos are discarded by the caller).
+ * gvl_seq_read copies the ids generated so far, from index `first`, to the host (at most cap), reports the total count in
+ * *n_gen and synchronises `stream`.  Free a sequence only after a gvl_seq_read / stream synchronise that follows its last step. */
+int gvl_decode_steps(gvl_ctx* ctx, const int* seq_ids, int n_seqs, int n_steps, void* stream);
+int gvl_seq_read(gvl_ctx* ctx, int seq_id, int first, int32_t* out_ids_host, int cap, int* n_gen, void* stream);
 /* teacher-forced single step (parity tests): appends token `tok`, returns logits f32 [vocab]. */
 int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, void* stream);
 

@@ -226,3 +226,70 @@ def test_prefill_batch_is_bit_identical_to_single(which):
                 eng.seq_free(s)
             assert got == single[:n], f"{which} S={S}: prefill_batch({n}) + batched decode differs from the single-sequence path"
     eng.close()
+
+
+@pytest.mark.parametrize("which", ["phi3_tiny", "llama_tiny"])
+def test_prefill_varlen_is_bit_identical_to_single(which):
+    """gvl_prefill_varlen: RAGGED sequences prefilled together (rows packed back to back through the decoder GEMMs; RoPE / KV
+    append / attention per sequence) -- the reference's left-padded batch (llava_next_video.py:622-647) without the padding.
+    Every sequence must end in exactly the state of its own gvl_prefill: same first token, same continuation."""
+    meta, g = load_golden(which)
+    c = meta["cfg"]
+    if which == "phi3_tiny":
+        geo = _phi_geo(c)
+        W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
+    else:
+        geo = tiny_geo(llm="llama3", hidden=c["hidden"], inter=c["inter"], layers=c["layers"], heads=c["heads"], kv_heads=c["kv_heads"], vocab=c["vocab"],
+                       rope_theta=c["rope_theta"], rope_orig_max_pos=0)
+        W = synth.llm_weights("llama", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
+    eng = llm_engine(geo, W)
+    new = 10
+    for lens in ((7, 64, 61, 65), (1, 130, 2, 129), (33, 33, 40, 33)):   # page boundaries, single-token prompts, a near-uniform batch
+        xs = [synth.det_tensor(f"pvar.{which}.{S}.{i}", (S, c["hidden"]), 0.5).to(DEV).to(bf) for i, S in enumerate(lens)]
+        single = [eng.generate_ids(x, new, None) for x in xs]
+        for n in (2, 3, 4):
+            seqs = [eng.seq_alloc(lens[i] + new) for i in range(n)]
+            eng.prefill_batch(seqs, xs[:n])
+            got = eng.decode_greedy_batch(seqs, new, None)
+            for s in seqs:
+                eng.seq_free(s)
+            assert got == single[:n], f"{which} lens={lens[:n]}: ragged prefill + batched decode differs from the single-sequence path"
+    eng.close()
+
+
+def test_scheduler_matches_one_at_a_time():
+    """Continuous batching (serve.ClipScheduler over gvl_prefill_varlen / gvl_decode_steps / gvl_seq_read): requests of ragged
+    lengths join and leave between decode chunks, members of a decode group are at different generation steps -- the ids of
+    every request must equal its own one-at-a-time generate (greedy, eos included)."""
+    from grounded_video_llm_amd import serve
+    meta, g = load_golden("phi3_tiny")
+    c = meta["cfg"]
+    geo = _phi_geo(c)
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
+    eng = llm_engine(geo, W)
+    lens = (7, 64, 61, 65, 1, 130, 2, 129, 33)
+    xs = [synth.det_tensor(f"sched.{S}.{i}", (S, c["hidden"]), 0.5).to(DEV).to(bf) for i, S in enumerate(lens)]
+    new = 24
+    free = eng.generate_ids(xs[0], new, None)
+    eos = free[5]                                              # a token the model really emits -> some requests stop early
+    single = [eng.generate_ids(x, new, eos) for x in xs]
+    assert any(len(s) < new for s in single)
+    for max_active, chunk in ((4, 4), (3, 7), (8, 1)):
+        sch = serve.ClipScheduler(eng, eos, max_active=max_active, chunk=chunk, max_prefill_rows=geo.max_prefill)
+        rids = [sch.submit(x, new) for x in xs]
+        out = sch.run()
+        assert [out[r] for r in rids] == single, f"scheduler(max_active={max_active}, chunk={chunk}) differs from one-at-a-time generate"
+        assert sch.stats["max_concurrent"] > 1
+    # state errors of the two new entry points
+    seq = eng.seq_alloc(64)
+    with pytest.raises(RuntimeError):
+        eng.decode_steps([seq], 1)                             # not prefilled
+    eng.prefill(seq, xs[0])
+    with pytest.raises(RuntimeError):
+        eng.decode_steps([seq], 64)                            # would exceed the sequence's capacity
+    with pytest.raises(RuntimeError):
+        eng.decode_steps([seq, seq], 1)                        # duplicate
+    eng.decode_steps([seq], 3)
+    assert eng.seq_read(seq) == free[:4] and eng.seq_read(seq, 2) == free[2:4] and eng.seq_read(seq, 1, 1) == free[1:2]
+    eng.seq_free(seq)
+    eng.close()

@@ -172,3 +172,114 @@ def test_reference_checkpoint_layout_roundtrip(tmp_path, llm):
             assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), f"{name}:{k}"
     with pytest.raises(FileNotFoundError):
         M.load_reference_checkpoints(llm, str(tmp_path / "missing.pt"), str(d))
+
+
+# ---- continuous-batching scheduler on a scripted engine ------------------------------------------------
+class _Emb:
+    def __init__(self, S, seed):
+        self.shape, self.seed = (S, 8), seed
+
+
+class _ScriptedEngine:
+    """Engine double: token t of a request is a pure function of (its seed, t); KV pages are a finite pool."""
+
+    def __init__(self, pages, vocab=50, max_seq=4096):
+        from types import SimpleNamespace
+        self.free, self.vocab, self.geo = pages, vocab, SimpleNamespace(max_seq=max_seq)
+        self.seqs, self.log, self._next = {}, [], 0
+
+    def _tok(self, seed, t):
+        import zlib
+        return zlib.crc32(f"{seed}:{t}".encode()) % self.vocab
+
+    def seq_alloc(self, max_tokens):
+        need = (max_tokens + 63) // 64
+        if need > self.free:
+            e = L.GvlError("KV pages exhausted")
+            e.status = L.ERR_OOM
+            raise e
+        self.free -= need
+        self._next += 1
+        self.seqs[self._next] = dict(pages=need, cap=max_tokens, seed=None, pos=0, out=[])
+        return self._next
+
+    def seq_free(self, seq):
+        self.free += self.seqs.pop(seq)["pages"]
+
+    def prefill_batch(self, seqs, embs):
+        self.log.append(("prefill", [e.shape[0] for e in embs]))
+        for s, e in zip(seqs, embs):
+            q = self.seqs[s]
+            assert q["seed"] is None and e.shape[0] <= q["cap"]
+            q["seed"], q["pos"] = e.seed, e.shape[0]
+            q["out"].append(self._tok(e.seed, 0))
+
+    def decode_steps(self, seqs, k):
+        assert len(set(seqs)) == len(seqs) and k >= 1
+        self.log.append(("decode", len(seqs), k))
+        for s in seqs:
+            q = self.seqs[s]
+            assert q["pos"] + k <= q["cap"], "scheduler overran a sequence's KV capacity"
+            for _ in range(k):
+                q["out"].append(self._tok(q["seed"], len(q["out"])))
+            q["pos"] += k
+
+    def seq_read(self, seq, first=0, cap=4096):
+        return self.seqs[seq]["out"][first:first + cap]
+
+    def alone(self, emb, max_new, eos):
+        out = []
+        for t in range(min(max_new, self.geo.max_seq - emb.shape[0] + 1)):
+            out.append(self._tok(emb.seed, t))
+            if eos is not None and out[-1] == eos:
+                break
+        return out
+
+
+@pytest.mark.parametrize("max_active,chunk,pages", [(1, 1, 64), (4, 8, 64), (3, 5, 7), (8, 16, 1000)])
+def test_scheduler_ids_equal_one_at_a_time(max_active, chunk, pages):
+    from grounded_video_llm_amd import serve
+    eng = _ScriptedEngine(pages)
+    rng = np.random.default_rng(max_active * 100 + chunk)
+    embs = [_Emb(int(rng.integers(1, 200)), int(rng.integers(1, 10**6))) for _ in range(23)]
+    eos, max_new = 7, 40
+    want = [eng.alone(e, max_new, eos) for e in embs]
+    assert any(len(w) < max_new for w in want) and any(len(w) == max_new for w in want)      # both exits are exercised
+    sch = serve.ClipScheduler(eng, eos, max_active=max_active, chunk=chunk)
+    rids = [sch.submit(e, max_new) for e in embs]
+    out = sch.run()
+    assert [out[r] for r in rids] == want
+    assert eng.free == pages and not eng.seqs, "pages leaked"
+    assert sch.stats["max_concurrent"] <= max_active
+    if max_active > 1 and pages >= 64:
+        assert sch.stats["max_concurrent"] > 1 and any(op[0] == "prefill" and len(op[1]) > 1 for op in eng.log)
+    # no decode chunk ran past a member's max_new; wasted steps (after an eos inside a chunk) are bounded by chunk - 1 per request
+    assert sch.stats["wasted_seq_steps"] <= (chunk - 1) * len(embs)
+
+
+def test_scheduler_edge_cases():
+    from grounded_video_llm_amd import serve
+    eng = _ScriptedEngine(4, max_seq=128)
+    # request that cannot ever fit the KV pool -> loud error, not a spin
+    sch = serve.ClipScheduler(eng, None, max_active=2, chunk=4)
+    sch.submit(_Emb(100, 1), 1000)            # clamped to max_seq = 128 tokens -> 2 pages: fits
+    out = sch.run()
+    assert len(out[0]) == 128 - 100 + 1       # generate() stops at the context limit
+    big = _ScriptedEngine(1, max_seq=4096)
+    sch = serve.ClipScheduler(big, None, max_active=2, chunk=4)
+    sch.submit(_Emb(100, 1), 100)             # 200 tokens = 4 pages > pool of 1
+    with pytest.raises(L.GvlError, match="does not fit"):
+        sch.run()
+    # eos as the very first (prefill) token and max_new == 1: finish without a decode step
+    eng = _ScriptedEngine(16)
+    e = _Emb(10, 5)
+    first = eng._tok(5, 0)
+    assert serve.generate_many(eng, [e, _Emb(12, 6)], 1, None) == [[first], [eng._tok(6, 0)]]
+    assert serve.generate_many(eng, [e], 9, first) == [[first]]
+    assert not any(op[0] == "decode" for op in eng.log)
+    # prefill workspace limit: newcomers are split over iterations
+    eng = _ScriptedEngine(64)
+    out = serve.generate_many(eng, [_Emb(60, i) for i in range(4)], 3, None, max_active=4, chunk=2, max_prefill_rows=128)
+    assert [op[1] for op in eng.log if op[0] == "prefill"][:2] == [[60, 60], [60, 60]] and len(out) == 4
+    with pytest.raises(ValueError):
+        serve.ClipScheduler(eng, None, max_active=0)

@@ -2,6 +2,7 @@
 // (+ qk-RMSNorm / RoPE), HD-merge / pooling glue, decode GEMV, argmax.   gfx950 only.
 // Every kernel moves 8/16 bytes per lane (guide G13) and keeps statistics in fp32.
 #include "gvl_internal.h"
+#include <cstring>
 
 #define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -3)
 
@@ -778,6 +779,51 @@ __global__ void gather_tok_rows_kernel(const bf16_t* __restrict__ table, const T
 int gvl_launch_gather_tok_rows(const bf16_t* table, const TokPtrs& toks, bf16_t* dst, int cols, hipStream_t st) {
   if (cols % 8 || toks.n < 1 || toks.n > GVL_MAX_DECODE_BATCH) return -1;
   hipLaunchKernelGGL(gather_tok_rows_kernel, dim3((cols / 8 + 255) / 256, toks.n), dim3(256), 0, st, table, toks, dst, cols);
+  return CHECK_LAUNCH();
+}
+// dst[r] = table[ids[r]] with the ids passed BY VALUE (256 per launch): no device staging buffer, so back-to-back calls on a busy
+// stream cannot overwrite each other's ids (a blocking hipMemcpy into one shared buffer could).
+__global__ void gather_rows_byval_kernel(const bf16_t* __restrict__ table, const IntList ids, bf16_t* __restrict__ dst, int cols) {
+  const int r = blockIdx.y;
+  const size_t src = (size_t)ids.v[r] * cols;
+  for (int c = (blockIdx.x * blockDim.x + threadIdx.x) * 8; c < cols; c += gridDim.x * blockDim.x * 8)
+    *(u32x4_t*)(dst + (size_t)r * cols + c) = *(const u32x4_t*)(table + src + c);
+}
+int gvl_launch_gather_rows_host_ids(const bf16_t* table, const int* host_ids, int n, bf16_t* dst, int cols, hipStream_t st) {
+  if (cols % 8 || n < 0) return -1;
+  constexpr int CH = (int)(sizeof(IntList::v) / sizeof(int));
+  for (int r0 = 0; r0 < n; r0 += CH) {
+    IntList l; l.n = n - r0 < CH ? n - r0 : CH;
+    memcpy(l.v, host_ids + r0, (size_t)l.n * sizeof(int));
+    hipLaunchKernelGGL(gather_rows_byval_kernel, dim3((cols / 8 + 255) / 256, l.n), dim3(256), 0, st, table, l, dst + (size_t)r0 * cols, cols);
+  }
+  return CHECK_LAUNCH();
+}
+// ---- training-forward loss tail: rows with a label -> final norm -> lm_head -> cross entropy -------------
+// nll[r] = logsumexp(logits[r,:]) - logits[r, target[r]] in f32 on the bf16 logits (`logits.float()` then CrossEntropyLoss,
+// modeling_phi3.py:1527-1539).  One block per row; max pass, then sum-of-exponentials pass, fixed reduction order.
+__global__ void __launch_bounds__(256) ce_rows_kernel(const bf16_t* __restrict__ logits, int ld, const int* __restrict__ targets,
+                                                      float* __restrict__ nll, int V) {
+  __shared__ float red[4];
+  const bf16_t* row = logits + (size_t)blockIdx.x * ld;
+  const int tid = threadIdx.x, wid = tid >> 6, ln = tid & 63;
+  float m = -3.0e38f;
+  for (int c = tid; c < V; c += 256) m = fmaxf(m, bf2f(row[c]));
+  m = wave_max(m);
+  if (ln == 0) red[wid] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = tid; c < V; c += 256) s += expf(bf2f(row[c]) - m);
+  s = wave_sum(s);
+  if (ln == 0) red[wid] = s;
+  __syncthreads();
+  if (tid == 0) nll[blockIdx.x] = (m + logf((red[0] + red[1]) + (red[2] + red[3]))) - bf2f(row[targets[blockIdx.x]]);
+}
+int gvl_launch_ce_rows(const bf16_t* logits, int ld, const int* targets, float* nll, int n, int V, hipStream_t st) {
+  if (n < 1 || V < 1) return -1;
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(n), dim3(256), 0, st, logits, ld, targets, nll, V);
   return CHECK_LAUNCH();
 }
 __global__ void inc_many_kernel(const IntPtrs ptrs) { if (threadIdx.x < ptrs.n) (*ptrs.p[threadIdx.x])++; }

@@ -206,6 +206,12 @@ struct GemvArgs {
 };
 int gvl_launch_gemv(const GemvArgs& a, hipStream_t st);
 // greedy sampling for `batch` logit rows (stride n): token -> *tok_ptrs[b] and out_lists[b][steps[b]]
+// small host int list passed to kernels by value (stream ordered, no host / staging buffer lifetime)
+struct IntList { int v[GVL_MAX_DECODE_BATCH * 64]; int n; };
+// dst[r] = table[host_ids[r]], ids travel in the kernel arguments (256 per launch)
+int gvl_launch_gather_rows_host_ids(const bf16_t* table, const int* host_ids, int n, bf16_t* dst, int cols, hipStream_t st);
+// loss tail of the training forward: nll[r] = logsumexp(logits[r]) - logits[r][targets[r]] (f32 on bf16 logits)
+int gvl_launch_ce_rows(const bf16_t* logits, int ld, const int* targets, float* nll, int n, int V, hipStream_t st);
 struct ArgmaxArgs { const float* logits; int n, batch; int* tok_ptrs[GVL_MAX_DECODE_BATCH]; int* out_lists[GVL_MAX_DECODE_BATCH]; int steps[GVL_MAX_DECODE_BATCH]; };
 int gvl_launch_argmax(const ArgmaxArgs& a, hipStream_t st);
 // x[b][:] = table[*tok_ptrs[b]][:]  and  (*pos_ptrs[b])++ helpers of the batched decode loop

@@ -170,12 +170,16 @@ size_t visual_bytes(const gvl_ctx* c, int n) {
   b += 4 * al256((size_t)f.hidden * 2 + cin * 2);
   return b + 4096;
 }
+constexpr int kLossChunk = 128;    // rows of logits materialised at a time by the training-forward loss tail
+// labelled rows of a training forward: device lists (row index into the sequence, target id) and the per-row nll output
+struct LossReq { int n; const int* h_rows; const int* h_targets; float* h_nll; };
 size_t prefill_bytes(const gvl_ctx* c, int S) {
   const gvl_config& f = c->cfg;
   const size_t qkvw = (size_t)(f.heads + 2 * f.kv_heads) * c->l_Dr;
   size_t b = 0;
   b += 2 * al256((size_t)S * f.hidden * 2) + al256((size_t)S * qkvw * 2) + al256((size_t)S * f.heads * c->l_Dr * 2);
   b += al256((size_t)S * f.inter * 2) + al256((size_t)f.heads * S * c->l_D * 2);
+  b += al256((size_t)kLossChunk * f.vocab * 2) + al256((size_t)kLossChunk * f.hidden * 2) + 3 * al256((size_t)S * 4);   // loss tail (gvl_forward_loss)
   return b + 4096;
 }
 size_t feats_bytes(const gvl_ctx* c, int n) {
@@ -282,14 +286,13 @@ int build_visual(gvl_ctx* ctx, const float* clip_feats, const bf16_t* iv2_feats,
 }
 
 // page ids of a batch of equal-length sequences, passed by value to a stream-ordered fill (no host buffer lifetime)
-struct IntList { int v[GVL_MAX_DECODE_BATCH * 64]; int n; };
 __global__ void fill_ints_kernel(int* dst, const IntList l) { for (int i = threadIdx.x; i < l.n; i += blockDim.x) dst[i] = l.v[i]; }
 
 // Prefill of nb = 1, 2 or 4 sequences together (lens[b] tokens each).  The decoder GEMMs run over the rows of all of them
 // (packed back to back, no padding); RoPE / KV append / causal attention run per sequence on its own pages -- as ONE launch with a
 // batch dimension when the lengths are equal, as nb launches otherwise.  Every kernel is batch-invariant, so each sequence's
 // result is bit-identical to a prefill on its own.
-int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embeds, const int* lens, hipStream_t st) {
+int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embeds, const int* lens, hipStream_t st, const LossReq* loss = nullptr) {
   const gvl_config& f = ctx->cfg;
   const int Hd = f.hidden, H = f.heads, KV = f.kv_heads, Dr = ctx->l_Dr, D = ctx->l_D, I = f.inter;
   const int qkvw = (H + 2 * KV) * Dr;
@@ -337,6 +340,24 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
     RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln2, h, M, Hd, f.rms_eps, st));
     { GemmArgs g = gemm(h, Hd, w.guw, act, I, M, 2 * I, Hd); g.act = GVL_ACT_SILU_MUL; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
     { GemmArgs g = gemm(act, I, w.downw, x, Hd, M, Hd, I); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+  }
+  if (loss && loss->n > 0) {
+    // training forward (llava_next_video.py:598-614 -> Phi3ForCausalLM.forward labels branch, modeling_phi3.py:1512-1539): only rows
+    // whose NEXT token carries a label need logits.  gather -> final RMSNorm -> lm_head GEMM (+bias, bf16 logits as under
+    // autocast) -> f32 cross entropy per row; the host adds the rows up in order (deterministic).
+    if (nb != 1) return fail(ctx, GVL_ERR_ARG, "llm_prefill: loss tail takes one sequence");
+    LALLOC(d_rows, int, loss->n); LALLOC(d_tgt, int, loss->n); LALLOC(d_nll, float, loss->n);
+    LALLOC(hs, bf16_t, (size_t)kLossChunk * Hd); LALLOC(lg, bf16_t, (size_t)kLossChunk * f.vocab);
+    HIPCHK(ctx, hipMemcpyAsync(d_rows, loss->h_rows, (size_t)loss->n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(d_tgt, loss->h_targets, (size_t)loss->n * 4, hipMemcpyHostToDevice, st));
+    for (int r0 = 0; r0 < loss->n; r0 += kLossChunk) {
+      const int n = loss->n - r0 < kLossChunk ? loss->n - r0 : kLossChunk;
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_rows(x, d_rows + r0, hs, n, Hd, st));
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(hs, ctx->l_norm, h, n, Hd, f.rms_eps, st));      // h is free by now; n <= S - 1 rows
+      { GemmArgs g = gemm(h, Hd, ctx->l_headw, lg, f.vocab, n, f.vocab, Hd); g.bias = ctx->l_headb; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_ce_rows(lg, f.vocab, d_tgt + r0, d_nll + r0, n, f.vocab, st));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(loss->h_nll, d_nll, (size_t)loss->n * 4, hipMemcpyDeviceToHost, st));
   }
   // last-row-only lm_head: final RMSNorm fused into the GEMV; one weight stream for the nb last rows
   const bf16_t* last = x + (size_t)(S0 - 1) * Hd;
@@ -672,7 +693,7 @@ int gvl_encode_segments(gvl_ctx* ctx, const float* spatial_px, const float* temp
 
 int gvl_splice(gvl_ctx* ctx, const int64_t* ids, int n_ids, const uint16_t* visual, int n_visual, uint16_t* embeds, int* seq_len_out, void* stream) {
   REQUIRE_READY(ctx->has_llm, "gvl_splice");
-  if (!ids || !visual || !embeds || n_ids <= 0 || n_visual < 0 || n_ids > ctx->ids_cap) return fail(ctx, GVL_ERR_ARG, "gvl_splice: bad arguments");
+  if (!ids || (!visual && n_visual > 0) || !embeds || n_ids <= 0 || n_visual < 0 || n_ids > ctx->ids_cap) return fail(ctx, GVL_ERR_ARG, "gvl_splice: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   int idx = -1, cnt = 0;
   std::vector<int> text; text.reserve(n_ids);
@@ -682,10 +703,10 @@ int gvl_splice(gvl_ctx* ctx, const int64_t* ids, int n_ids, const uint16_t* visu
   }
   if (cnt != 1) return fail(ctx, GVL_ERR_ARG, "gvl_splice: exactly one IMAGE_TOKEN_INDEX (-200) expected");
   const int Hd = ctx->cfg.hidden, n_post = n_ids - 1 - idx;
-  HIPCHK(ctx, hipMemcpy(ctx->d_ids, text.data(), text.size() * 4, hipMemcpyHostToDevice));
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_rows(ctx->l_embed, ctx->d_ids, embeds, idx, Hd, st));
-  HIPCHK(ctx, hipMemcpyAsync(embeds + (size_t)idx * Hd, visual, (size_t)n_visual * Hd * 2, hipMemcpyDeviceToDevice, st));
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_rows(ctx->l_embed, ctx->d_ids + idx, embeds + (size_t)(idx + n_visual) * Hd, n_post, Hd, st));
+  // ids travel by value in the kernel arguments: stream ordered, nothing shared between back-to-back splices
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_rows_host_ids(ctx->l_embed, text.data(), idx, embeds, Hd, st));
+  if (n_visual > 0) HIPCHK(ctx, hipMemcpyAsync(embeds + (size_t)idx * Hd, visual, (size_t)n_visual * Hd * 2, hipMemcpyDeviceToDevice, st));
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_rows_host_ids(ctx->l_embed, text.data() + idx, n_post, embeds + (size_t)(idx + n_visual) * Hd, Hd, st));
   if (seq_len_out) *seq_len_out = n_ids - 1 + n_visual;
   return 0;
 }
@@ -735,6 +756,33 @@ int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int S, float* 
   int rc = llm_prefill(ctx, one, 1, e1, &S, st);
   if (rc) return rc;
   if (last_logits) HIPCHK(ctx, hipMemcpyAsync(last_logits, ctx->d_logits, (size_t)ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int gvl_forward_loss(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int S, const int64_t* labels, double* nll_sum, int* n_valid, void* stream) {
+  REQUIRE_READY(ctx->has_llm, "gvl_forward_loss");
+  if (seq_id < 0 || seq_id >= (int)ctx->seqs.size() || !ctx->seqs[seq_id].used) return fail(ctx, GVL_ERR_ARG, "gvl_forward_loss: bad seq");
+  Seq& sq = ctx->seqs[seq_id];
+  if (!embeds || !labels || !nll_sum || !n_valid || S <= 0 || S > sq.max_tokens || S > ctx->cfg.max_prefill) return fail(ctx, GVL_ERR_ARG, "gvl_forward_loss: bad arguments / length");
+  if (sq.pos != 0) return fail(ctx, GVL_ERR_STATE, "gvl_forward_loss: sequence already holds tokens");
+  // shift (logits[:-1] vs labels[1:]) and drop ignore_index (-100) on the host: integer work
+  std::vector<int> rows, tgt;
+  for (int t = 0; t + 1 < S; ++t) {
+    const int64_t y = labels[t + 1];
+    if (y == -100) continue;
+    if (y < 0 || y >= ctx->cfg.vocab) return fail(ctx, GVL_ERR_ARG, "gvl_forward_loss: label out of range");   // torch CrossEntropyLoss raises too
+    rows.push_back(t); tgt.push_back((int)y);
+  }
+  std::vector<float> nll(rows.size());
+  LossReq lr{(int)rows.size(), rows.data(), tgt.data(), nll.data()};
+  hipStream_t st = (hipStream_t)stream;
+  Seq* one[1] = {&sq}; const bf16_t* e1[1] = {embeds};
+  const int rc = llm_prefill(ctx, one, 1, e1, &S, st, &lr);
+  if (rc) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(st));                     // host vectors above are the copy endpoints
+  double acc = 0;
+  for (float v : nll) acc += (double)v;
+  *nll_sum = acc; *n_valid = (int)rows.size();
   return 0;
 }
 

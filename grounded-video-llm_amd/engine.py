@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -243,6 +243,20 @@ class Engine:
         self._chk(self.lib.gvl_decode_greedy_batch(self.ctx, ids, n, int(max_new), -1 if eos_id is None else int(eos_id), buf, nout, self.stream),
                   "gvl_decode_greedy_batch")
         return [[int(buf[i * max_new + j]) for j in range(nout[i])] for i in range(n)]
+
+    def forward_loss(self, embeds: torch.Tensor, labels: Sequence[int]) -> Tuple[float, int]:
+        """Causal-LM loss terms of one sample: (sum of token nll, number of labelled tokens); labels use -100 = ignore."""
+        embeds = embeds.contiguous()
+        S = embeds.shape[0]
+        assert len(labels) == S, "labels must cover every row of inputs_embeds"
+        lab = (C.c_int64 * S)(*[int(v) for v in labels])
+        nll, n = C.c_double(0.0), C.c_int(0)
+        seq = self.seq_alloc(S)
+        try:
+            self._chk(self.lib.gvl_forward_loss(self.ctx, seq, _ptr(embeds), S, lab, C.byref(nll), C.byref(n), self.stream), "gvl_forward_loss")
+        finally:
+            self.seq_free(seq)
+        return nll.value, n.value
 
     def decode_steps(self, seqs: Sequence[int], n_steps: int) -> None:
         """Advance every listed sequence by n_steps greedy tokens (mixed generation steps allowed; asynchronous)."""

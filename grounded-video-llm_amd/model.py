@@ -163,6 +163,40 @@ class LLAVA_NEXT_VIDEO:
         texts = self.tokenizer.batch_decode(out_ids, skip_special_tokens=True)
         return [t.strip() for t in texts]
 
+    # training forward --------------------------------------------------------------------------
+    @torch.inference_mode()
+    def forward(self, samples) -> Dict[str, torch.Tensor]:
+        """LLAVA_NEXT_VIDEO.forward(samples) -> {"loss"} (models/llava_next_video.py:598-614), forward only: prepare_batch
+        (labels / right padding / truncation), encode_images, label + mask splice, then the causal-LM loss of the language model.
+        The padded batch is never materialised: the masked rows of every sample sit at its END (right padding; the dummy visual
+        rows of a 'text' sample), so dropping them leaves positions and causal attention of the kept rows unchanged, and
+        CrossEntropyLoss(mean) over the flattened batch == sum of token losses / number of labelled tokens over the samples."""
+        tk = self.tokenizer
+        tok = (lambda s: tk(s).input_ids) if hasattr(tk("x"), "input_ids") else tk
+        ids, labels, mask = P.prepare_batch(self.llm, samples["text_inputs"], tok, getattr(tk, "bos_token_id", None),
+                                            tk.pad_token_id, tk.eos_token_id, self.max_txt_len)
+        feats = self.encode_images(samples)
+        total, count = 0.0, 0
+        for b, vid in enumerate(samples["video_ids"]):
+            is_text = vid == "text"
+            ml, mm = P.splice_labels(ids[b], labels[b], mask[b], feats.shape[1], is_text)
+            n = int(mm.sum())
+            assert bool((mm[:n] == 1).all()), "attention mask is not a prefix of ones"
+            if bool((ml[n:] != P.IGNORE_INDEX).any()) and not getattr(self, "_warned_pad_label", False):
+                # reference quirk: after truncation `batch_labels[:, -1] = eos` also labels the PAD slot of shorter rows, whose
+                # logits come from a masked pad row; that term is dropped here (it trains nothing but the pad embedding)
+                print("WARNING: label on a masked (padding) position ignored")
+                self._warned_pad_label = True
+            row = [int(t) for t, m in zip(ids[b], mask[b]) if m]
+            emb = self.engine.splice(row, feats[b][:0] if is_text else feats[b])
+            assert emb.shape[0] == n
+            s, c = self.engine.forward_loss(emb, ml[:n].tolist())
+            total, count = total + s, count + c
+        loss = total / count if count else float("nan")         # CrossEntropyLoss over zero targets is nan in torch too
+        return {"loss": torch.tensor(loss, dtype=torch.float32, device=self.engine.device)}
+
+    __call__ = forward
+
     def generate_ids(self, ids_arr, mask, feats, max_new: int) -> List[List[int]]:
         eos = getattr(self.tokenizer, "eos_token_id", None)
         eng = self.engine

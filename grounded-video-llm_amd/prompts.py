@@ -135,3 +135,65 @@ def left_pad_truncate(batch_ids: Sequence[Sequence[int]], pad_id: int, max_txt_l
     if width > max_txt_len:
         ids, mask = ids[:, width - max_txt_len:], mask[:, width - max_txt_len:]
     return ids, mask
+
+
+# ---- training forward: label masking, right-padded batch, label / mask splice -------------------------
+# Per-family corrections of the reference's mask arithmetic (llava_next_video.py:344-407): tokens to take off the instruction
+# length, and the drift it applies to BOTH lengths from the second round on.
+_LABEL_RULE = {"llama3": (1, 0), "vicuna": (2, -1), "phi3.5": (2, +1)}
+
+
+def make_labels(llm: str, input_ids: Sequence[int], prompt: str, tokenize: Callable[[str], List[int]], bos_token_id: Optional[int]) -> np.ndarray:
+    """Labels of one conversation: a copy of input_ids where everything except the assistant answers (+ their eos) is
+    IGNORE_INDEX.  Round / instruction lengths are measured by re-tokenising the text pieces, like the reference does; numpy
+    slice semantics equal torch's, so degenerate (negative) lengths behave identically."""
+    if llm not in _LABEL_RULE:
+        raise ValueError(f"unknown llm {llm!r}")
+    minus, drift = _LABEL_RULE[llm]
+    sep, eos_token = TEMPLATES[llm].separator
+    n_tok = lambda text: len(tokenize_with_image(text, tokenize, bos_token_id))
+    labels = np.asarray(list(input_ids), dtype=np.int64).copy()
+    cur = 1                                                   # the bos slot
+    labels[:cur] = IGNORE_INDEX
+    for i, rnd in enumerate(prompt.split(eos_token)):
+        pieces = rnd.split(sep) if rnd != "" else []
+        if len(pieces) != 2:
+            break
+        d = drift if i >= 1 else 0
+        round_len = n_tok(rnd) + d                            # + eos - bos cancel
+        instr_len = n_tok(pieces[0] + sep) - minus + d
+        labels[cur: cur + instr_len] = IGNORE_INDEX
+        cur += round_len
+    labels[cur:] = IGNORE_INDEX
+    return labels
+
+
+def prepare_batch(llm: str, texts: Sequence[str], tokenize, bos_token_id: Optional[int], pad_token_id: int, eos_token_id: int, max_txt_len: int):
+    """ids / labels / attention mask of a training batch: RIGHT padded (pad id, IGNORE_INDEX, 0), cut to max_txt_len columns;
+    when the cut happens the reference writes eos into the last label column of every row (llava_next_video.py:445-450)."""
+    ids = [tokenize_with_image(t, tokenize, bos_token_id) for t in texts]
+    width = max(len(x) for x in ids)
+    bi = np.full((len(ids), width), pad_token_id, dtype=np.int64)
+    bl = np.full((len(ids), width), IGNORE_INDEX, dtype=np.int64)
+    bm = np.zeros((len(ids), width), dtype=np.int64)
+    for r, (x, t) in enumerate(zip(ids, texts)):
+        bi[r, :len(x)] = x
+        bl[r, :len(x)] = make_labels(llm, x, t, tokenize, bos_token_id)
+        bm[r, :len(x)] = 1
+    if width > max_txt_len:
+        bi, bl, bm = bi[:, :max_txt_len], bl[:, :max_txt_len].copy(), bm[:, :max_txt_len]
+        bl[:, -1] = eos_token_id
+    return bi, bl, bm
+
+
+def splice_labels(input_ids: np.ndarray, labels: np.ndarray, mask: np.ndarray, n_visual: int, is_text: bool):
+    """Labels / mask after the visual rows took the place of the `<image>` id: visual rows carry IGNORE_INDEX; for a text-only
+    sample (video_ids == 'text') the dummy visual rows go to the END with mask 0 (llava_next_video.py:583-590)."""
+    where = np.flatnonzero(np.asarray(input_ids) == IMAGE_TOKEN_INDEX)
+    if where.size != 1:
+        raise ValueError(f"expected exactly one <image> id, found {where.size}")
+    k = int(where[0])
+    ign = np.full(n_visual, IGNORE_INDEX, dtype=np.int64)
+    if is_text:
+        return (np.concatenate([labels[:k], labels[k + 1:], ign]), np.concatenate([mask[:k], mask[k + 1:], np.zeros(n_visual, dtype=np.int64)]))
+    return (np.concatenate([labels[:k], ign, labels[k + 1:]]), np.concatenate([mask[:k], np.ones(n_visual, dtype=np.int64), mask[k + 1:]]))

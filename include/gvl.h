@@ -142,6 +142,16 @@ int gvl_seq_read(gvl_ctx* ctx, int seq_id, int first, int32_t* out_ids_host, int
 /* teacher-forced single step (parity tests): appends token `tok`, returns logits f32 [vocab]. */
 int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, void* stream);
 
+/* ---- training forward ---------------------------------------------------------- */
+/* LLAVA_NEXT_VIDEO.forward(samples)["loss"] for ONE sample (llava_next_video.py:598-614): the causal-LM loss of
+ * language_model(inputs_embeds, labels) -- Phi3ForCausalLM.forward labels branch (modeling_phi3.py:1512-1539; Llama alike):
+ * logits[:-1] against labels[1:], ignore_index -100.  embeds bf16 [seq_len, hidden] (device, the spliced prefix WITHOUT the
+ * masked right padding); labels int64 [seq_len] (host).  Returns the SUM of the token losses and their count, so that a batch
+ * loss is sum(nll_sum) / sum(n_valid) exactly like CrossEntropyLoss(mean) over the flattened padded batch.  Only rows with a
+ * label reach the lm_head.  Uses seq_id's KV pages as scratch (allocate >= seq_len tokens, free afterwards).  Forward only. */
+int gvl_forward_loss(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int seq_len, const int64_t* labels_host,
+                     double* nll_sum, int* n_valid, void* stream);
+
 /* ---- frame pre-processing ---------------------------------------------------- */
 /* frame_transform(image_size = size, mean, std) of the reference (mm_utils/utils.py:153-183, called per frame from
  * inference.py:69-88) for n uint8 RGB frames of one video: torchvision Resize(size, BICUBIC) [shortest edge -> size;

@@ -181,6 +181,87 @@ def left_pad_truncate(batch_ids: Sequence[Sequence[int]], pad_id: int, max_txt_l
 
 
 # --------------------------------------------------------------------------------------
+# f4 -- training forward: label masking (integers) and the causal-LM loss
+# --------------------------------------------------------------------------------------
+def make_labels(llm: str, input_ids: Sequence[int], prompt: str, tokenize: Callable[[str], List[int]], bos_token_id: Optional[int]) -> torch.Tensor:
+    """models/llava_next_video.py:325-407 (make_labels + _make_masks_{llama3,vicuna,phi3}): everything but the assistant
+    answers (and their eos) is IGNORE_INDEX.  Tensor slicing semantics (negative lengths give empty slices) are the reference's."""
+    labels = torch.tensor(list(input_ids), dtype=torch.long).clone()
+    sep, eos_token = _ASSIST[llm]
+    rounds = prompt.split(eos_token)
+    cur_len = 1                      # bos
+    labels[:cur_len] = IGNORE_INDEX
+    for i, rou in enumerate(rounds):
+        if rou == "":
+            break
+        parts = rou.split(sep)
+        if len(parts) != 2:
+            break
+        parts[0] += sep
+        round_len = len(tokenizer_image_token(rou, tokenize, bos_token_id)) + 1 - 1          # + eos - bos
+        if llm == "llama3":
+            instruction_len = len(tokenizer_image_token(parts[0], tokenize, bos_token_id)) - 1
+        elif llm == "vicuna":
+            instruction_len = len(tokenizer_image_token(parts[0], tokenize, bos_token_id)) - 1 - 1
+            if i >= 1:
+                instruction_len -= 1
+                round_len -= 1
+        elif llm == "phi3.5":
+            instruction_len = len(tokenizer_image_token(parts[0], tokenize, bos_token_id)) - 1 - 1
+            if i >= 1:
+                instruction_len += 1
+                round_len += 1
+        else:
+            raise ValueError(llm)
+        labels[cur_len: cur_len + instruction_len] = IGNORE_INDEX
+        cur_len += round_len
+    labels[cur_len:] = IGNORE_INDEX
+    return labels
+
+
+def prepare_batch(llm: str, texts: Sequence[str], tokenize, bos_token_id, pad_token_id: int, eos_token_id: int, max_txt_len: int):
+    """models/llava_next_video.py:428-452: per-text ids / labels / ones-mask, RIGHT pad (pad id / -100 / 0), truncate to
+    max_txt_len columns and overwrite the last label column with eos (for EVERY row, also the padded ones)."""
+    ids = [tokenizer_image_token(t, tokenize, bos_token_id) for t in texts]
+    labs = [make_labels(llm, x, t, tokenize, bos_token_id) for x, t in zip(ids, texts)]
+    W = max(len(x) for x in ids)
+    bi = torch.full((len(ids), W), pad_token_id, dtype=torch.long)
+    bl = torch.full((len(ids), W), IGNORE_INDEX, dtype=torch.long)
+    bm = torch.zeros((len(ids), W), dtype=torch.long)
+    for r, (x, l) in enumerate(zip(ids, labs)):
+        bi[r, :len(x)] = torch.tensor(x, dtype=torch.long)
+        bl[r, :len(x)] = l
+        bm[r, :len(x)] = 1
+    if W > max_txt_len:
+        bi, bl, bm = bi[:, :max_txt_len], bl[:, :max_txt_len].clone(), bm[:, :max_txt_len]
+        bl[:, -1] = eos_token_id
+    return bi, bl, bm
+
+
+def splice_labels(input_ids: torch.Tensor, labels: torch.Tensor, mask: torch.Tensor, n_visual: int, is_text: bool):
+    """Label / mask half of prepare_multimodal_inputs (models/llava_next_video.py:568-596): visual rows are IGNORE_INDEX;
+    a 'text' sample gets its (dummy) visual rows appended at the END with mask 0."""
+    k = int(torch.where(input_ids == IMAGE_TOKEN_INDEX)[0])
+    ign = torch.full((n_visual,), IGNORE_INDEX, dtype=torch.long)
+    if is_text:
+        return torch.cat([labels[:k], labels[k + 1:], ign]), torch.cat([mask[:k], mask[k + 1:], torch.zeros(n_visual, dtype=torch.long)])
+    return torch.cat([labels[:k], ign, labels[k + 1:]]), torch.cat([mask[:k], torch.ones(n_visual, dtype=torch.long), mask[k + 1:]])
+
+
+def causal_lm_loss_terms(logits: torch.Tensor, labels: torch.Tensor):
+    """Phi3ForCausalLM.forward labels branch (models/modeling_phi3.py:1527-1539): logits.float(); logits[:-1] vs labels[1:];
+    CrossEntropyLoss(ignore_index=-100).  Returns (sum of token nll, number of labelled tokens); loss = sum / count."""
+    lg = logits.float()[:-1]
+    y = labels[1:]
+    keep = y != IGNORE_INDEX
+    if int(keep.sum()) == 0:
+        return 0.0, 0
+    lp = torch.log_softmax(lg[keep], dim=-1)
+    nll = -lp[torch.arange(lp.shape[0]), y[keep]]
+    return float(nll.double().sum()), int(keep.sum())
+
+
+# --------------------------------------------------------------------------------------
 # a2 / a3 -- CLIP ViT-L/14-336 (models/modeling_clip.py)
 # --------------------------------------------------------------------------------------
 def clip_embeddings(px: torch.Tensor, W: Dict[str, torch.Tensor], emu=False, prefix="vision_model.") -> torch.Tensor:

@@ -265,6 +265,88 @@ def g_int(ns):
     print("wrote integer_paths.json")
 
 
+def g_train(ns):
+    """Training forward: make_labels / prepare_batch / prepare_multimodal_inputs label+mask splice (integers)
+    and the causal-LM loss of Phi3ForCausalLM / LlamaForCausalLM (fp32 CPU reference) on seeded inputs."""
+    L, T = ns.llava, ns.template
+    IMG, GND = T.DEFAULT_IMAGE_TOKEN, T.GROUNDING_TOKEN
+
+    class Tok:                                  # toy whitespace tokenizer (BOS=1, EOS=2, PAD=0); same word hash as g_int
+        bos_token_id, eos_token_id, pad_token_id = 1, 2, 0
+
+        def __call__(self, s):
+            return type("O", (), {"input_ids": [1] + [3 + (sum(map(ord, w)) % 90) for w in s.split()]})()
+
+    class TokPadIsEos(Tok):                     # llama3-style: pad == eos -> make_labels adds the eos count to total_len
+        pad_token_id = 2
+
+    class Skel(L.LLAVA_NEXT_VIDEO):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.embed = torch.nn.Embedding(100, 8)
+
+        def get_input_embeddings(self):
+            return self.embed
+
+    tm = {"phi3.5": T.Phi_3_5_Template, "llama3": T.LLaMA3_Template, "vicuna": T.Vicuna_Template}
+    convs = {
+        "ground1": [{"from": "human", "value": IMG + " " + GND + "\nWhen does 'a person opens the door' occur in the video?"},
+                    {"from": "gpt", "value": "From <36> to <64>."}],
+        "qa2": [{"from": "human", "value": IMG + "\nWhat is the person doing?"}, {"from": "gpt", "value": "Opening a door ."},
+                {"from": "human", "value": "And after that ?"}, {"from": "gpt", "value": "They walk away slowly ."}],
+        "qa3": [{"from": "human", "value": IMG + "\nq one"}, {"from": "gpt", "value": "a one"},
+                {"from": "human", "value": "q two two"}, {"from": "gpt", "value": "a two"},
+                {"from": "human", "value": "q three"}, {"from": "gpt", "value": "a three three three"}],
+        "text": [{"from": "human", "value": IMG + "\nTell me a story about doors ."}, {"from": "gpt", "value": "Once upon a time ."}],
+    }
+    cases = {}
+    for llm, tcls in tm.items():
+        for tname, tok in (("pad0", Tok()), ("padeos", TokPadIsEos())):
+            for max_txt_len in (4096, 48):
+                sk = Skel()
+                sk.llm, sk.dtype, sk.separator, sk.tokenizer, sk.max_txt_len = llm, torch.float32, tcls.separator, tok, max_txt_len
+                texts = [tcls().encode(c) for c in convs.values()]
+                video_ids = ["vid", "vid", "vid", "text"]
+                ids, labels, mask = sk.prepare_batch(texts)
+                feats = torch.zeros(len(texts), 5, 8)
+                emb, mlabels, mmask = sk.prepare_multimodal_inputs(ids, labels, mask, feats, video_ids)
+                cases[f"{llm}|{tname}|{max_txt_len}"] = dict(
+                    texts=texts, video_ids=video_ids, n_visual=5, input_ids=ids.tolist(), labels=labels.tolist(), attention_mask=mask.tolist(),
+                    mm_labels=mlabels.tolist(), mm_mask=mmask.tolist(), emb_shape=list(emb.shape))
+    with open(os.path.join(OUT, "train_labels.json"), "w") as f:
+        json.dump(dict(cases=cases), f, indent=0)
+    print("wrote train_labels.json", len(cases), "cases")
+
+    # causal-LM loss (modeling_phi3.py:1529-1539, modeling_llama.py labels branch): shift, ignore_index -100, mean over valid tokens
+    out, meta = {}, {}
+    m, W = _phi(ns, 64, 128, 2, 4, 4, 100, "g.phi.tiny")
+    for name, S, lo in (("a", 40, 25), ("b", 70, 60), ("c", 9, 0)):
+        x = synth.det_tensor("g.train.phi." + name, (1, S, 64), 0.5)
+        lab = torch.tensor([(7 * i + 3 * len(name) + S) % 97 + 3 if i >= lo and i != lo + 2 else -100 for i in range(S)])
+        r = m(inputs_embeds=x, labels=lab[None], use_cache=False)
+        lp = torch.log_softmax(r.logits[0, :-1].float(), -1)
+        valid = lab[1:] != -100
+        nll = -(lp[torch.arange(S - 1)[valid], lab[1:][valid]])
+        assert abs(float(nll.mean()) - float(r.loss)) < 1e-5
+        out[f"phi_{name}_loss"] = r.loss
+        out[f"phi_{name}_nll_sum"] = nll.double().sum()
+        meta[f"phi_{name}"] = dict(x="g.train.phi." + name, S=S, labels=lab.tolist(), n_valid=int(valid.sum()))
+    # right-padded batch of (a, b) with attention_mask: the batch loss must equal sum(nll) / sum(n_valid) of the members on their own
+    try:
+        xa = synth.det_tensor("g.train.phi.a", (1, 40, 64), 0.5)
+        xb = synth.det_tensor("g.train.phi.b", (1, 70, 64), 0.5)
+        xpad = torch.cat([torch.cat([xa, torch.zeros(1, 30, 64)], 1), xb], 0)
+        la = torch.tensor(meta["phi_a"]["labels"] + [-100] * 30)
+        lb = torch.tensor(meta["phi_b"]["labels"])
+        am = torch.cat([torch.cat([torch.ones(1, 40), torch.zeros(1, 30)], 1), torch.ones(1, 70)], 0).long()
+        rb = m(inputs_embeds=xpad, attention_mask=am, labels=torch.stack([la, lb]), use_cache=False)
+        out["phi_batch_ab_loss"] = rb.loss
+        print("padded batch loss", float(rb.loss), "vs members", float((out["phi_a_nll_sum"] + out["phi_b_nll_sum"]) / (meta["phi_a"]["n_valid"] + meta["phi_b"]["n_valid"])))
+    except Exception as e:                                     # installed transformers may lack the 4.40 mask helper
+        print("padded-batch case not generated:", repr(e)[:200])
+    save("train_loss", dict(cfg=dict(kind="phi3", hidden=64, inter=128, layers=2, heads=4, kv_heads=4, vocab=100), seed="g.phi.tiny", cases=meta), **out)
+
+
 def g_pre(ns):
     """Frame pre-processing goldens: PIL.Image.resize(BICUBIC) -- the library the reference's frame_transform calls
     (mm_utils/utils.py:172-174 through torchvision) -- on seeded uint8 frames.  torchvision itself is not installed: the size / crop
@@ -289,7 +371,7 @@ def g_pre(ns):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["int", "clip", "iv2", "phi3", "llama", "glue", "pre"]
+    which = sys.argv[1:] or ["int", "clip", "iv2", "phi3", "llama", "glue", "pre", "train"]
     ns = ref_shims.load_reference() if any(w != "pre" for w in which) else None
     for w in which:
-        {"int": g_int, "clip": g_clip, "iv2": g_iv2, "phi3": g_phi3, "llama": g_llama, "glue": g_glue, "pre": g_pre}[w](ns)
+        {"int": g_int, "clip": g_clip, "iv2": g_iv2, "phi3": g_phi3, "llama": g_llama, "glue": g_glue, "pre": g_pre, "train": g_train}[w](ns)

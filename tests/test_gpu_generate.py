@@ -69,3 +69,54 @@ def test_generate_matches_oracle(llm):
                               do_sample=False, num_beams=1, max_new_tokens=10)[0] for i in range(3)]
     assert texts3 == singles and texts3[0] == texts[0]
     model.engine.close()
+
+
+@pytest.mark.parametrize("llm", ["phi3.5", "llama3"])
+def test_training_forward_loss_matches_oracle(llm):
+    """f4 end to end: LLAVA_NEXT_VIDEO.forward(samples)["loss"] (llava_next_video.py:598-614) on a batch of two video samples and
+    one text-only sample with conversations of different lengths, against the oracle pipeline on the same seeded weights:
+    prepare_batch -> encode_images -> splice (+labels/mask) -> decoder -> shifted cross entropy over the right-padded batch."""
+    hid, vocab = 128, 640
+    kind = "phi3" if llm == "phi3.5" else "llama"
+    short, long = synth.longrope_factors(32)
+    geo = E.TowerGeometry(llm=llm, clip_hidden=64, clip_inter=128, clip_layers=3, clip_heads=4, iv2_dim=64, iv2_inter=128, iv2_depth=3,
+                          iv2_heads=4, hidden=hid, inter=256, layers=2, heads=4, kv_heads=4 if kind == "phi3" else 2, vocab=vocab,
+                          rope_short=short if kind == "phi3" else None, rope_long=long if kind == "phi3" else None,
+                          rope_theta=10000.0 if kind == "phi3" else 500000.0, max_seq=2048, max_segs=2, kv_pages=40, max_prefill=1024)
+    sd = {"vision_tower": synth.clip_weights(64, 128, 3, seed="gen.clip"),
+          "video_encoder": synth.iv2_weights(64, 128, 3, 2, seed="gen.iv2"),
+          "projectors": synth.projector_weights(llm, hid, 64, 64, seed="gen.proj"),
+          "language_model": synth.llm_weights(kind, hid, 256, 2, 4, geo.kv_heads, vocab, True, seed="gen.llm")}
+    tok = SyntheticTokenizer(vocab, 300)
+    model = LLAVA_NEXT_VIDEO(stage="sft", max_txt_len=256, num_frames=4, num_segs=2, num_temporal_tokens=300, lora=False, llm=llm,
+                             geometry=geo, tokenizer=tok, state_dicts=sd, device=DEV)
+    T = P.TEMPLATES[llm]
+    convs = [[{"from": "human", "value": "<image> <timestamp_grounding>\nWhen does the person open the door ?"}, {"from": "gpt", "value": "From <36> to <64> ."}],
+             [{"from": "human", "value": "<image>\nWhat happens ?"}, {"from": "gpt", "value": "A dog jumps over the fence ."},
+              {"from": "human", "value": "And then ?"}, {"from": "gpt", "value": "It runs away quickly ."}],
+             [{"from": "human", "value": "<image>\nTell me about doors ."}, {"from": "gpt", "value": "Doors open and close ."}]]
+    texts = [T.encode(c) for c in convs]
+    video_ids = ["v0", "v1", "text"]
+    sp = synth.det_tensor("trn.sp", (3, 2, 3, 336, 336))
+    tp = synth.det_tensor("trn.tp", (3, 4, 3, 224, 224))
+    samples = {"text_inputs": texts, "video_ids": video_ids, "spatial_pixel_values": sp.to(DEV), "temporal_pixel_values": tp.to(DEV)}
+    got = float(model.forward(samples)["loss"])
+    # --- oracle
+    ids, labels, mask = O.prepare_batch(llm, texts, tok, tok.bos_token_id, tok.pad_token_id, tok.eos_token_id, model.max_txt_len)
+    vis = O.encode_images(sp, tp, sd["vision_tower"], sd["video_encoder"], sd["projectors"], llm, clip_layers=3, clip_heads=4, iv2_depth=3, iv2_heads=4, emu=True)
+    ocfg = O.LLMConfig(kind, hid, 256, 2, 4, geo.kv_heads, vocab, 1e-5, geo.rope_theta, 131072, 4096, geo.rope_short, geo.rope_long)
+    tot, cnt = 0.0, 0
+    for b in range(3):
+        is_text = video_ids[b] == "text"
+        ml, mm = O.splice_labels(ids[b], labels[b], mask[b], vis.shape[1], is_text)
+        n = int(mm.sum())
+        row = ids[b][mask[b] == 1]
+        emb = O.splice(row, vis[b][:0] if is_text else vis[b], sd["language_model"]["model.embed_tokens.weight"], emu=True)
+        assert emb.shape[0] == n
+        lg = O.llm_forward(ocfg, sd["language_model"], emb, True, None, 0, last_only=False).to(bf)
+        s, c = O.causal_lm_loss_terms(lg, ml[:n])
+        tot, cnt = tot + s, cnt + c
+    assert cnt > 10
+    print(f"[parity] forward({llm}) loss gpu {got:.5f} oracle {tot / cnt:.5f} over {cnt} labelled tokens")
+    assert abs(got - tot / cnt) < 1e-2 * (tot / cnt)
+    model.engine.close()

@@ -181,3 +181,46 @@ def test_preprocess_oracle_matches_pillow():
         assert x.dtype == np.float32 and np.array_equal(x, ref)
     assert O.tv_resized_size(360, 640, 224) == (224, 398) and O.tv_resized_size(400, 226, 224) == (396, 224)
     assert O.tv_center_crop_offsets(224, 398, 224) == (0, 87) and O.tv_center_crop_offsets(229, 224, 224) == (2, 0)   # round-half-even: 2.5 -> 2
+
+
+def test_training_labels_oracle_and_host_match_reference():
+    """f4 integer path: make_labels / prepare_batch / prepare_multimodal_inputs labels+mask of the reference (generated by
+    oracle/make_golden.py g_train with a toy tokenizer) vs the oracle restatement AND the product's host mirror -- bit-exact."""
+    from grounded_video_llm_amd import prompts as P
+    with open(os.path.join(GOLDEN, "train_labels.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) == 12
+    tok = lambda s: [1] + [3 + (sum(map(ord, w)) % 90) for w in s.split()]
+    n_answer = 0
+    for key, c in cases.items():
+        llm, tname, mtl = key.split("|")
+        pad = 0 if tname == "pad0" else 2
+        for impl, as_list in ((O, lambda t: t.tolist()), (P, lambda a: np.asarray(a).tolist())):
+            ids, labels, mask = impl.prepare_batch(llm, c["texts"], tok, 1, pad, 2, int(mtl))
+            assert as_list(ids) == c["input_ids"] and as_list(labels) == c["labels"] and as_list(mask) == c["attention_mask"], f"{key} {impl.__name__}"
+            for r, vid in enumerate(c["video_ids"]):
+                ml, mm = impl.splice_labels(ids[r], labels[r], mask[r], c["n_visual"], vid == "text")
+                assert as_list(ml) == c["mm_labels"][r] and as_list(mm) == c["mm_mask"][r], f"{key} row {r} {impl.__name__}"
+        n_answer += sum(v != -100 for row in c["mm_labels"] for v in row)
+    assert n_answer > 100                                      # the fixtures do contain supervised tokens
+
+
+def test_training_loss_oracle_matches_reference():
+    """f4 FP path: oracle forward (fp32) + causal_lm_loss_terms vs Phi3ForCausalLM(labels=...).loss of the reference, incl. the
+    right-padded batch identity loss(batch) == sum(nll) / sum(count) over its members."""
+    meta, g = load_golden("train_loss")
+    c = meta["cfg"]
+    short, long = synth.longrope_factors(c["hidden"] // c["heads"])
+    cfg = O.LLMConfig("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], 1e-5, 10000.0, 131072, 4096, short, long)
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
+    tot, cnt = 0.0, 0
+    for name, m in meta["cases"].items():
+        x = synth.det_tensor(m["x"], (1, m["S"], c["hidden"]), 0.5)[0]
+        logits = O.llm_forward(cfg, W, x, False, None, 0, last_only=False)
+        s, n = O.causal_lm_loss_terms(logits, torch.tensor(m["labels"]))
+        assert n == m["n_valid"]
+        assert abs(s / n - float(g[name + "_loss"])) < 2e-5 * abs(float(g[name + "_loss"])), name
+        assert abs(s - float(g[name + "_nll_sum"])) < 2e-5 * abs(s)
+        if name in ("phi_a", "phi_b"):
+            tot, cnt = tot + s, cnt + n
+    assert abs(tot / cnt - float(g["phi_batch_ab_loss"])) < 2e-5 * float(g["phi_batch_ab_loss"])

@@ -820,6 +820,12 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
   const int es = a.out_f32 ? 4 : 2;
   const bool stg_ok = a.N % 16 == 0 && a.grp_rows == 0 && ((size_t)a.ldc * es) % 16 == 0 && ((uintptr_t)a.C & 15) == 0 &&
                       (!a.resid || (((size_t)a.ldr * es) % 16 == 0 && ((uintptr_t)a.resid & 15) == 0));
+  if (cfg == 21 && a.tile_cfg == 21 && env_cfg == 0) {   // planner remainder / tail launches only
+    static const int small64 = [] { const char* e = getenv("GVL_GEMM_SMALL64"); return e ? atoi(e) : 3; }();   // 0 = off (A/B); measured -0.6 ms of GEMM time per clip
+    static const int n_cu2 = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
+    const long t128 = (long)((a.M - a.m_begin + 127) / 128) * ((a.N + 127) / 128);
+    if (small64 && t128 * 2 <= (long)small64 * n_cu2) cfg = 22;
+  }
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 0>(a, st);            // plain lock-step baseline (tests / A-B)
     // cfg 21 / 82 run the LDS-staged whole-row epilogue (compile-time specialised per fused-epilogue code) whenever the
@@ -832,6 +838,18 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
         default: break;
       }
       return launch_cfg<128, 128, 2, 2, 1, -1>(a, st);
+    }
+    // cfg 22 = 64x128 tiles, same kernel (wave tile 32x64): twice the blocks of cfg 21 for launches that would leave most CUs with
+    // ONE 128x128 block (remainder rows / tail columns of the planner: 193-264 tiles on 512 slots).  Same k-order per output
+    // element as every other cfg, so the results are bit-identical.
+    case 22: {
+      if (stg_ok) switch (epi) {
+#define S_CASE(E) case E: return launch_cfg<64, 128, 2, 2, 1, E, 1>(a, st);
+        S_CASE(0) S_CASE(32) S_CASE(33) S_CASE(34) S_CASE(3) S_CASE(44) S_CASE(56) S_CASE(8) S_CASE(4) S_CASE(36)
+#undef S_CASE
+        default: break;
+      }
+      return launch_cfg<64, 128, 2, 2, 1, -1>(a, st);
     }
     case 82: {
       if (stg_ok) switch (epi) {

@@ -22,7 +22,7 @@ def _rand(name, shape, std=1.0):
     return synth.det_tensor(name, shape, std).to(DEV)
 
 
-@pytest.mark.parametrize("cfg", [1, 0, 21, 82, 85])
+@pytest.mark.parametrize("cfg", [1, 0, 21, 22, 82, 85])
 @pytest.mark.parametrize("M,N,K", [(100, 64, 64), (300, 256, 128), (577, 1024, 640), (1000, 1408, 1408), (1, 128, 192), (513, 4224, 256), (259, 72, 64)])
 def test_gemm_plain(eng, M, N, K, cfg):
     A = _rand(f"gA{M}{N}{K}", (M, K)).to(bf)

@@ -163,6 +163,23 @@ class LLAVA_NEXT_VIDEO:
         texts = self.tokenizer.batch_decode(out_ids, skip_special_tokens=True)
         return [t.strip() for t in texts]
 
+    @torch.inference_mode()
+    def generate_shared(self, samples, prompts: Sequence[str], **generate_kwargs) -> List[str]:
+        """Several prompts about ONE video.  The reference's inference.py calls generate() once per prompt (grounding / QA /
+        referring, inference.py:178-182) and re-runs both vision towers every time; here the video is encoded once and the prompts
+        are prefilled and decoded together.  Texts are identical to one generate() call per prompt (batch-invariant kernels)."""
+        if generate_kwargs.get("do_sample", False) or generate_kwargs.get("num_beams", 1) != 1:
+            raise NotImplementedError("this tier implements greedy decoding (do_sample=False, num_beams=1)")
+        if samples["spatial_pixel_values"].shape[0] != 1:
+            raise ValueError("generate_shared takes the pixel tensors of one video")
+        max_new = int(generate_kwargs.get("max_new_tokens", 2048))
+        ids = [self.tokenizer_image_token(t) for t in prompts]
+        pad_id = getattr(self.tokenizer, "pad_token_id", 0) or 0
+        ids_arr, mask = P.left_pad_truncate(ids, pad_id, self.max_txt_len)
+        feats = self.encode_images(samples).expand(len(prompts), -1, -1)
+        out_ids = self.generate_ids(ids_arr, mask, feats, max_new)
+        return [t.strip() for t in self.tokenizer.batch_decode(out_ids, skip_special_tokens=True)]
+
     # training forward (SURVEY.md §8 f4) --------------------------------------------------------------------------
     @torch.inference_mode()
     def forward(self, samples) -> Dict[str, torch.Tensor]:

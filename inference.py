@@ -57,6 +57,7 @@ def parse_args(argv=None):
     p.add_argument("--max_new_tokens", type=int, default=2048)
     p.add_argument("--temperature", type=float, default=0.2)
     p.add_argument("--top_p", type=float, default=None)
+    p.add_argument("--share_visual", type=_bool, default=False, help="encode the video ONCE for the three prompts and batch them (the reference re-encodes per prompt); greedy only")
     p.add_argument("--synthetic", action="store_true", help="seeded random weights / frames / tokenizer (offline image)")
     p.add_argument("--synthetic_scale", type=str, default="small", choices=["small", "full"])
     return p.parse_args(argv)
@@ -75,6 +76,11 @@ def read_frames(video_path: str, num_frames: int):
     return frames, fps, vlen, vlen / fps
 
 
+def create_prompt(args, mode: str, duration: float) -> str:
+    text = {"grounding": args.prompt_grounding, "qa": args.prompt_videoqa, "referring": args.prompt_referring}[mode]
+    return P.build_prompt(args.llm, mode, text, duration, args.num_temporal_tokens)
+
+
 def create_inputs(args, mode: str, frames_u8: torch.Tensor, duration: float, engine):
     """inference.py:65-134 of the reference.  frame_transform (Resize bicubic + CenterCrop + ToTensor + Normalize,
     mm_utils/utils.py:153-183) runs on the GPU, bit-exact to the reference's PIL chain (gvl_preprocess_frames): the uint8
@@ -83,8 +89,7 @@ def create_inputs(args, mode: str, frames_u8: torch.Tensor, duration: float, eng
     temporal = engine.preprocess_frames(fr, 224, P.INTERNVIDEO_MEAN, P.INTERNVIDEO_STD).unsqueeze(0)
     sel = P.spatial_indices(args.num_frames, args.num_segs)
     spatial = engine.preprocess_frames(fr[sel], 336, P.OPENAI_DATASET_MEAN, P.OPENAI_DATASET_STD).unsqueeze(0)
-    text = {"grounding": args.prompt_grounding, "qa": args.prompt_videoqa, "referring": args.prompt_referring}[mode]
-    prompt = P.build_prompt(args.llm, mode, text, duration, args.num_temporal_tokens)
+    prompt = create_prompt(args, mode, duration)
     return {"video_ids": [args.video_path], "question_ids": [args.video_path], "prompts": [prompt],
             "temporal_pixel_values": temporal.to(args.device), "spatial_pixel_values": spatial.to(args.device)}
 
@@ -127,9 +132,17 @@ def main(argv=None):
 
     kw = {"do_sample": args.do_sample, "num_beams": args.num_beams, "max_new_tokens": args.max_new_tokens, "temperature": args.temperature, "top_p": args.top_p}
     outs = {}
-    for mode in ("grounding", "qa", "referring"):
-        samples = create_inputs(args, mode, frames, duration, model.engine)
-        outs[mode] = (samples["prompts"][0], model.generate(samples, **kw)[0])
+    modes = ("grounding", "qa", "referring")
+    if args.share_visual and not args.do_sample:
+        # one pre-processing + one vision encode for the three prompts (the reference re-encodes the video per prompt)
+        per_mode = [create_inputs(args, mode, frames, duration, model.engine) for mode in modes[:1]]
+        prompts = [per_mode[0]["prompts"][0]] + [create_prompt(args, mode, duration) for mode in modes[1:]]
+        texts = model.generate_shared(per_mode[0], prompts, **kw)
+        outs = {mode: (p, t) for mode, p, t in zip(modes, prompts, texts)}
+    else:
+        for mode in modes:
+            samples = create_inputs(args, mode, frames, duration, model.engine)
+            outs[mode] = (samples["prompts"][0], model.generate(samples, **kw)[0])
     print("\n******grounding example******")
     print(outs["grounding"][0])
     print(P.parse_time_interval(outs["grounding"][1], duration, args.num_temporal_tokens, args.llm if args.llm != "vicuna" else "llama3"))

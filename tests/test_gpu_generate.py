@@ -68,6 +68,10 @@ def test_generate_matches_oracle(llm):
     singles = [model.generate({"prompts": [prompts[i]], "spatial_pixel_values": sp3[i:i + 1], "temporal_pixel_values": tp3[i:i + 1], "video_ids": ["x"]},
                               do_sample=False, num_beams=1, max_new_tokens=10)[0] for i in range(3)]
     assert texts3 == singles and texts3[0] == texts[0]
+    # several prompts about ONE video: encoded once, prompts batched -- same texts as one generate() per prompt
+    one = {"spatial_pixel_values": sp3[1:2], "temporal_pixel_values": tp3[1:2], "video_ids": ["x"]}
+    shared = model.generate_shared(one, prompts, do_sample=False, num_beams=1, max_new_tokens=10)
+    assert shared == [model.generate({**one, "prompts": [p]}, do_sample=False, num_beams=1, max_new_tokens=10)[0] for p in prompts]
     model.engine.close()
 
 

@@ -224,17 +224,31 @@ class LLAVA_NEXT_VIDEO:
         # un-padded length -- identical maths to the masked left-padded batch.  Prefill runs over the packed rows of the batch
         # (gvl_prefill_varlen) and the greedy decode of the whole batch runs together (gvl_decode_greedy_batch: one weight stream
         # per token for groups of 4 / 2 / 1 sequences)
-        seqs, embs = [], []
-        try:
-            for b in range(ids_arr.shape[0]):
-                row = [int(t) for t, m in zip(ids_arr[b], mask[b]) if m]
-                embs.append(eng.splice(row, feats[b]))
-                seqs.append(eng.seq_alloc(embs[-1].shape[0] + max_new))
-            eng.prefill_batch(seqs, embs)
-            return eng.decode_greedy_batch(seqs, max_new, eos)
-        finally:
-            for seq in seqs:
-                eng.seq_free(seq)
+        # The KV pool bounds how many samples are resident at once: the batch is processed in as many groups as it takes.
+        from .lib import GvlError, ERR_OOM
+        out: List[List[int]] = []
+        b, n = 0, ids_arr.shape[0]
+        while b < n:
+            seqs, embs = [], []
+            try:
+                while b + len(seqs) < n:
+                    i = b + len(seqs)
+                    row = [int(t) for t, m in zip(ids_arr[i], mask[i]) if m]
+                    emb = eng.splice(row, feats[i])
+                    try:
+                        seqs.append(eng.seq_alloc(emb.shape[0] + max_new))
+                    except GvlError as e:
+                        if e.status == ERR_OOM and seqs:
+                            break                      # pool full: run what fits, the rest in the next group
+                        raise
+                    embs.append(emb)
+                eng.prefill_batch(seqs, embs)
+                out += eng.decode_greedy_batch(seqs, max_new, eos)
+            finally:
+                for seq in seqs:
+                    eng.seq_free(seq)
+            b += len(seqs)
+        return out
 
 
 def load_reference_checkpoints(llm: str, pretrained_video_path: str, pretrained_vision_proj_llm_path: str):

@@ -283,3 +283,19 @@ def test_scheduler_edge_cases():
     assert [op[1] for op in eng.log if op[0] == "prefill"][:2] == [[60, 60], [60, 60]] and len(out) == 4
     with pytest.raises(ValueError):
         serve.ClipScheduler(eng, None, max_active=0)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/gvl.h compiles as strict C99 (nothing but <stdint.h>), a C program links libgvl.so and -- on a host without a GPU --
+    gets GVL_ERR_NOGPU from gvl_create: the boundary is a C ABI, not a Python extension."""
+    L.load()                                                  # builds the library if needed
+    exe = str(tmp_path / "abi_consumer")
+    libdir = os.path.dirname(L.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c", "abi_consumer.c"), "-o", exe, "-L", libdir, "-lgvl", f"-Wl,-rpath,{libdir}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    if not torch.cuda.is_available():
+        assert "create=-5" in r.stdout and "no CPU fallback" in r.stdout

@@ -71,7 +71,7 @@ struct gvl_ctx {
   // decode buffers
   bf16_t *d_x = nullptr, *d_qkv = nullptr, *d_q = nullptr, *d_attn = nullptr, *d_act = nullptr;
   // (all decode work buffers hold GVL_MAX_DECODE_BATCH rows: one per sequence of a batched decode step)
-  float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_seq_tok = nullptr, *d_seq_out = nullptr, *d_ids = nullptr;
+  float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_seq_tok = nullptr, *d_seq_out = nullptr;
   int nsplit = 16, outlist_cap = 8192, ids_cap = 16384;
   // frame pre-processing scratch (tmp image + tap tables), grown on demand
   void* pre_scratch = nullptr; size_t pre_scratch_bytes = 0;
@@ -122,6 +122,8 @@ void* arena_l_alloc(gvl_ctx* c, size_t bytes) {
   return c->arena_l + off;
 }
 #define LALLOC(var, type, count) type* var = (type*)arena_l_alloc(ctx, (size_t)(count) * sizeof(type)); if (!var) return fail(ctx, GVL_ERR_OOM, "LLM workspace arena too small for " #var)
+// workspace arenas are bump allocators: a call takes a mark and every exit path -- errors included -- must give the space back
+struct ArenaScope { size_t& off; const size_t mark; explicit ArenaScope(size_t& o) : off(o), mark(o) {} ~ArenaScope() { off = mark; } };
 
 const Tensor* find(gvl_ctx* c, const std::string& n) { auto it = c->w.find(n); return it == c->w.end() ? nullptr : &it->second; }
 
@@ -191,7 +193,7 @@ int clip_encode(gvl_ctx* ctx, const float* px, int n, float* out, hipStream_t st
   const gvl_config& f = ctx->cfg;
   const int C = f.clip_hidden, H = f.clip_heads, S = ctx->c_S, P = ctx->c_P, M = n * S, I = f.clip_inter, D = ctx->c_D, Dr = ctx->c_Dr;
   const int tiles = (S + 63) / 64;
-  const size_t mark = ctx->arena_off;
+  ArenaScope arena_scope(ctx->arena_off);
   AALLOC(x, float, (size_t)M * C); AALLOC(h, bf16_t, (size_t)M * C); AALLOC(qkv, bf16_t, (size_t)M * 3 * C);
   AALLOC(att, bf16_t, (size_t)M * C); AALLOC(mlp, bf16_t, (size_t)M * I);
   AALLOC(pA, bf16_t, (size_t)n * P * ctx->c_Kp); AALLOC(pO, bf16_t, (size_t)n * P * C);
@@ -218,7 +220,6 @@ int clip_encode(gvl_ctx* ctx, const float* px, int n, float* out, hipStream_t st
       RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
   }
   RUN(GVL_PROF_OTHER, 0, gvl_launch_strip_cls(x, out, n, S, C, 4, st));
-  ctx->arena_off = mark;
   return 0;
 }
 
@@ -226,7 +227,7 @@ int iv2_encode(gvl_ctx* ctx, const float* px, int n, bf16_t* out, hipStream_t st
   const gvl_config& f = ctx->cfg;
   const int C = f.iv2_dim, H = f.iv2_heads, S = ctx->v_S, TL = ctx->v_TL, M = n * S, I = f.iv2_inter, D = ctx->v_D, Dr = ctx->v_Dr;
   const int tiles = (S + 63) / 64;
-  const size_t mark = ctx->arena_off;
+  ArenaScope arena_scope(ctx->arena_off);
   AALLOC(x, bf16_t, (size_t)M * C); AALLOC(h, bf16_t, (size_t)M * C); AALLOC(qkv, bf16_t, (size_t)M * 3 * C);
   AALLOC(att, bf16_t, (size_t)M * C); AALLOC(mlp, bf16_t, (size_t)M * I);
   AALLOC(pA, bf16_t, (size_t)n * TL * ctx->v_Kp); AALLOC(pO, bf16_t, (size_t)n * TL * C);
@@ -252,7 +253,6 @@ int iv2_encode(gvl_ctx* ctx, const float* px, int n, bf16_t* out, hipStream_t st
       RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
   }
   RUN(GVL_PROF_OTHER, 0, gvl_launch_strip_cls(x, out, n, S, C, 2, st));
-  ctx->arena_off = mark;
   return 0;
 }
 
@@ -261,7 +261,7 @@ int build_visual(gvl_ctx* ctx, const float* clip_feats, const bf16_t* iv2_feats,
   const int Hd = f.hidden, L = ctx->tok_per_seg, IT = ctx->img_tok, ST = ctx->seg_tok, T = f.iv2_frames_per_seg;
   const bool phi = f.llm_kind == GVL_LLM_PHI3;
   const int cin = phi ? 4 * f.clip_hidden : f.clip_hidden;
-  const size_t mark = ctx->arena_off;
+  ArenaScope arena_scope(ctx->arena_off);
   AALLOC(A1, bf16_t, (size_t)n * IT * cin); AALLOC(T1, bf16_t, (size_t)n * IT * Hd);
   AALLOC(A2, bf16_t, (size_t)n * ST * f.iv2_dim); AALLOC(T2, bf16_t, (size_t)n * ST * Hd);
   AALLOC(nl1, bf16_t, Hd); AALLOC(nl2, bf16_t, Hd);
@@ -281,7 +281,6 @@ int build_visual(gvl_ctx* ctx, const float* clip_feats, const bf16_t* iv2_feats,
   } else {
     RUN(GVL_PROF_OTHER, 0, gvl_launch_bcast_row(ctx->newline, visual, n, L, IT + ST, Hd, st));
   }
-  ctx->arena_off = mark;
   return 0;
 }
 
@@ -302,7 +301,7 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
   for (int b = 0; b < nb; ++b) { off[b + 1] = off[b] + lens[b]; uniform = uniform && lens[b] == lens[0]; }
   const int M = off[nb], S0 = lens[0], P0 = (S0 + 63) / 64;
   if (nb > 1 && uniform && nb * P0 > GVL_MAX_DECODE_BATCH * 64) uniform = false;   // page-id list below holds 256 entries
-  const size_t mark = ctx->arena_l_off;
+  ArenaScope arena_scope(ctx->arena_l_off);
   LALLOC(x, bf16_t, (size_t)M * Hd); LALLOC(h, bf16_t, (size_t)M * Hd); LALLOC(qkv, bf16_t, (size_t)M * qkvw);
   LALLOC(att, bf16_t, (size_t)M * H * Dr); LALLOC(act, bf16_t, (size_t)M * I); LALLOC(Q, bf16_t, (size_t)M * H * D);
   const int* table = sqs[0]->d_block_table;
@@ -376,7 +375,6 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
     RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sqs[b]->d_pos, lens[b], st));
     sqs[b]->pos = lens[b]; sqs[b]->n_gen = 1;
   }
-  ctx->arena_l_off = mark;
   return 0;
 }
 
@@ -557,7 +555,6 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
     ok &= hipMalloc((void**)&ctx->d_seq_pos, (size_t)gvl_ctx::kMaxSeqs * 4) == hipSuccess;
     if (!ok) { gvl_destroy(ctx); return fail(nullptr, GVL_ERR_OOM, "hipMalloc(decode buffers) failed"); }
   }
-  if (hipMalloc((void**)&ctx->d_ids, (size_t)ctx->ids_cap * 4) != hipSuccess) { gvl_destroy(ctx); return fail(nullptr, GVL_ERR_OOM, "hipMalloc failed"); }
   *out = ctx;
   return 0;
 }
@@ -566,7 +563,7 @@ int gvl_destroy(gvl_ctx* ctx) {
   if (!ctx) return 0;
   hipDeviceSynchronize();
   for (auto& kv : ctx->w) if (kv.second.p) hipFree(kv.second.p);
-  void* ptrs[] = {ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_out, ctx->d_ids, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
+  void* ptrs[] = {ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_out, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& r : ctx->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   delete ctx;
@@ -681,13 +678,12 @@ int gvl_encode_segments(gvl_ctx* ctx, const float* spatial_px, const float* temp
   REQUIRE_READY(ctx->has_proj, "gvl_encode_segments");
   if (!spatial_px || !temporal_px || !visual || n <= 0 || n > std::max(1, ctx->cfg.max_segs)) return fail(ctx, GVL_ERR_ARG, "gvl_encode_segments: bad n/pointers");
   hipStream_t st = (hipStream_t)stream;
-  const size_t mark = ctx->arena_off;
+  ArenaScope arena_scope(ctx->arena_off);
   AALLOC(cf, float, (size_t)n * ctx->c_P * ctx->cfg.clip_hidden);
   AALLOC(vf, bf16_t, (size_t)n * ctx->v_TL * ctx->cfg.iv2_dim);
   int rc = clip_encode(ctx, spatial_px, n, cf, st);
   if (!rc) rc = iv2_encode(ctx, temporal_px, n, vf, st);
   if (!rc) rc = gvl_build_visual(ctx, cf, vf, n, visual, stream);
-  ctx->arena_off = mark;
   return rc;
 }
 
@@ -965,13 +961,12 @@ int gvl_op_attention(gvl_ctx* ctx, const uint16_t* q, const uint16_t* k, const u
   if (D < 0 || (Dr & 7)) return fail(ctx, GVL_ERR_ARG, "gvl_op_attention: head dim unsupported");
   hipStream_t st = (hipStream_t)stream;
   const int tiles = (S + 63) / 64;
-  const size_t mark = ctx->arena_off;
+  ArenaScope arena_scope(ctx->arena_off);
   AALLOC(Q, bf16_t, (size_t)B * H * S * D); AALLOC(Kt, bf16_t, (size_t)B * tiles * KV * 64 * D); AALLOC(Vt, bf16_t, (size_t)B * tiles * KV * 64 * D);
   { QkvPostArgs p; memset(&p, 0, sizeof(p)); p.qkv = q; p.ld = (H + 2 * KV) * Dr; p.Q = Q; p.Kt = Kt; p.Vt = Vt; p.B = B; p.S = S; p.H = H; p.KV = KV; p.Dr = Dr; p.D = D; p.mode = 0;
     RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(p, st)); }
   { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; a.O = out; a.B = B; a.H = H; a.KV = KV; a.S = S; a.D = D; a.Dout = Dr; a.scale = scale; a.causal = causal;
     RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
-  ctx->arena_off = mark;
   return 0;
 }
 int gvl_op_layernorm(gvl_ctx* ctx, const float* x, const float* w, const float* b, uint16_t* y, int rows, int cols, float eps, void* stream) {

@@ -77,6 +77,7 @@ class Stepper:
         self.sp, self.tp, self.ids = make_inputs(self.dev, rank)
         self.L = eng.tokens_per_seg
         self.decode_s = 0.0
+        self.h2d = False
         if world > 1:
             # clip c's segment block b goes to rank (b + c) % world (dist.rotated_encode_plan): every rank encodes exactly 12
             # segments.  Synthetic pixels: every rank generates the segments it encodes itself.
@@ -92,6 +93,9 @@ class Stepper:
     def encode(self):
         """vision towers + projectors for this rank's 12 segments (+ the all-gather for N > 1) -> visual tokens of THIS rank's clip."""
         eng = self.eng
+        if self.h2d:                                                    # extra (untimed for `value`): pixels arrive over PCIe
+            self.sp.copy_(self.sp_host, non_blocking=True)
+            self.tp.copy_(self.tp_host, non_blocking=True)
         vis = eng.encode_segments(self.sp, self.tp)                     # [12*L, hidden]
         if self.world > 1:
             recv = torch.empty((self.world * vis.shape[0], vis.shape[1]), dtype=bf, device=self.dev)
@@ -285,7 +289,22 @@ def main():
         dt = float(tt.item())
     clips_per_s = world * args.steps * cps / dt
 
-    # ---- untimed extras: single-clip latency, decode-only rate, per-kernel-family profile, CPU baseline -----
+    # ---- untimed extras: PCIe-inclusive rate, single-clip latency, decode-only rate, per-kernel-family profile, CPU baseline -----
+    # The boundary takes DEVICE pixel tensors (`value` above); here every clip's 74 MB of f32 pixels is first copied from pinned
+    # host memory on the vision stream, as a caller holding CPU-preprocessed frames would (inference.py:119-120 of the reference).
+    clips_per_s_h2d = None
+    if world == 1:
+        st.sp_host, st.tp_host = st.sp.cpu().pin_memory(), st.tp.cpu().pin_memory()
+        st.h2d = True
+        _ = stepfn()
+        barrier()
+        th = time.perf_counter()
+        for _ in range(args.steps):
+            _ = stepfn()
+        barrier()
+        clips_per_s_h2d = args.steps * cps / (time.perf_counter() - th)
+        st.h2d = False
+        _ = stepfn()                      # the next vision encode in flight reads resident pixels again
     torch.cuda.synchronize()
     tl = time.perf_counter()
     for _ in range(2):
@@ -355,7 +374,7 @@ def main():
                           "parallelism": "1 GPU" if world == 1 else f"frame-batch sharded over {world} GPUs + all-gather of visual tokens, LLM replica per clip"},
                "decode_tokens_per_s": None if decode_tok_s is None else round(world * decode_tok_s, 1),
                "decode_tokens_per_s_batched": None if decode_tok_s_batched is None else round(world * decode_tok_s_batched, 1),
-               "single_clip_latency_ms": round(latency_ms, 2), "mode": args.mode, "ids_match_serial": same_ids,
+               "clips_per_s_incl_pixel_h2d": None if clips_per_s_h2d is None else round(clips_per_s_h2d, 4), "single_clip_latency_ms": round(latency_ms, 2), "mode": args.mode, "ids_match_serial": same_ids,
                "roofline": roofline, "stages": stages}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(geo)

@@ -299,3 +299,53 @@ def test_header_is_plain_c_and_links(tmp_path):
     assert r.returncode == 0, (r.stdout, r.stderr)
     if not torch.cuda.is_available():
         assert "create=-5" in r.stdout and "no CPU fallback" in r.stdout
+
+
+def test_host_integer_paths_fuzz_against_oracle():
+    """The product's host-side integer / text plumbing (prompts.py) against the oracle restatement (pinned on the reference's own
+    outputs) on random inputs: frame sampling, temporal-token <-> seconds, <image> splitting, padding, conversation templates,
+    training label masks -- all bit-exact."""
+    rng = np.random.default_rng(7)
+    words = ["the", "door", "opens", "<image>", "a", "person", "walks", "<17>", "<timestamp_grounding>", "?", "video", "12 seconds", "from", "to", "<300>", "3 seconds"]
+    tok = lambda s: [1] + [3 + (sum(map(ord, w)) % 90) for w in s.split()]
+    tok_nobos = lambda s: [3 + (sum(map(ord, w)) % 90) for w in s.split()]
+    for _ in range(300):
+        nf, vlen = int(rng.integers(1, 300)), int(rng.integers(1, 9000))
+        assert P.sample_frame_indices(nf, vlen) == O.get_frame_indices(nf, vlen)
+        segs = int(rng.integers(1, 33)); nfr = segs * int(rng.integers(1, 17))
+        assert P.spatial_indices(nfr, segs) == O.spatial_frame_indices(nfr, segs)
+        dur, t = float(rng.uniform(0.5, 4000)), float(rng.uniform(0, 4000))
+        assert P.quantize_time(min(t, dur), dur, 300) == O.quantize_timestamp(min(t, dur), dur, 300)
+        text = " ".join(rng.choice(words, size=int(rng.integers(1, 14))))
+        assert P.seconds_to_tokens(text, dur) == O.seconds_to_temporal_tokens(text, dur)
+        for llm in ("phi3.5", "llama3"):
+            assert P.parse_time_interval(text, dur, 300, llm) == O.parse_time_interval(text, dur, 300, llm)
+        for tk, bos in ((tok, 1), (tok_nobos, 1), (tok, None)):
+            assert P.tokenize_with_image(text, tk, bos) == O.tokenizer_image_token(text, tk, bos)
+    for _ in range(60):
+        rows = [list(rng.integers(3, 90, size=int(rng.integers(1, 40)))) for _ in range(int(rng.integers(1, 6)))]
+        mtl = int(rng.integers(1, 50))
+        a_ids, a_mask = P.left_pad_truncate(rows, 0, mtl)
+        o_ids, o_mask = O.left_pad_truncate(rows, 0, mtl)
+        assert np.array_equal(a_ids, o_ids.numpy()) and np.array_equal(a_mask, o_mask.numpy())
+    # conversations: templates + label masks, 1-4 rounds, image token in the first question, all three LLM families
+    for _ in range(120):
+        llm = ("phi3.5", "llama3", "vicuna")[int(rng.integers(0, 3))]
+        conv = []
+        for r in range(int(rng.integers(1, 5))):
+            q = " ".join(rng.choice(words[:3] + words[4:7] + ["?"], size=int(rng.integers(1, 8))))
+            a = " ".join(rng.choice(words[:3] + words[4:8] + ["."], size=int(rng.integers(0, 8))))
+            conv += [{"from": "human", "value": ("<image>\n" if r == 0 else "") + q}, {"from": "gpt", "value": a}]
+        text = P.TEMPLATES[llm].encode(conv)
+        assert text == O.template_encode(llm, conv)
+        mtl = int(rng.integers(20, 400))
+        pad = int(rng.choice([0, 2]))
+        try:
+            o = O.prepare_batch(llm, [text], tok, 1, pad, 2, mtl)
+        except Exception as e:
+            with pytest.raises(type(e)):
+                P.prepare_batch(llm, [text], tok, 1, pad, 2, mtl)
+            continue
+        p = P.prepare_batch(llm, [text], tok, 1, pad, 2, mtl)
+        for x, y in zip(p, o):
+            assert np.array_equal(x, y.numpy()), (llm, text)

@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 import gvl_oracle as O
@@ -224,3 +225,22 @@ def test_training_loss_oracle_matches_reference():
         if name in ("phi_a", "phi_b"):
             tot, cnt = tot + s, cnt + n
     assert abs(tot / cnt - float(g["phi_batch_ab_loss"])) < 2e-5 * float(g["phi_batch_ab_loss"])
+
+
+def test_pillow_resampler_restatement_fuzz():
+    """Where Pillow is importable (this image: 12.2.0; the pinned reference version is 11.1.0, same Resample.c arithmetic) the
+    restatement is checked LIVE on random geometries -- strong down-scaling (wide kernels), up-scaling, 1-pixel axes, odd aspect
+    ratios -- beyond the 7 committed golden cases.  Bit-exact."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    rng = np.random.default_rng(20260927)
+    geoms = [(1, 1, 7, 5), (2, 3, 1, 1), (17, 640, 224, 224), (1080, 1920, 126, 224), (37, 41, 224, 398), (224, 224, 224, 224), (5, 300, 300, 5)]
+    geoms += [tuple(int(v) for v in (rng.integers(1, 400), rng.integers(1, 400), rng.integers(1, 300), rng.integers(1, 300))) for _ in range(25)]
+    for h, w, oh, ow in geoms:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if h * w > 64:                                         # hard edges / saturation: exercises the clip8 of both passes
+            img[: h // 2, : w // 2] = 255
+            img[h // 2:, w // 2:] = 0
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BICUBIC))
+        got = O.pil_resize_bicubic(img, ow, oh)
+        assert got.shape == ref.shape and np.array_equal(got, ref), f"{(h, w)} -> {(oh, ow)}: {int((got != ref).sum())} bytes differ from Pillow {PIL.__version__}"

@@ -344,7 +344,30 @@ def g_train(ns):
         print("padded batch loss", float(rb.loss), "vs members", float((out["phi_a_nll_sum"] + out["phi_b_nll_sum"]) / (meta["phi_a"]["n_valid"] + meta["phi_b"]["n_valid"])))
     except Exception as e:                                     # installed transformers may lack the 4.40 mask helper
         print("padded-batch case not generated:", repr(e)[:200])
-    save("train_loss", dict(cfg=dict(kind="phi3", hidden=64, inter=128, layers=2, heads=4, kv_heads=4, vocab=100), seed="g.phi.tiny", cases=meta), **out)
+    # Llama (GQA 4/2, plain RoPE): same label pattern through LlamaForCausalLM's labels branch
+    from transformers import LlamaConfig
+    c = LlamaConfig(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                    num_key_value_heads=2, rms_norm_eps=1e-5, max_position_embeddings=8192, pad_token_id=0, bos_token_id=1,
+                    eos_token_id=2, attention_bias=False)
+    c.rope_theta = 500000.0
+    c.rope_scaling = None
+    c.pretraining_tp = 1
+    c.attention_dropout = 0.0
+    c.mlp_bias = False
+    c._attn_implementation = "eager"
+    ml = ns.llama.LlamaForCausalLM(c)
+    ml.lm_head = torch.nn.Linear(64, 100, bias=True)
+    load_into(ml, synth.llm_weights("llama", 64, 128, 2, 4, 2, 100, True, seed="g.llama.tiny"))
+    lmeta = {}
+    for name, S, lo in (("a", 40, 25), ("b", 70, 60)):
+        x = synth.det_tensor("g.train.llama." + name, (1, S, 64), 0.5)
+        lab = torch.tensor([(5 * i + 11 * len(name) + S) % 97 + 3 if i >= lo and i != lo + 2 else -100 for i in range(S)])
+        r = ml(inputs_embeds=x, labels=lab[None], use_cache=False)
+        out[f"llama_{name}_loss"] = r.loss
+        lmeta[f"llama_{name}"] = dict(x="g.train.llama." + name, S=S, labels=lab.tolist(), n_valid=int((lab[1:] != -100).sum()))
+    save("train_loss", dict(cfg=dict(kind="phi3", hidden=64, inter=128, layers=2, heads=4, kv_heads=4, vocab=100), seed="g.phi.tiny", cases=meta,
+                            llama_cfg=dict(kind="llama", hidden=64, inter=128, layers=2, heads=4, kv_heads=2, vocab=100, rope_theta=500000.0),
+                            llama_seed="g.llama.tiny", llama_cases=lmeta), **out)
 
 
 def g_pre(ns):

@@ -319,6 +319,18 @@ def test_forward_loss_matches_reference_golden():
         if name in ("phi_a", "phi_b"):
             tot, cnt = tot + s, cnt + n
     assert abs(tot / cnt - float(g["phi_batch_ab_loss"])) < 5e-3 * float(g["phi_batch_ab_loss"])   # the right-padded batch of (a, b)
+    # Llama (GQA 4/2): LlamaForCausalLM(labels=...) goldens through the same entry point
+    lc = meta["llama_cfg"]
+    lgeo = tiny_geo(llm="llama3", hidden=lc["hidden"], inter=lc["inter"], layers=lc["layers"], heads=lc["heads"], kv_heads=lc["kv_heads"], vocab=lc["vocab"],
+                    rope_theta=lc["rope_theta"], rope_orig_max_pos=0)
+    leng = llm_engine(lgeo, synth.llm_weights("llama", lc["hidden"], lc["inter"], lc["layers"], lc["heads"], lc["kv_heads"], lc["vocab"], True, seed=meta["llama_seed"]))
+    for name, m in meta["llama_cases"].items():
+        x = synth.det_tensor(m["x"], (1, m["S"], lc["hidden"]), 0.5)[0]
+        s, n = leng.forward_loss(x.to(DEV).to(bf), m["labels"])
+        ref = float(g[name + "_loss"])
+        print(f"[parity] forward_loss {name}: gpu {s / n:.6f} reference {ref:.6f}")
+        assert n == m["n_valid"] and abs(s / n - ref) < 5e-3 * ref
+    leng.close()
     # deterministic, and independent of what else the sequence slot / arena held before
     x = synth.det_tensor(meta["cases"]["phi_b"]["x"], (1, 70, c["hidden"]), 0.5)[0].to(DEV).to(bf)
     assert eng.forward_loss(x, meta["cases"]["phi_b"]["labels"]) == eng.forward_loss(x, meta["cases"]["phi_b"]["labels"])

@@ -225,6 +225,14 @@ def test_training_loss_oracle_matches_reference():
         if name in ("phi_a", "phi_b"):
             tot, cnt = tot + s, cnt + n
     assert abs(tot / cnt - float(g["phi_batch_ab_loss"])) < 2e-5 * float(g["phi_batch_ab_loss"])
+    # Llama (GQA, plain RoPE) through LlamaForCausalLM's labels branch
+    lc = meta["llama_cfg"]
+    lcfg = O.LLMConfig("llama", lc["hidden"], lc["inter"], lc["layers"], lc["heads"], lc["kv_heads"], lc["vocab"], 1e-5, lc["rope_theta"], 8192, 0, None, None)
+    LW = synth.llm_weights("llama", lc["hidden"], lc["inter"], lc["layers"], lc["heads"], lc["kv_heads"], lc["vocab"], True, seed=meta["llama_seed"])
+    for name, m in meta["llama_cases"].items():
+        x = synth.det_tensor(m["x"], (1, m["S"], lc["hidden"]), 0.5)[0]
+        s, n = O.causal_lm_loss_terms(O.llm_forward(lcfg, LW, x, False, None, 0, last_only=False), torch.tensor(m["labels"]))
+        assert n == m["n_valid"] and abs(s / n - float(g[name + "_loss"])) < 2e-5 * float(g[name + "_loss"]), name
 
 
 def test_pillow_resampler_restatement_fuzz():

@@ -78,3 +78,24 @@ def test_preprocess_bad_arguments(eng):
         eng.preprocess_frames(fr, 0, (0, 0, 0), (1, 1, 1))
     with pytest.raises(L.GvlError):
         eng.preprocess_frames(fr, 8, (0, 0, 0), (1, 0, 1))
+
+
+def test_preprocess_random_geometries_vs_oracle(eng):
+    """Random source sizes / target sizes / layouts (strong down-scaling, up-scaling, thin frames, saturated edges): the GPU path
+    against the oracle restatement (itself checked live against Pillow on CPU, tests/test_oracle_golden.py) -- bit-exact."""
+    rng = np.random.default_rng(11)
+    geoms = [(1080, 1920, 224), (17, 640, 16), (37, 41, 64), (224, 224, 224), (5, 300, 4), (400, 226, 224), (2, 2, 8)]
+    geoms += [(int(rng.integers(2, 500)), int(rng.integers(2, 500)), int(rng.integers(1, 240))) for _ in range(14)]
+    for h, w, size in geoms:
+        n = int(rng.integers(1, 4))
+        img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        img[:, : h // 2, : w // 2] = 255
+        img[:, h // 2:, w // 2:] = 0
+        for layout in ("hwc", "chw"):
+            fr = torch.from_numpy(img)
+            if layout == "chw":
+                fr = fr.permute(0, 3, 1, 2).contiguous()
+            got = eng.preprocess_frames(fr.to(DEV), size, O.OPENAI_DATASET_MEAN, O.OPENAI_DATASET_STD).cpu().numpy()
+            for i in range(n):
+                ref = O.frame_transform(np.transpose(img[i], (2, 0, 1)), size, O.OPENAI_DATASET_MEAN, O.OPENAI_DATASET_STD)
+                assert got[i].shape == ref.shape and np.array_equal(got[i], ref), f"{(h, w)} -> {size} {layout}: {int((got[i] != ref).sum())} values differ"

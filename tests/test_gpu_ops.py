@@ -34,6 +34,34 @@ def test_gemm_plain(eng, M, N, K, cfg):
     check(got32, ref, 2e-4, f"gemm {M}x{N}x{K} cfg{cfg} f32 out")
 
 
+def test_gemm_random_shapes_auto_planner(eng):
+    """Seeded random (M, N, K) through the AUTOMATIC configuration (kernel choice + wave-quantisation planner: whole / tile-row
+    split / tail columns) with a random fused epilogue, against fp32 torch; and bit-identical to the plain 128x128 kernel (cfg 21):
+    every kernel accumulates an output element in the same k order."""
+    import random
+    rnd = random.Random(99)
+    shapes = [(6924, 1024, 1024), (4103, 1408, 1024), (2049, 4224, 1408), (8200, 1028, 64), (1, 4096, 2048), (5000, 260, 1024)]
+    shapes += [(rnd.randint(1, 9000), 4 * rnd.randint(1, 1200), 64 * rnd.randint(1, 32)) for _ in range(8)]
+    rb = lambda t: t.to(bf).float()
+    for i, (M, N, K) in enumerate(shapes):
+        g = torch.Generator(device=DEV); g.manual_seed(1000 + i)
+        A = torch.randn((M, K), device=DEV, generator=g).to(bf)
+        W = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).to(bf)
+        bias = torch.randn((N,), device=DEV, generator=g) * 0.5
+        res = torch.randn((M, N), device=DEV, generator=g).to(bf)
+        acc = A.float() @ W.float().T
+        kind = i % 3
+        if kind == 0:
+            kw, ref, tol = {}, acc, 6e-3
+        elif kind == 1:
+            kw, ref, tol = dict(bias=bias, act=L.ACT_GELU), torch.nn.functional.gelu(rb(acc + bias)), 8e-3
+        else:
+            kw, ref, tol = dict(bias=bias, resid=res), res.float() + rb(acc + bias), 8e-3
+        got = eng.op_gemm(A, W, tile_cfg=0, **kw)
+        check(got, ref, tol, f"gemm auto {M}x{N}x{K} epilogue {kind}")
+        assert torch.equal(got, eng.op_gemm(A, W, tile_cfg=21, **kw)), f"gemm auto {M}x{N}x{K}: planner result differs bitwise from cfg 21"
+
+
 def test_gemm_transpose_detect(eng):
     # A = identity-like with ASYMMETRIC W catches swapped row/col in the C write (guide §3)
     M = N = K = 128
@@ -104,6 +132,20 @@ def test_attention(eng, B, S, H, KV, Dr, causal):
     ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * S, H * Dr)
     got = eng.op_attention(qkv, B, S, H, KV, Dr, scale, causal)
     check(got, ref, 1.5e-2, f"attention B{B} S{S} H{H}/{KV} D{Dr} causal{causal}")
+
+
+def test_attention_random_shapes(eng):
+    """Seeded random (batch, length, heads, KV heads, head dim, causal) -- lengths around the 64-key page and 128-query block
+    boundaries, single-token sequences, grouped-query ratios 1 / 2 / 4 -- against fp32 softmax attention."""
+    import random
+    rnd = random.Random(20260927)
+    cases = [(1, 1, 2, 2, 64, 1), (3, 63, 2, 1, 32, 0), (2, 129, 4, 2, 88, 0), (1, 641, 8, 2, 96, 1), (2, 128, 4, 4, 128, 1), (1, 257, 2, 2, 16, 0)]
+    for _ in range(12):
+        KV = rnd.choice([1, 2, 4]); H = KV * rnd.choice([1, 2, 4])
+        cases.append((rnd.randint(1, 3), rnd.choice([rnd.randint(1, 700), 64 * rnd.randint(1, 6) + rnd.choice([-1, 0, 1])]), H, KV,
+                      rnd.choice([16, 32, 64, 88, 96, 128]), rnd.randint(0, 1)))
+    for B, S, H, KV, Dr, causal in cases:
+        test_attention(eng, B, S, H, KV, Dr, causal)
 
 
 def test_attention_spike_forces_rescale(eng):

@@ -10,13 +10,14 @@ import _gvl_bootstrap  # noqa
 from grounded_video_llm_amd import engine as E
 
 SHAPES = [  # (name, M, N, K)
+    ("clip.patch", 6912, 1024, 640), ("iv2.patch", 24576, 1408, 640),      # patch-embedding GEMMs (K = 588 padded to 640)
     ("clip.qkv", 6924, 3072, 1024), ("clip.out", 6924, 1024, 1024), ("clip.fc1", 6924, 4096, 1024), ("clip.fc2", 6924, 1024, 4096),
     ("iv2.qkv", 24588, 4224, 1408), ("iv2.proj", 24588, 1408, 1408), ("iv2.fc1", 24588, 6144, 1408), ("iv2.fc2", 24588, 1408, 6144),
     ("phi.qkv", 3519, 9216, 3072), ("phi.o", 3519, 3072, 3072), ("phi.gu", 3519, 16384, 3072), ("phi.down", 3519, 3072, 8192),
     ("sq4096", 4096, 4096, 4096), ("sq8192", 8192, 8192, 8192),
 ]
 # the fused epilogue each shape runs with in the model (GVL_BENCH_EPI=model); default: plain bf16 store
-EPI = {"clip.qkv": "bias", "clip.out": "bias_resid32", "clip.fc1": "bias_qgelu", "clip.fc2": "bias_resid32",
+EPI = {"iv2.patch": "bias", "clip.qkv": "bias", "clip.out": "bias_resid32", "clip.fc1": "bias_qgelu", "clip.fc2": "bias_resid32",
        "iv2.qkv": "plain", "iv2.proj": "bias_gamma_resid", "iv2.fc1": "bias_gelu", "iv2.fc2": "bias_gamma_resid",
        "phi.qkv": "plain", "phi.o": "resid", "phi.gu": "silu", "phi.down": "resid"}
 CFGS = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,21,82".split(","))]

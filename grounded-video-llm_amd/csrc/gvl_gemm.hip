@@ -759,14 +759,17 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
   if (cfg == 82 && a.tile_cfg == 0 && env_cfg == 0 && a.m_begin == 0) {
     // Wave-quantisation planner.  The persistent 256x256 kernel runs one block per CU, so a launch costs ceil(tiles / CUs)
     // tile times, and a partial last tile column (N = 1408 = 5.5 x 256) wastes half of its MFMA work.  Candidate plans, costed
-    // in units of one 256x256 tile time (the 128x128 kernel: 512 resident blocks, a full round of them = 0.66 units --
-    // half the FLOPs at ~0.76x the rate -- and half a round = 0.33):
+    // in units of one 256x256 tile time (the small kernel: see small_unit below):
     //   W  whole GEMM on the big kernel;
     //   M  whole rounds of tile ROWS on the big kernel, the remaining rows on the small kernel;
     //   N  the full 256-wide tile columns through W or M, the N % 256 tail columns on the small kernel.
-    // e.g. InternVideo2 proj/fc2 (M = 24588, N = 1408): W = 3, M = 2.66, N = 2.33 (485 big tiles in 2 rounds + 193 small).
+    // e.g. InternVideo2 proj/fc2 (M = 24588, N = 1408): W = 3, M = 3.0, N = 2.5 (485 big tiles in 2 rounds + 193 small).
     static const int n_cu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
-    auto small_cost = [&](long t) { const long halves = (t + n_cu - 1) / n_cu; return t > 0 ? 0.33 * (double)halves : 0.0; };
+    // cost of up to one CU-count of small tiles, in big-tile times.  Half the FLOPs at ~0.76x the rate would be 0.33, but an
+    // under-filled small launch runs its lone blocks far below that rate: same-box A/B of the whole bench, 0.33 / 0.45-0.75 / 0.90
+    // -> GEMM time 73.4 / 73.0 / 75.7 ms per clip (GVL_GEMM_SMALLCOST = percent, experiments only)
+    static const double small_unit = [] { const char* e = getenv("GVL_GEMM_SMALLCOST"); return e ? atoi(e) / 100.0 : 0.5; }();
+    auto small_cost = [&](long t) { const long halves = (t + n_cu - 1) / n_cu; return t > 0 ? small_unit * (double)halves : 0.0; };
     struct Plan { double cost; int big_rows; };   // big_rows = tile rows given to the big kernel (all of them: no M split)
     auto plan_mw = [&](int M, int N) {            // best of W and M for an [M, N] problem
       const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;

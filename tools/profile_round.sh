@@ -13,6 +13,6 @@ cd $R
 for d in trace serial fetch write; do f=$(find $O/$d -name "*.db" | head -1); echo "$d $f $(du -sh $f | cut -f1)"; done > $O/files.txt
 python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) $O/kernel_stats_default.txt > /dev/null 2>&1
 python tools/rocpd_stats.py $(find $O/serial -name "*.db" | head -1) $O/kernel_stats_serial.txt > /dev/null 2>&1
-python tools/pmc_traffic.py $(find $O/fetch -name "*.db" | head -1) $(find $O/write -name "*.db" | head -1) $O/pmc_traffic.json 7 > $O/pmc.log 2>&1
+python tools/pmc_traffic.py $(find $O/fetch -name "*.db" | head -1) $(find $O/write -name "*.db" | head -1) $O/pmc_traffic.json 10 > $O/pmc.log 2>&1
 find $O -name "*.db" -delete
 python bench.py > $O/bench_default.log 2>&1

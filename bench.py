@@ -7,7 +7,8 @@ A "step" = one pass of the hot path over one batch of synthetic input: for every
 ~100-token prompt -> Phi-3.5 prefill (S ~ 3520) -> greedy decode of 12 new tokens through the paged KV cache.
 The clips of a step are prefilled one after the other and decoded TOGETHER (gvl_decode_greedy_batch: every weight matrix is
 streamed once per token for all of them -- the reference batches clips in generate() too, llava_next_video.py:622-647), while
-the vision encode of the next step's clips runs on a second stream.  `single_clip_latency_ms` (one clip, stages back to back)
+the vision encode of the next step's clips runs on a second stream (the CLIP tower once over the 12 x 4 key frames of the step --
+gvl_clip_encode -- then InternVideo2 + projectors per clip: gvl_iv2_encode / gvl_build_visual).  `single_clip_latency_ms` (one clip, stages back to back)
 is reported next to `value`; `--clips-per-step 1` gives the one-clip-per-step pipeline (8.6 clips/s).
 Random-init weights of the real architecture, synthetic pixels (no network for checkpoints/datasets).
 
@@ -90,22 +91,37 @@ class Stepper:
             self.tp = torch.randn((n_mine, 3, 8, 224, 224), device=self.dev, generator=g)
 
     # ---- the three stages of one clip ---------------------------------------------------------------------
+    def _exchange(self, vis):
+        """N > 1: ONE all-gather of this rank's 12 segment blocks, then pick the blocks of this rank's clip (segment order)."""
+        if self.world == 1:
+            return vis
+        recv = torch.empty((self.world * vis.shape[0], vis.shape[1]), dtype=bf, device=self.dev)
+        if torch.distributed.get_backend() == "gloo":                 # debug only (GVL_BENCH_BACKEND=gloo): stage through the host
+            rc = recv.cpu(); torch.distributed.all_gather_into_tensor(rc, vis.cpu()); recv.copy_(rc)
+        else:
+            torch.distributed.all_gather_into_tensor(recv, vis)       # ONE collective per clip round (RCCL over xGMI)
+        recv = recv.view(self.world, 12 * self.L, -1)
+        return torch.cat([recv[src, off * self.L:(off + n) * self.L] for src, off, n in self.gather], 0)   # clip == rank, segment order
+
     def encode(self):
         """vision towers + projectors for this rank's 12 segments (+ the all-gather for N > 1) -> visual tokens of THIS rank's clip."""
-        eng = self.eng
         if self.h2d:                                                    # extra (untimed for `value`): pixels arrive over PCIe
             self.sp.copy_(self.sp_host, non_blocking=True)
             self.tp.copy_(self.tp_host, non_blocking=True)
-        vis = eng.encode_segments(self.sp, self.tp)                     # [12*L, hidden]
-        if self.world > 1:
-            recv = torch.empty((self.world * vis.shape[0], vis.shape[1]), dtype=bf, device=self.dev)
-            if torch.distributed.get_backend() == "gloo":                 # debug only (GVL_BENCH_BACKEND=gloo): stage through the host
-                rc = recv.cpu(); torch.distributed.all_gather_into_tensor(rc, vis.cpu()); recv.copy_(rc)
-            else:
-                torch.distributed.all_gather_into_tensor(recv, vis)       # ONE collective per step (RCCL over xGMI)
-            recv = recv.view(self.world, 12 * self.L, -1)
-            vis = torch.cat([recv[src, off * self.L:(off + n) * self.L] for src, off, n in self.gather], 0)   # clip == rank, segment order
-        return vis
+        return self._exchange(self.eng.encode_segments(self.sp, self.tp))   # [12*L, hidden]
+
+    def encode_multi(self, cps):
+        """Vision encode of the next `cps` clip rounds.  The CLIP tower runs ONCE over the 12 x cps key frames of the step (per clip
+        its N = 1024 GEMMs have only 112 tiles: +1.6 % clips/s measured); InternVideo2 + projectors (+ the all-gather) stay per clip.
+        GVL_BENCH_CLIP_BATCH=0 restores one gvl_encode_segments call per clip."""
+        if not self.clip_batch:
+            return [self.encode() for _ in range(cps)]
+        if self.h2d:
+            for c in range(cps):
+                self.sp_multi[c * 12:(c + 1) * 12].copy_(self.sp_host, non_blocking=True)
+            self.tp.copy_(self.tp_host, non_blocking=True)
+        cf = self.eng.clip_encode(self.sp_multi)
+        return [self._exchange(self.eng.build_visual(cf[c * 12:(c + 1) * 12], self.eng.iv2_encode(self.tp))) for c in range(cps)]
 
     def llm(self, vis):
         eng = self.eng
@@ -140,10 +156,12 @@ class Stepper:
 
     def pipe_start_multi(self, cps):
         self.cps = cps
+        self.clip_batch = os.environ.get("GVL_BENCH_CLIP_BATCH", "1") != "0" and cps > 1
+        self.sp_multi = self.sp.repeat(cps, 1, 1, 1) if self.clip_batch else None     # the key frames of the step's clips, resident
         self.sV, self.sL = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
         self.evV, self.evL = torch.cuda.Event(), torch.cuda.Event()
         with torch.cuda.stream(self.sV):
-            self.vis_next = [self.encode() for _ in range(cps)]
+            self.vis_next = self.encode_multi(cps)
             self.evV.record(self.sV)
 
     def pipe_step_multi(self):
@@ -163,7 +181,7 @@ class Stepper:
                 for seq, emb in zip(seqs, embs):
                     self.eng.prefill(seq, emb)
         with torch.cuda.stream(self.sV):
-            self.vis_next = [self.encode() for _ in range(self.cps)]
+            self.vis_next = self.encode_multi(self.cps)
             self.evV.record(self.sV)
         with torch.cuda.stream(self.sL):
             outs = self.eng.decode_greedy_batch(seqs, self.new_tokens, None)   # synchronises its stream
@@ -257,7 +275,8 @@ def main():
     torch.cuda.set_device(dev)
 
     cps = args.clips_per_step if args.mode == "pipelined" else 1
-    eng, geo = build_engine(dev, new_tokens=args.new_tokens, clips_per_step=cps)
+    clip_batch = os.environ.get("GVL_BENCH_CLIP_BATCH", "1") != "0" and cps > 1
+    eng, geo = build_engine(dev, max_segs=12 * cps if clip_batch else 12, new_tokens=args.new_tokens, clips_per_step=cps)
     st = Stepper(eng, geo, rank, world, args.new_tokens)
 
     def barrier():
@@ -369,7 +388,8 @@ def main():
                "config": {"workload": "Phi-3.5-3.8B, 96 frames (12 segs x 8), 336^2 spatial + 224^2 temporal, ~100-token prompt, "
                                       f"{args.new_tokens} greedy tokens, {cps} clip{'s' if cps > 1 else ''} per GPU per step" +
                                       ((f" ({2 * cps} clips in flight per GPU: the vision encode of the next {cps} overlaps the prefill + " +
-                                        ("batched greedy decode" if cps > 1 else "decode") + f" of the current {cps})") if args.mode == "pipelined" else ""),
+                                        ("batched greedy decode" if cps > 1 else "decode") + f" of the current {cps}" +
+                                        (f"; CLIP tower batched over the {12 * cps} key frames of a step" if clip_batch else "") + ")") if args.mode == "pipelined" else ""),
                           "clips_per_step": cps, "ms_per_clip": round(1e3 * dt / (args.steps * cps), 2), "prefill_len": S, "visual_tokens": 12 * st.L,
                           "parallelism": "1 GPU" if world == 1 else f"frame-batch sharded over {world} GPUs + all-gather of visual tokens, LLM replica per clip"},
                "decode_tokens_per_s": None if decode_tok_s is None else round(world * decode_tok_s, 1),

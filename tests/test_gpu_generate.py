@@ -20,7 +20,7 @@ def test_generate_matches_oracle(llm):
     geo = E.TowerGeometry(llm=llm, clip_hidden=64, clip_inter=128, clip_layers=3, clip_heads=4, iv2_dim=64, iv2_inter=128, iv2_depth=3,
                           iv2_heads=4, hidden=hid, inter=256, layers=2, heads=4, kv_heads=4 if kind == "phi3" else 2, vocab=vocab,
                           rope_short=short if kind == "phi3" else None, rope_long=long if kind == "phi3" else None,
-                          rope_theta=10000.0 if kind == "phi3" else 500000.0, max_seq=2048, max_segs=2, kv_pages=40, max_prefill=1024)
+                          rope_theta=10000.0 if kind == "phi3" else 500000.0, max_seq=2048, max_segs=6, kv_pages=40, max_prefill=1024)
     sd = {"vision_tower": synth.clip_weights(64, 128, 3, seed="gen.clip"),
           "video_encoder": synth.iv2_weights(64, 128, 3, 2, seed="gen.iv2"),
           "projectors": synth.projector_weights(llm, hid, 64, 64, seed="gen.proj"),
@@ -86,7 +86,7 @@ def test_training_forward_loss_matches_oracle(llm):
     geo = E.TowerGeometry(llm=llm, clip_hidden=64, clip_inter=128, clip_layers=3, clip_heads=4, iv2_dim=64, iv2_inter=128, iv2_depth=3,
                           iv2_heads=4, hidden=hid, inter=256, layers=2, heads=4, kv_heads=4 if kind == "phi3" else 2, vocab=vocab,
                           rope_short=short if kind == "phi3" else None, rope_long=long if kind == "phi3" else None,
-                          rope_theta=10000.0 if kind == "phi3" else 500000.0, max_seq=2048, max_segs=2, kv_pages=40, max_prefill=1024)
+                          rope_theta=10000.0 if kind == "phi3" else 500000.0, max_seq=2048, max_segs=6, kv_pages=40, max_prefill=1024)
     sd = {"vision_tower": synth.clip_weights(64, 128, 3, seed="gen.clip"),
           "video_encoder": synth.iv2_weights(64, 128, 3, 2, seed="gen.iv2"),
           "projectors": synth.projector_weights(llm, hid, 64, 64, seed="gen.proj"),

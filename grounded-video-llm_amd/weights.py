@@ -179,3 +179,22 @@ def pack_llm(W: Dict[str, torch.Tensor], kind: str, layers: int, heads: int, kv_
         cl, sl = rope_tables(d, max_seq, rope_theta, long_factor, max_pos, orig_max_pos, dev)
         out["rope.cos_l"], out["rope.sin_l"] = cl, sl
     return out
+
+
+# ---- packed file: what `tools/pack_checkpoint.py` writes once and the serving process maps at start ------------------
+def save_packed(path: str, packed: Dict[str, torch.Tensor], meta: Optional[Dict[str, str]] = None) -> None:
+    """All packed tensors (the names / layouts `gvl_load_weight` expects) in ONE safetensors file: LoRA already merged, q/k/v fused,
+    K padded, RoPE tables built -- the per-start cost drops to a file map + one host-to-device copy per tensor."""
+    from safetensors.torch import save_file
+    save_file({k: v.detach().cpu().contiguous() for k, v in packed.items()}, path, metadata={"format": "gvl-packed-1", **(meta or {})})
+
+
+def load_packed_file(path: str) -> Dict[str, torch.Tensor]:
+    from safetensors import safe_open
+    out = {}
+    with safe_open(path, framework="pt", device="cpu") as f:
+        if (f.metadata() or {}).get("format") != "gvl-packed-1":
+            raise ValueError(f"{path}: not a gvl packed weight file")
+        for k in f.keys():
+            out[k] = f.get_tensor(k)
+    return out

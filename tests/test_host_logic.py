@@ -172,6 +172,26 @@ def test_reference_checkpoint_layout_roundtrip(tmp_path, llm):
             assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), f"{name}:{k}"
     with pytest.raises(FileNotFoundError):
         M.load_reference_checkpoints(llm, str(tmp_path / "missing.pt"), str(d))
+    # offline packing CLI: reference directory (+ fine-tuned ckpt) -> ONE packed file -> exactly the tensors of the in-memory path
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pack_checkpoint", os.path.join(ROOT, "tools", "pack_checkpoint.py"))
+    pc = importlib.util.module_from_spec(spec); spec.loader.exec_module(pc)
+    from grounded_video_llm_amd.engine import TowerGeometry
+    geo = TowerGeometry(llm=llm, clip_hidden=64, clip_inter=128, clip_layers=3, clip_heads=4, iv2_dim=64, iv2_inter=128, iv2_depth=3, iv2_heads=4,
+                        hidden=hid, inter=128, layers=2, heads=4, kv_heads=kvh, vocab=vocab, max_seq=256, rope_orig_max_pos=0)
+    ck_path = tmp_path / "sft.pth"
+    torch.save({"model": ckpt}, ck_path)
+    out = tmp_path / "w.gvl.safetensors"
+    pc.main(["--llm", llm, "--pretrained_video_path", str(iv2_path), "--pretrained_vision_proj_llm_path", str(d), "--ckpt_path", str(ck_path),
+             "--num_frames", "4", "--num_segs", "2", "--out", str(out)], geometry=geo)
+    got = Wt.load_packed_file(str(out))
+    want = pc.pack_all({**sd, "projectors": dict(sd["projectors"])}, geo, llm)
+    assert set(got) == set(want)
+    for k in want:
+        assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k].cpu()), k
+    with pytest.raises(ValueError):
+        save_file({"x": torch.zeros(1)}, str(tmp_path / "other.safetensors"))
+        Wt.load_packed_file(str(tmp_path / "other.safetensors"))
 
 
 # ---- continuous-batching scheduler on a scripted engine ------------------------------------------------

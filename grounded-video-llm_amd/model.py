@@ -71,7 +71,7 @@ class LLAVA_NEXT_VIDEO:
                  pretrained_video_path="weight_path/internvideo/vision-encoder-InternVideo2-stage2_1b-224p-f4.pt",
                  pretrained_vision_proj_llm_path="weight_path/Phi-3.5-vision-instruct-seperated/",
                  *, geometry: Optional[TowerGeometry] = None, tokenizer=None, state_dicts: Optional[Dict[str, Dict[str, torch.Tensor]]] = None,
-                 device: str = "cuda:0", group=None):
+                 device: str = "cuda:0", group=None, packed_weights: Optional[str] = None):
         if dtype not in (torch.bfloat16,):
             raise ValueError("the MI355X path computes in bfloat16 (the reference's recommended dtype, README.md:57)")
         if num_frames % num_segs != 0:
@@ -97,6 +97,10 @@ class LLAVA_NEXT_VIDEO:
             if stage in ("grounded", "sft"):
                 self.tokenizer.add_tokens(P.temporal_token_strings(num_temporal_tokens))   # :235-236
         self.engine = Engine(geometry, device)
+        if packed_weights is not None:                    # file written by tools/pack_checkpoint.py: no per-start packing / LoRA merge
+            self.engine.load_packed(Wt.load_packed_file(packed_weights))
+            self.engine.finalize()
+            return
         if state_dicts is None:
             state_dicts = load_reference_checkpoints(llm, pretrained_video_path, pretrained_vision_proj_llm_path)
         self.load_state_dicts(state_dicts)

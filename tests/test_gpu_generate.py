@@ -73,6 +73,23 @@ def test_generate_matches_oracle(llm):
     shared = model.generate_shared(one, prompts, do_sample=False, num_beams=1, max_new_tokens=10)
     assert shared == [model.generate({**one, "prompts": [p]}, do_sample=False, num_beams=1, max_new_tokens=10)[0] for p in prompts]
     model.engine.close()
+    # start from ONE packed weight file (tools/pack_checkpoint.py's output format) instead of state dicts: same answers
+    import os, tempfile
+    from grounded_video_llm_amd import weights as Wt
+    g2 = model.geo
+    packed = {}
+    packed.update(Wt.pack_clip(sd["vision_tower"], g2.clip_layers - 1))
+    packed.update(Wt.pack_iv2(sd["video_encoder"], g2.iv2_depth - 1, g2.frames_per_seg))
+    packed.update(Wt.pack_projectors(sd["projectors"], llm))
+    packed.update(Wt.pack_llm(sd["language_model"], g2.kind, g2.layers, g2.heads, g2.kv_heads, g2.max_seq, g2.rope_theta, g2.rope_short, g2.rope_long,
+                              g2.rope_max_pos, g2.rope_orig_max_pos))
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "w.gvl.safetensors")
+        Wt.save_packed(path, packed)
+        m2 = LLAVA_NEXT_VIDEO(stage="sft", max_txt_len=64, num_frames=4, num_segs=2, num_temporal_tokens=300, lora=False, llm=llm,
+                              geometry=g2, tokenizer=tok, packed_weights=path, device=DEV)
+        assert m2.generate(samples, do_sample=False, num_beams=1, max_new_tokens=10) == texts
+        m2.engine.close()
 
 
 @pytest.mark.parametrize("llm", ["phi3.5", "llama3"])

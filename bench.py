@@ -42,9 +42,11 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
 
-def build_engine(dev, frames_per_seg=8, max_segs=12, new_tokens=12, clips_per_step=1):
+def build_engine(dev, frames_per_seg=8, max_segs=12, new_tokens=12, clips_per_step=1, kv_pages=None):
+    """kv_pages None: a pool that just holds the step's clips (tests share the GPU with other engines); 0: sized from the free HBM
+    once the weights are resident (gvl_finalize_weights) -- what bench.py's main uses."""
     geo = E.TowerGeometry(llm="phi3.5", frames_per_seg=frames_per_seg, max_segs=max_segs, max_seq=4096, max_prefill=3712 * clips_per_step,
-                          kv_pages=64 * clips_per_step)
+                          kv_pages=64 * clips_per_step if kv_pages is None else kv_pages)
     geo.rope_short, geo.rope_long = synth.longrope_factors(96)
     eng = E.Engine(geo, dev)
     d = str(dev)
@@ -91,17 +93,25 @@ class Stepper:
             self.tp = torch.randn((n_mine, 3, 8, 224, 224), device=self.dev, generator=g)
 
     # ---- the three stages of one clip ---------------------------------------------------------------------
-    def _exchange(self, vis):
-        """N > 1: ONE all-gather of this rank's 12 segment blocks, then pick the blocks of this rank's clip (segment order)."""
-        if self.world == 1:
-            return vis
-        recv = torch.empty((self.world * vis.shape[0], vis.shape[1]), dtype=bf, device=self.dev)
+    def _exchange(self, vis, force=False):
+        return self._exchange_multi([vis], force)[0]
+
+    def _exchange_multi(self, vis_list, force=False):
+        """N > 1: ONE all-gather per STEP: this rank's 12 segment blocks of each of the step's `cps` clip rounds travel together
+        (cps x 3.5 MB per rank; xGMI is point-to-point, every rank pushes to its 7 peers at once), then each round picks the blocks
+        of this rank's clip in segment order.  force: run the collective at world == 1 too (RCCL smoke test on a 1-GPU box)."""
+        if self.world == 1 and not force:
+            return vis_list
+        cps, rows = len(vis_list), vis_list[0].shape[0]
+        send = torch.cat(vis_list, 0) if cps > 1 else vis_list[0]
+        recv = torch.empty((self.world * send.shape[0], send.shape[1]), dtype=bf, device=self.dev)
         if torch.distributed.get_backend() == "gloo":                 # debug only (GVL_BENCH_BACKEND=gloo): stage through the host
-            rc = recv.cpu(); torch.distributed.all_gather_into_tensor(rc, vis.cpu()); recv.copy_(rc)
+            rc = recv.cpu(); torch.distributed.all_gather_into_tensor(rc, send.cpu()); recv.copy_(rc)
         else:
-            torch.distributed.all_gather_into_tensor(recv, vis)       # ONE collective per clip round (RCCL over xGMI)
-        recv = recv.view(self.world, 12 * self.L, -1)
-        return torch.cat([recv[src, off * self.L:(off + n) * self.L] for src, off, n in self.gather], 0)   # clip == rank, segment order
+            torch.distributed.all_gather_into_tensor(recv, send)      # RCCL over xGMI
+        recv = recv.view(self.world, cps, rows, -1)
+        gather = self.gather if self.world > 1 else [(0, 0, rows // self.L)]
+        return [torch.cat([recv[src, c, off * self.L:(off + n) * self.L] for src, off, n in gather], 0) for c in range(cps)]   # clip == rank, segment order
 
     def encode(self):
         """vision towers + projectors for this rank's 12 segments (+ the all-gather for N > 1) -> visual tokens of THIS rank's clip."""
@@ -115,13 +125,33 @@ class Stepper:
         its N = 1024 GEMMs have only 112 tiles: +1.6 % clips/s measured); InternVideo2 + projectors (+ the all-gather) stay per clip.
         GVL_BENCH_CLIP_BATCH=0 restores one gvl_encode_segments call per clip."""
         if not self.clip_batch:
-            return [self.encode() for _ in range(cps)]
+            if self.h2d:
+                return [self.encode() for _ in range(cps)]
+            return self._exchange_multi([self.eng.encode_segments(self.sp, self.tp) for _ in range(cps)])
         if self.h2d:
             for c in range(cps):
                 self.sp_multi[c * 12:(c + 1) * 12].copy_(self.sp_host, non_blocking=True)
             self.tp.copy_(self.tp_host, non_blocking=True)
         cf = self.eng.clip_encode(self.sp_multi)
-        return [self._exchange(self.eng.build_visual(cf[c * 12:(c + 1) * 12], self.eng.iv2_encode(self.tp))) for c in range(cps)]
+        return self._exchange_multi([self.eng.build_visual(cf[c * 12:(c + 1) * 12], self.eng.iv2_encode(self.tp)) for c in range(cps)])
+
+    def stage_times(self):
+        """One clip round on this rank, stages back to back with HIP events between them (diagnosis of the N > 1 runs):
+        vision encode of 12 segments / exchange / splice + prefill / greedy decode, in ms."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        vis = self.eng.encode_segments(self.sp, self.tp)
+        ev[1].record()
+        vis = self._exchange(vis)
+        ev[2].record()
+        seq, _ = self.llm(vis)
+        ev[3].record()
+        self.decode(seq)
+        ev[4].record()
+        torch.cuda.synchronize()
+        names = ("vision_ms", "exchange_ms", "prefill_ms", "decode_ms")
+        return {n: round(ev[i].elapsed_time(ev[i + 1]), 3) for i, n in enumerate(names)}
 
     def llm(self, vis):
         eng = self.eng
@@ -211,12 +241,8 @@ class Stepper:
     overlap = os.environ.get("GVL_BENCH_OVERLAP", "full")
 
 
-def cpu_baseline(geo):
-    """CPU oracle (the reference-equivalent fp32 PyTorch path) on a bounded sample: ONE full-width layer of each tower
-    at the benchmark shapes, scaled by the layer counts of the 96-frame clip."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import gvl_oracle as O
-    torch.set_grad_enabled(False)
+def _cpu_layer_samples(O):
+    """One full-width layer of each tower at the C1 shapes on the host cores (seconds) -- scaled to a 96-frame clip by the caller."""
     t = {}
     Wv = synth.iv2_weights(depth=1, frames=8, seed="cpu.iv2")
     x = synth.det_tensor("cpu.iv2.x", (1, 2049, 1408), 0.5)
@@ -235,13 +261,51 @@ def cpu_baseline(geo):
     for i in range(4):
         O.llm_forward(ocfg, Wl, x[:1], cache=cache, pos0=S + i, last_only=True)
     t["phi_layer_decode_tok"] = (time.perf_counter() - t0) / 4
-    # scale: 39 blocks x 12 segs; 23 layers x 12 imgs; prefill S=3520 = 4x the GEMM rows (+ attention grows ~16x, ignored -> optimistic for the CPU);
-    # decode 12 tokens x 32 layers
-    clip_s = t["iv2_block_1seg"] * 39 * 12 + t["clip_layer_1img"] * 23 * 12 + t["phi_layer_S880"] * 4 * 32 + t["phi_layer_decode_tok"] * 32 * 12
-    return {"value": 1.0 / clip_s, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "CPU oracle (fp32 torch restatement of the reference): 1 InternVideo2 block on 1 segment (S=2049), 1 CLIP layer on 1 image, "
-                      "1 Phi-3.5 layer prefill at S=880 and 4 cached decode tokens; scaled by 39x12, 23x12, 4x32 and 32x12 to one 96-frame clip "
-                      f"(sample times s: {json.dumps({k: round(v, 3) for k, v in t.items()})})"}
+    return t
+
+
+def cpu_baseline(dev, new_tokens=12):
+    """The CPU oracle (fp32 torch restatement of the reference, eager attention, KV-cached greedy as HF generate does) timed END TO END
+    on BASELINE configs[0] -- Phi-3.5, ONE 8-frame segment: CLIP 23 L + InternVideo2 39 blocks + projectors + splice + 32-layer
+    prefill (S = 384) + 12 greedy tokens -- on this box's host cores (SURVEY §8d 'CPU baseline').  The weights are
+    the synth.exact_tensor streams of tests/golden/c0_full.npz (generated on the GPU, copied to the host), so the run also checks
+    the oracle's ids against the REFERENCE's own greedy ids stored in that golden.  Plus the round-1 per-layer sample scaled to
+    the 96-frame clip, for context."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gvl_oracle as O
+    import numpy as np
+    torch.set_grad_enabled(False)
+    d = str(dev)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "c0_full.npz"))
+    meta = json.loads(str(z["meta"]))
+    sd = meta["seeds"]
+    cpu = lambda W: {k: v.cpu() for k, v in W.items()}
+    Wc = cpu(synth.clip_weights(seed=sd["clip"], device=d, exact=True))
+    Wv = cpu(synth.iv2_weights(seed=sd["iv2"], device=d, exact=True))
+    Wp = cpu(synth.projector_weights("phi3.5", seed=sd["proj"], device=d, exact=True))
+    Wl = cpu(synth.llm_weights("phi3", seed=sd["llm"], device=d, exact=True))
+    torch.cuda.empty_cache()
+    sp = synth.exact_tensor(sd["sp"], (1, 1, 3, 336, 336), device=d).cpu()
+    tp = synth.exact_tensor(sd["tp"], (1, 8, 3, 224, 224), device=d).cpu()
+    ocfg = O.LLMConfig("phi3", 3072, 8192, 32, 32, 32, 32366, 1e-5, 10000.0, 131072, 4096, *synth.longrope_factors(96))
+    ids = torch.tensor(meta["ids"])
+    t0 = time.perf_counter()
+    vis = O.encode_images(sp, tp, Wc, Wv, Wp, "phi3.5")
+    t1 = time.perf_counter()
+    emb = O.splice(ids, vis[0], Wl["model.embed_tokens.weight"])
+    out = O.greedy_generate(ocfg, Wl, emb, new_tokens, None, use_cache=True)
+    t2 = time.perf_counter()
+    ref_ids = meta["greedy_ids"][:new_tokens]
+    t = _cpu_layer_samples(O)
+    c1_s = t["iv2_block_1seg"] * 39 * 12 + t["clip_layer_1img"] * 23 * 12 + t["phi_layer_S880"] * 4 * 32 + t["phi_layer_decode_tok"] * 32 * 12
+    return {"value": round(1.0 / (t2 - t0), 5), "unit": "clips/s (8-frame C0 clip)", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"BASELINE configs[0] end to end on the host: Phi-3.5, 1 segment x 8 frames, S = {emb.shape[0]} prefill, {new_tokens} greedy tokens, "
+                      "fp32 torch oracle (oracle/gvl_oracle.py), KV-cached greedy",
+            "c0_seconds": {"vision": round(t1 - t0, 3), "llm_prefill_plus_decode": round(t2 - t1, 3), "total": round(t2 - t0, 3)},
+            "oracle_ids_equal_reference_golden": out == ref_ids, "oracle_ids": out, "reference_ids": ref_ids,
+            "c1_scaled_estimate_clips_per_s": round(1.0 / c1_s, 5),
+            "c1_scaled_estimate_from": "one full-width layer of each tower at the 96-frame shapes x layer counts (attention growth of the S=3520 prefill ignored): "
+                                       + json.dumps({k: round(v, 3) for k, v in t.items()})}
 
 
 def main():
@@ -276,7 +340,8 @@ def main():
 
     cps = args.clips_per_step if args.mode == "pipelined" else 1
     clip_batch = os.environ.get("GVL_BENCH_CLIP_BATCH", "1") != "0" and cps > 1
-    eng, geo = build_engine(dev, max_segs=12 * cps if clip_batch else 12, new_tokens=args.new_tokens, clips_per_step=cps)
+    eng, geo = build_engine(dev, max_segs=12 * cps if clip_batch else 12, new_tokens=args.new_tokens, clips_per_step=cps,
+                            kv_pages=int(os.environ.get("GVL_BENCH_KV_PAGES", "0")))
     st = Stepper(eng, geo, rank, world, args.new_tokens)
 
     def barrier():
@@ -359,15 +424,22 @@ def main():
     eng.prof_enable(False)
     g = prof["gemm"]
     gemm_tflops = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-    traffic = None   # HBM-side bytes per GEMM launch from the PMC passes of the same command (profiles/r01_pmc_traffic.json)
+    # HBM-side bytes per GEMM launch: NOT measured by this run -- PMC counters need their own rocprofv3 passes (MI355X_MICROARCH.md);
+    # the figure is read from the committed summary of those passes over this same command and labelled as such (traffic_source)
+    traffic, traffic_src = None, None
+    for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+            traffic_src = "profiles/" + cand
+            break
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fpm:
+        with open(os.path.join(ROOT, traffic_src)) as fpm:
             pm = json.load(fpm)
             traffic = int(pm["families"]["gemm"]["total_traffic_bytes"] / (pm["clips_in_trace"] * max(1, g["launches"])))   # per LOGICAL GEMM launch
     except Exception:
         pass
     roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)", "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": None if traffic is None else traffic_src + " (separate rocprofv3 --pmc passes of this command; not measured by this run)",
                 "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 2), "launches_per_step": g["launches"],
                 "algorithmic_tflop_per_step": round(g["work"] / 1e12, 2)}
     stages = {}
@@ -381,6 +453,12 @@ def main():
     for k, p in prof.items():
         stages[k + "_ms_per_step"] = round(p["ms"], 3)
 
+    per_rank = None
+    if world > 1:                                       # per-rank stage times of one un-overlapped clip round: makes a scaling run diagnosable
+        mine = dict(st.stage_times(), rank=rank)
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, mine)
+        per_rank = gathered
     if rank == 0:
         out = {"metric": "clips/sec + grounding tokens/sec, 96-frame Phi3.5-3.8B @1/2/4/8 MI355X", "value": round(clips_per_s, 4), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True,
@@ -395,9 +473,12 @@ def main():
                "decode_tokens_per_s": None if decode_tok_s is None else round(world * decode_tok_s, 1),
                "decode_tokens_per_s_batched": None if decode_tok_s_batched is None else round(world * decode_tok_s_batched, 1),
                "clips_per_s_incl_pixel_h2d": None if clips_per_s_h2d is None else round(clips_per_s_h2d, 4), "single_clip_latency_ms": round(latency_ms, 2), "mode": args.mode, "ids_match_serial": same_ids,
-               "roofline": roofline, "stages": stages}
+               "roofline": roofline, "stages": stages, "kv_pool": eng.kv_info()}
+        if per_rank is not None:
+            out["per_rank_stage_ms"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(geo)
+            eng.close()                                  # give the HBM back: the C0 weights are generated on the GPU, then copied to the host
+            out["cpu_baseline"] = cpu_baseline(dev, args.new_tokens)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -11,6 +11,12 @@
 #include "gvl_internal.h"
 #include "../../include/gvl.h"
 
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -66,7 +72,7 @@ struct gvl_ctx {
   // KV pool
   bf16_t *kpool = nullptr, *vpool = nullptr; size_t layer_stride = 0; std::vector<int> free_pages;
   std::vector<Seq> seqs;
-  static constexpr int kMaxSeqs = 64;
+  static constexpr int kMaxSeqs = 256;   // live sequences (slots of the device-side tables); the KV pool is the real limit
   int* d_seq_tables = nullptr; int* d_seq_pos = nullptr; int seq_table_cap = 0;   // [kMaxSeqs][seq_table_cap], [kMaxSeqs]
   // decode buffers
   bf16_t *d_x = nullptr, *d_qkv = nullptr, *d_q = nullptr, *d_attn = nullptr, *d_act = nullptr;
@@ -75,6 +81,9 @@ struct gvl_ctx {
   int nsplit = 16, outlist_cap = 8192, ids_cap = 16384;
   // frame pre-processing scratch (tmp image + tap tables), grown on demand
   void* pre_scratch = nullptr; size_t pre_scratch_bytes = 0;
+  int kv_total_pages = 0;
+  // RCCL communicator owned by the ctx (gvl_comm_init); the library is dlopen'ed on first use
+  void* comm = nullptr; int comm_rank = 0, comm_world = 1;
   // profiling
   bool prof = false; std::vector<ProfRec> recs;
   double prof_ms[GVL_PROF_NCAT] = {0}, prof_work[GVL_PROF_NCAT] = {0}; int64_t prof_n[GVL_PROF_NCAT] = {0};
@@ -142,6 +151,36 @@ GemmArgs gemm(const bf16_t* A, int lda, const bf16_t* W, void* C, int ldc, int M
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = A; g.lda = lda; g.W = W; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   return g;
+}
+
+// paged KV pool: [layer][page][KV][64][D] for K and for V^T, zero-initialised (padded keys / values must be finite)
+int alloc_kv_pool(gvl_ctx* ctx, int pages) {
+  const gvl_config& f = ctx->cfg;
+  ctx->layer_stride = (size_t)pages * f.kv_heads * 64 * ctx->l_D;
+  const size_t pool = ctx->layer_stride * f.layers * 2;
+  if (hipMalloc((void**)&ctx->kpool, pool) != hipSuccess || hipMalloc((void**)&ctx->vpool, pool) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(ctx, GVL_ERR_OOM, "hipMalloc(kv pool) failed: " + std::to_string(pages) + " pages = " + std::to_string(2 * pool >> 20) + " MiB");
+  }
+  if (hipMemset(ctx->kpool, 0, pool) != hipSuccess || hipMemset(ctx->vpool, 0, pool) != hipSuccess) return fail(ctx, GVL_ERR_HIP, "hipMemset(kv pool) failed");
+  ctx->free_pages.clear();
+  for (int p = pages - 1; p >= 0; --p) ctx->free_pages.push_back(p);
+  ctx->kv_total_pages = pages;
+  return 0;
+}
+// pages that fit in the HBM still free now (weights and workspaces are resident): `frac` of it, minus a fixed reserve for the
+// caller's own tensors (pixels, embeddings, logits) and the runtime
+int auto_kv_pages(const gvl_ctx* ctx, double frac, size_t reserve) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return -1;
+  const gvl_config& f = ctx->cfg;
+  const size_t page_bytes = (size_t)f.kv_heads * 64 * ctx->l_D * 2 /*bf16*/ * 2 /*K and V^T*/ * f.layers;
+  double usable = (double)free_b * frac - (double)reserve;
+  if (usable < (double)page_bytes) return 1;
+  double pages = usable / (double)page_bytes;
+  const double cap = (double)gvl_ctx::kMaxSeqs * ((f.max_seq + 63) / 64);   // more than every slot at full context is never reachable
+  if (pages > cap) pages = cap;
+  return (int)pages;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -529,14 +568,10 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
     ctx->arena_l_bytes = prefill_bytes(ctx, f.max_prefill) + (1 << 20);
     if (hipMalloc((void**)&ctx->arena_l, ctx->arena_l_bytes) != hipSuccess) { gvl_destroy(ctx); return fail(nullptr, GVL_ERR_OOM, "hipMalloc(LLM arena) failed"); }
   }
-  // KV pool + decode buffers
+  // KV pool + decode buffers.  cfg.kv_pages > 0: a pool of exactly that many pages, now.  cfg.kv_pages <= 0: the pool is sized from
+  // the HBM that is still free once the weights are resident (gvl_finalize_weights) -- "paged KV cache sized for 288 GB".
   if (ctx->has_llm) {
-    const int pages = f.kv_pages > 0 ? f.kv_pages : 1;
-    ctx->layer_stride = (size_t)pages * f.kv_heads * 64 * ctx->l_D;
-    const size_t pool = ctx->layer_stride * f.layers * 2;
-    if (hipMalloc((void**)&ctx->kpool, pool) != hipSuccess || hipMalloc((void**)&ctx->vpool, pool) != hipSuccess) { gvl_destroy(ctx); return fail(nullptr, GVL_ERR_OOM, "hipMalloc(kv pool) failed"); }
-    hipMemset(ctx->kpool, 0, pool); hipMemset(ctx->vpool, 0, pool);   // padded keys/values must be finite
-    for (int p = pages - 1; p >= 0; --p) ctx->free_pages.push_back(p);
+    if (f.kv_pages > 0) { const int rc = alloc_kv_pool(ctx, f.kv_pages); if (rc) { std::string e = ctx->err; gvl_destroy(ctx); return fail(nullptr, rc, e); } }
     const int qkvw = (f.heads + 2 * f.kv_heads) * ctx->l_Dr;
     bool ok = true;
     const size_t NB = GVL_MAX_DECODE_BATCH;
@@ -563,6 +598,7 @@ int gvl_destroy(gvl_ctx* ctx) {
   if (!ctx) return 0;
   hipDeviceSynchronize();
   for (auto& kv : ctx->w) if (kv.second.p) hipFree(kv.second.p);
+  if (ctx->comm) gvl_comm_destroy(ctx);
   void* ptrs[] = {ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_out, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& r : ctx->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
@@ -631,6 +667,14 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
     NEED("vp.1.w", GVL_BF16, (int64_t)Hd * Hd, &ctx->vp1w); NEED("vp.1.b", GVL_F32, Hd, &ctx->vp1b);
     if (phi) { NEED("sub_gn", GVL_F32, cin, &ctx->sub_gn); NEED("glb_gn", GVL_BF16, cin, &ctx->glb_gn); }
     else NEED("newline", GVL_BF16, Hd, &ctx->newline);
+  }
+  if (ctx->has_llm && !ctx->kpool) {          // cfg.kv_pages <= 0: size the pool from what is free NOW (weights resident)
+    const char* fe = getenv("GVL_KV_FRACTION");
+    const double frac = fe ? atof(fe) : 0.85;
+    const int pages = auto_kv_pages(ctx, frac > 0 && frac <= 1 ? frac : 0.85, (size_t)4 << 30);
+    if (pages <= 0) return fail(ctx, GVL_ERR_HIP, "hipMemGetInfo failed");
+    const int rc = alloc_kv_pool(ctx, pages);
+    if (rc) return rc;
   }
   if (ctx->has_llm) {
     const int Hd = f.hidden, I = f.inter, Dr = ctx->l_Dr, qkvw = (f.heads + 2 * f.kv_heads) * Dr;
@@ -902,6 +946,166 @@ int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, voi
   int rc = decode_step(ctx, one, 1, st);
   if (rc) return rc;
   if (logits) HIPCHK(ctx, hipMemcpyAsync(logits, ctx->d_logits, (size_t)ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int gvl_kv_info(const gvl_ctx* ctx, int* total_pages, int* free_pages, int64_t* pool_bytes, int* max_live_seqs) {
+  if (!ctx) return GVL_ERR_ARG;
+  if (total_pages) *total_pages = ctx->kv_total_pages;
+  if (free_pages) *free_pages = (int)ctx->free_pages.size();
+  if (pool_bytes) *pool_bytes = (int64_t)(ctx->layer_stride * ctx->cfg.layers * 2 * 2);
+  if (max_live_seqs) *max_live_seqs = gvl_ctx::kMaxSeqs;
+  return 0;
+}
+
+// ---- packed weight file (safetensors container): u64 header length, JSON header, raw little-endian tensor bytes ----------------
+namespace {
+struct StEntry { std::string name, dtype; std::vector<int64_t> shape; uint64_t b = 0, e = 0; };
+// Minimal reader for the restricted JSON a safetensors header is: {"name": {"dtype": "...", "shape": [..], "data_offsets": [b, e]}, ...,
+// "__metadata__": {"k": "v", ...}}.  Returns false on anything else.
+struct StParser {
+  const char* p; const char* end; std::string err;
+  void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+  bool lit(char c) { ws(); if (p < end && *p == c) { ++p; return true; } return false; }
+  bool str(std::string& out) {
+    ws(); if (p >= end || *p != '"') return false; ++p; out.clear();
+    while (p < end && *p != '"') {
+      if (*p == '\\') { if (p + 1 >= end) return false; const char c = p[1]; p += 2;
+        if (c == 'u') { if (p + 4 > end) return false; out += '?'; p += 4; } else out += (c == 'n' ? '\n' : c == 't' ? '\t' : c); }
+      else out += *p++;
+    }
+    if (p >= end) return false; ++p; return true;
+  }
+  bool num(uint64_t& v) { ws(); if (p >= end || *p < '0' || *p > '9') return false; v = 0; while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (uint64_t)(*p++ - '0'); return true; }
+  bool numlist(std::vector<int64_t>& v) {
+    v.clear(); if (!lit('[')) return false; if (lit(']')) return true;
+    for (;;) { uint64_t x; if (!num(x)) return false; v.push_back((int64_t)x); if (lit(']')) return true; if (!lit(',')) return false; }
+  }
+  bool parse(std::vector<StEntry>& out, std::unordered_map<std::string, std::string>& meta) {
+    if (!lit('{')) return false; if (lit('}')) return true;
+    for (;;) {
+      std::string key; if (!str(key) || !lit(':') || !lit('{')) return false;
+      if (key == "__metadata__") {
+        if (!lit('}')) for (;;) { std::string k, v; if (!str(k) || !lit(':') || !str(v)) return false; meta[k] = v; if (lit('}')) break; if (!lit(',')) return false; }
+      } else {
+        StEntry en; en.name = key; bool have_off = false;
+        for (;;) {
+          std::string k; if (!str(k) || !lit(':')) return false;
+          if (k == "dtype") { if (!str(en.dtype)) return false; }
+          else if (k == "shape") { if (!numlist(en.shape)) return false; }
+          else if (k == "data_offsets") { std::vector<int64_t> o; if (!numlist(o) || o.size() != 2) return false; en.b = (uint64_t)o[0]; en.e = (uint64_t)o[1]; have_off = true; }
+          else return false;
+          if (lit('}')) break; if (!lit(',')) return false;
+        }
+        if (!have_off) return false;
+        out.push_back(en);
+      }
+      if (lit('}')) return true; if (!lit(',')) return false;
+    }
+  }
+};
+}  // namespace
+
+int gvl_load_packed(gvl_ctx* ctx, const char* path, int* n_loaded) {
+  if (!ctx || !path) return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: bad argument");
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return fail(ctx, GVL_ERR_ARG, std::string("gvl_load_packed: cannot open ") + path);
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || sb.st_size < 8) { close(fd); return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: file too short"); }
+  const size_t fsize = (size_t)sb.st_size;
+  void* map = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (map == MAP_FAILED) return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: mmap failed");
+  struct Unmap { void* m; size_t n; ~Unmap() { munmap(m, n); } } unmap{map, fsize};
+  const unsigned char* base = (const unsigned char*)map;
+  uint64_t hlen = 0; for (int i = 7; i >= 0; --i) hlen = (hlen << 8) | base[i];
+  if (hlen > fsize - 8) return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: header length exceeds the file");
+  std::vector<StEntry> ents; std::unordered_map<std::string, std::string> meta;
+  StParser ps{(const char*)base + 8, (const char*)base + 8 + hlen, {}};
+  if (!ps.parse(ents, meta)) return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: malformed safetensors header");
+  if (meta["format"] != "gvl-packed-1") return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: not a gvl packed weight file (metadata format != gvl-packed-1)");
+  const unsigned char* data = base + 8 + hlen; const size_t dsize = fsize - 8 - hlen;
+  int n = 0;
+  for (const StEntry& en : ents) {
+    int dt; size_t esz;
+    if (en.dtype == "BF16") { dt = GVL_BF16; esz = 2; } else if (en.dtype == "F32") { dt = GVL_F32; esz = 4; }
+    else return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: tensor " + en.name + " has dtype " + en.dtype + " (want BF16 / F32)");
+    int64_t numel = 1; for (int64_t d : en.shape) numel *= d;
+    if (en.e < en.b || en.e > dsize || (uint64_t)numel * esz != en.e - en.b || en.shape.size() > 8) return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: bad offsets / shape for " + en.name);
+    int64_t one = 1;
+    const int rc = gvl_load_weight(ctx, en.name.c_str(), data + en.b, dt, en.shape.empty() ? &one : en.shape.data(), en.shape.empty() ? 1 : (int)en.shape.size(), 0);
+    if (rc) return rc;
+    ++n;
+  }
+  if (n_loaded) *n_loaded = n;
+  return 0;
+}
+
+// ---- RCCL (dlopen'ed: libgvl.so itself links only the HIP runtime) ------------------------------------------------------------
+namespace {
+struct Rccl {
+  struct UID { char b[128]; };          // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed BY VALUE to ncclCommInitRank
+  void* h = nullptr; bool tried = false; std::string err;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, UID, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+} g_rccl;
+bool rccl_load() {
+  if (g_rccl.tried) return g_rccl.h != nullptr;
+  g_rccl.tried = true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) { g_rccl.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rccl.h) break; }
+  if (!g_rccl.h) { g_rccl.err = std::string("dlopen(librccl) failed: ") + (dlerror() ? dlerror() : "?"); return false; }
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.h, "ncclCommInitRank");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.h, "ncclCommDestroy");
+  g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.h, "ncclAllGather");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) { g_rccl.err = "librccl lacks a required symbol"; dlclose(g_rccl.h); g_rccl.h = nullptr; return false; }
+  return true;
+}
+std::string rccl_msg(const char* what, int rc) { return std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error") + " (" + std::to_string(rc) + ")"; }
+constexpr int kNcclBfloat16 = 9;    // ncclDataType_t, rccl.h
+}  // namespace
+
+int gvl_comm_unique_id(char id_out[128]) {
+  if (!id_out) return fail(nullptr, GVL_ERR_ARG, "gvl_comm_unique_id: null");
+  if (!rccl_load()) return fail(nullptr, GVL_ERR_STATE, g_rccl.err);
+  const int rc = g_rccl.GetUniqueId(id_out);
+  if (rc) return fail(nullptr, GVL_ERR_HIP, rccl_msg("ncclGetUniqueId", rc));
+  return 0;
+}
+int gvl_comm_init(gvl_ctx* ctx, const char id[128], int rank, int world) {
+  if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return fail(ctx, GVL_ERR_ARG, "gvl_comm_init: bad arguments");
+  if (ctx->comm) return fail(ctx, GVL_ERR_STATE, "gvl_comm_init: communicator already initialised");
+  if (!rccl_load()) return fail(ctx, GVL_ERR_STATE, g_rccl.err);
+  Rccl::UID uid; memcpy(uid.b, id, 128);
+  void* comm = nullptr;
+  const int rc = g_rccl.CommInitRank(&comm, world, uid, rank);
+  if (rc) return fail(ctx, GVL_ERR_HIP, rccl_msg("ncclCommInitRank", rc));
+  ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_world = world;
+  return 0;
+}
+int gvl_comm_destroy(gvl_ctx* ctx) {
+  if (!ctx) return GVL_ERR_ARG;
+  if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+  ctx->comm = nullptr; ctx->comm_world = 1; ctx->comm_rank = 0;
+  return 0;
+}
+int gvl_allgather_visual(gvl_ctx* ctx, void* comm, const uint16_t* local, int rows_per_rank, int hidden, uint16_t* all, void* stream) {
+  if (!ctx || !local || !all || rows_per_rank <= 0 || hidden <= 0) return fail(ctx, GVL_ERR_ARG, "gvl_allgather_visual: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  void* cm = comm ? comm : ctx->comm;
+  const size_t count = (size_t)rows_per_rank * hidden;
+  if (!cm) {   // no communicator: a single-rank job
+    if (local != all) HIPCHK(ctx, hipMemcpyAsync(all, local, count * 2, hipMemcpyDeviceToDevice, st));
+    return 0;
+  }
+  if (!rccl_load()) return fail(ctx, GVL_ERR_STATE, g_rccl.err);
+  const int rc = g_rccl.AllGather(local, all, count, kNcclBfloat16, cm, st);
+  if (rc) return fail(ctx, GVL_ERR_HIP, rccl_msg("ncclAllGather", rc));
   return 0;
 }
 

@@ -32,14 +32,15 @@ def my_shard(n_units: int, rank: int, world: int) -> Tuple[int, int]:
     return shard_bounds(n_units, world)[rank]
 
 
-def allgather_visual(local: torch.Tensor, n_units: int, rows_per_unit: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+def allgather_visual(local: torch.Tensor, n_units: int, rows_per_unit: int, group: Optional[dist.ProcessGroup] = None,
+                     force_collective: bool = False) -> torch.Tensor:
     """local: [n_local * rows_per_unit, D] for this rank's block -> full [n_units * rows_per_unit, D] on every rank.
 
     Blocks are padded to the largest block so that a single fixed-size all_gather_into_tensor is used
     (12 segments over 8 ranks is uneven: 2,2,2,2,1,1,1,1)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if world == 1:
+    if world == 1 and not force_collective:       # force_collective: run the (degenerate) collective anyway -- RCCL smoke test on one GPU
         return local
     bounds = shard_bounds(n_units, world)
     max_units = max(hi - lo for lo, hi in bounds)

@@ -6,6 +6,7 @@ inside libgvl.so.  If the library cannot be loaded this module raises -- there i
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -55,6 +56,35 @@ class TowerGeometry:
     @property
     def kind(self) -> str:
         return "phi3" if self.llm == "phi3.5" else "llama"
+
+    @staticmethod
+    def vicuna_7b(**kw) -> "TowerGeometry":
+        """LLaVA-Next vicuna-7b-v1.5 base [ext]: Llama-2 architecture -- MHA 32 x 128, inter 11008, theta 1e4, vocab 32000 + 302."""
+        base = dict(llm="vicuna", hidden=4096, inter=11008, layers=32, heads=32, kv_heads=32, vocab=32000 + 302, rope_theta=10000.0,
+                    rope_short=None, rope_long=None, rope_orig_max_pos=0, max_seq=4096)
+        base.update(kw)
+        return TowerGeometry(**base)
+
+    def apply_hf_config(self, cfg: dict) -> "TowerGeometry":
+        """Fill the LLM fields from an HF config.json dict (the `text`/top-level keys of Phi-3.5(-vision) / Llama configs [ext]):
+        hidden sizes, rms_norm_eps, rope_theta and -- for Phi-3.5 -- the LongRoPE short/long factors and both context limits that
+        Phi3LongRoPEScaledRotaryEmbedding reads (models/modeling_phi3.py:369-409).  Returns self."""
+        cfg = cfg.get("text_config", cfg)
+        m = {"hidden_size": "hidden", "intermediate_size": "inter", "num_hidden_layers": "layers", "num_attention_heads": "heads",
+             "num_key_value_heads": "kv_heads", "rms_norm_eps": "rms_eps", "rope_theta": "rope_theta"}
+        for k, a in m.items():
+            if cfg.get(k) is not None:
+                setattr(self, a, type(getattr(self, a))(cfg[k]))
+        rs = cfg.get("rope_scaling")
+        if rs:
+            kind = rs.get("type", rs.get("rope_type"))
+            # Phi3Config._rope_scaling_adjustment renames the legacy types "su" / "yarn" to "longrope" (modeling_phi3.py:191-202)
+            if kind not in ("longrope", "su", "yarn") or "short_factor" not in rs or "long_factor" not in rs:
+                raise ValueError(f"unsupported rope_scaling {rs!r}: need type longrope with short_factor and long_factor (modeling_phi3.py:204-240)")
+            self.rope_short, self.rope_long = [float(v) for v in rs["short_factor"]], [float(v) for v in rs["long_factor"]]
+            self.rope_max_pos = int(cfg.get("max_position_embeddings", self.rope_max_pos))
+            self.rope_orig_max_pos = int(cfg.get("original_max_position_embeddings", self.rope_orig_max_pos))
+        return self
 
     @staticmethod
     def llama3_8b(**kw) -> "TowerGeometry":
@@ -135,9 +165,41 @@ class Engine:
             self._chk(self.lib.gvl_load_weight(self.ctx, name.encode(), C.c_void_p(t.data_ptr()), dt, shape, max(t.dim(), 1),
                                                1 if t.is_cuda else 0), f"gvl_load_weight({name})")
 
+    def load_packed_file(self, path: str) -> int:
+        """gvl_load_packed: the C++ loader of a `gvl-packed-1` file (tools/pack_checkpoint.py); no torch / safetensors involved."""
+        n = C.c_int(0)
+        self._chk(self.lib.gvl_load_packed(self.ctx, os.fsencode(path), C.byref(n)), "gvl_load_packed")
+        return n.value
+
     def finalize(self):
         self._chk(self.lib.gvl_finalize_weights(self.ctx), "gvl_finalize_weights")
         self._finalized = True
+
+    def kv_info(self) -> Dict[str, int]:
+        t, f, b, m = C.c_int(0), C.c_int(0), C.c_int64(0), C.c_int(0)
+        self._chk(self.lib.gvl_kv_info(self.ctx, C.byref(t), C.byref(f), C.byref(b), C.byref(m)), "gvl_kv_info")
+        return {"total_pages": t.value, "free_pages": f.value, "pool_bytes": b.value, "max_live_seqs": m.value, "tokens": t.value * 64}
+
+    # ---- multi-GPU exchange through the C ABI (RCCL dlopen'ed by libgvl) -----------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = self.lib.gvl_comm_unique_id(buf)
+        if rc != 0:
+            raise L.GvlError(f"gvl_comm_unique_id failed ({rc}): {self.lib.gvl_last_error(None).decode()}")
+        return buf.raw
+
+    def comm_init(self, uid: bytes, rank: int, world: int):
+        assert len(uid) == 128
+        self._chk(self.lib.gvl_comm_init(self.ctx, uid, int(rank), int(world)), "gvl_comm_init")
+        self.comm_world = world
+
+    def allgather_visual(self, local: torch.Tensor) -> torch.Tensor:
+        """local bf16 [rows, hidden] (same rows on every rank) -> [world * rows, hidden] in rank order (ncclAllGather on the current stream)."""
+        local = local.contiguous()
+        world = getattr(self, "comm_world", 1)
+        out = torch.empty((world * local.shape[0], local.shape[1]), dtype=bf, device=self.device)
+        self._chk(self.lib.gvl_allgather_visual(self.ctx, None, _ptr(local), local.shape[0], local.shape[1], _ptr(out), self.stream), "gvl_allgather_visual")
+        return out
 
     # ---- vision ----------------------------------------------------------------------------------
     def clip_encode(self, px: torch.Tensor) -> torch.Tensor:

@@ -41,6 +41,12 @@ _SIGS = {
     "gvl_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     "gvl_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int]),
     "gvl_finalize_weights": (C.c_int, [C.c_void_p]),
+    "gvl_load_packed": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "gvl_kv_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "gvl_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "gvl_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "gvl_comm_destroy": (C.c_int, [C.c_void_p]),
+    "gvl_allgather_visual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gvl_clip_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gvl_iv2_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gvl_build_visual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -71,7 +71,7 @@ class LLAVA_NEXT_VIDEO:
                  pretrained_video_path="weight_path/internvideo/vision-encoder-InternVideo2-stage2_1b-224p-f4.pt",
                  pretrained_vision_proj_llm_path="weight_path/Phi-3.5-vision-instruct-seperated/",
                  *, geometry: Optional[TowerGeometry] = None, tokenizer=None, state_dicts: Optional[Dict[str, Dict[str, torch.Tensor]]] = None,
-                 device: str = "cuda:0", group=None, packed_weights: Optional[str] = None):
+                 device: str = "cuda:0", group=None, packed_weights: Optional[str] = None, ckpt_path: Optional[str] = None):
         if dtype not in (torch.bfloat16,):
             raise ValueError("the MI355X path computes in bfloat16 (the reference's recommended dtype, README.md:57)")
         if num_frames % num_segs != 0:
@@ -80,8 +80,23 @@ class LLAVA_NEXT_VIDEO:
         self.num_frames, self.num_segs, self.lora, self.num_temporal_tokens, self.llm = num_frames, num_segs, lora, num_temporal_tokens, llm
         self.group = group
         if geometry is None:
-            geometry = TowerGeometry() if llm == "phi3.5" else TowerGeometry.llama3_8b()
+            geometry = geometry_from_checkpoint_dirs(llm, config_path, pretrained_vision_proj_llm_path)
         geometry.frames_per_seg = num_frames // num_segs
+        if geometry.max_segs < num_segs:
+            geometry.max_segs = num_segs
+        # the prefill workspace must hold the visual prefix plus the longest prompt the reference accepts (max_txt_len)
+        tok_seg = (156 if llm == "phi3.5" else 64) + 16 * geometry.frames_per_seg + 1
+        need = num_segs * tok_seg + max_txt_len
+        if geometry.max_prefill < need:
+            geometry.max_prefill = need
+        if geometry.max_seq < min(need + 256, 131072):
+            geometry.max_seq = min(need + 256, 131072)
+        if geometry.kv_pages * 64 < need + 256:
+            geometry.kv_pages = 0                     # 0 = size the paged KV pool from the free HBM (gvl_create)
+        if llm == "phi3.5" and geometry.rope_short is None and geometry.rope_orig_max_pos > 0:
+            raise ValueError("Phi-3.5 needs its LongRoPE short_factor / long_factor (config.json rope_scaling): Phi3LongRoPEScaledRotaryEmbedding "
+                             "applies the short factors and the sqrt(1 + ln(s)/ln(4096)) scale even below 4096 tokens (modeling_phi3.py:380-409); "
+                             "pass geometry=TowerGeometry().apply_hf_config(cfg) or a config_path that holds config.json")
         self.geo = geometry
         self.tokenizer = tokenizer
         if self.tokenizer is None:
@@ -97,26 +112,41 @@ class LLAVA_NEXT_VIDEO:
             if stage in ("grounded", "sft"):
                 self.tokenizer.add_tokens(P.temporal_token_strings(num_temporal_tokens))   # :235-236
         self.engine = Engine(geometry, device)
-        if packed_weights is not None:                    # file written by tools/pack_checkpoint.py: no per-start packing / LoRA merge
-            self.engine.load_packed(Wt.load_packed_file(packed_weights))
+        if packed_weights is not None:                    # file written by tools/pack_checkpoint.py: no per-start packing / LoRA merge;
+            self.engine.load_packed_file(packed_weights)  # read by libgvl itself (gvl_load_packed: mmap + one upload per tensor)
             self.engine.finalize()
             return
         if state_dicts is None:
             state_dicts = load_reference_checkpoints(llm, pretrained_video_path, pretrained_vision_proj_llm_path)
-        self.load_state_dicts(state_dicts)
+        self._base_sd = state_dicts
+        if ckpt_path is not None:                         # inference.py:156-162 in one pass: base + fine-tuned overlay, packed ONCE
+            ckpt = torch.load(ckpt_path, map_location="cpu")
+            self.load_ckpt(ckpt.get("model", ckpt))
+        else:
+            self.load_state_dicts(state_dicts)
 
     # weights -------------------------------------------------------------------------------------------
     def load_state_dicts(self, sd: Dict[str, Dict[str, torch.Tensor]], ckpt_frames: Optional[int] = None):
         g = self.geo
+        lm = sd["language_model"]
+        if self.stage in ("grounded", "sft"):
+            # the constructor of the reference grows the vocabulary BEFORE any fine-tuned weights arrive (reset_embeddings, :231-268)
+            ek = next(k for k in lm if k.endswith("embed_tokens.weight"))
+            n_new = g.vocab - lm[ek].shape[0]
+            if n_new > 0:
+                lm = Wt.reset_embeddings(lm, n_new, g.lm_head_bias)
         self.engine.load_packed(Wt.pack_clip(sd["vision_tower"], g.clip_layers - 1))
-        self.engine.load_packed(Wt.pack_iv2(sd["video_encoder"], g.iv2_depth - 1, g.frames_per_seg, ckpt_frames))
+        self.engine.load_packed(Wt.pack_iv2(sd["video_encoder"], g.iv2_depth - 1, g.frames_per_seg, ckpt_frames,
+                                            tokens_per_frame=(g.iv2_image // g.iv2_patch) ** 2))
         self.engine.load_packed(Wt.pack_projectors(sd["projectors"], self.llm))
-        self.engine.load_packed(Wt.pack_llm(sd["language_model"], g.kind, g.layers, g.heads, g.kv_heads, g.max_seq, g.rope_theta,
+        self.engine.load_packed(Wt.pack_llm(lm, g.kind, g.layers, g.heads, g.kv_heads, g.max_seq, g.rope_theta,
                                             g.rope_short, g.rope_long, g.rope_max_pos, g.rope_orig_max_pos))
         self.engine.finalize()
 
-    def load_ckpt(self, ckpt: Dict[str, Dict[str, torch.Tensor]], base: Dict[str, Dict[str, torch.Tensor]]):
-        """inference.py:156-162: overlay the fine-tuned groups {multi_modal_projector, video_projecter, language_model}."""
+    def load_ckpt(self, ckpt: Dict[str, Dict[str, torch.Tensor]], base: Optional[Dict[str, Dict[str, torch.Tensor]]] = None):
+        """inference.py:156-162: overlay the fine-tuned groups {multi_modal_projector, video_projecter, language_model} on the base
+        state dicts this object was built from (kept in memory: nothing is read from disk twice)."""
+        base = base if base is not None else self._base_sd
         proj = dict(base["projectors"])
         for grp in ("multi_modal_projector", "video_projecter"):
             for k, v in ckpt.get(grp, {}).items():
@@ -146,7 +176,9 @@ class LLAVA_NEXT_VIDEO:
         if self.group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
             world, rank = torch.distributed.get_world_size(self.group), torch.distributed.get_rank(self.group)
             lo, hi = gdist.my_shard(n, rank, world)
-            local = self.engine.encode_segments(sp[lo:hi], tp[lo:hi]) if hi > lo else torch.empty((0, self.geo.hidden), dtype=bf, device=self.engine.device)
+            ms = max(1, self.geo.max_segs)
+            parts = [self.engine.encode_segments(sp[i:min(i + ms, hi)], tp[i:min(i + ms, hi)]) for i in range(lo, hi, ms)]   # bs > 1: the shard may exceed max_segs
+            local = (torch.cat(parts, 0) if len(parts) > 1 else parts[0]) if parts else torch.empty((0, self.geo.hidden), dtype=bf, device=self.engine.device)
             vis = gdist.allgather_visual(local, n, L, self.group)
         else:
             ms = self.geo.max_segs
@@ -167,6 +199,10 @@ class LLAVA_NEXT_VIDEO:
         if generate_kwargs.get("do_sample", False) or generate_kwargs.get("num_beams", 1) != 1:
             raise NotImplementedError("this tier implements greedy decoding (do_sample=False, num_beams=1)")
         max_new = int(generate_kwargs.get("max_new_tokens", 2048))
+        if any(v == "text" for v in samples.get("video_ids", [])):
+            # prepare_multimodal_inputs' `video_ids == 'text'` branch (llava_next_video.py:583-586) is a TRAINING device (dummy visual
+            # rows appended with mask 0 so FSDP sees every parameter); the reference's inference never produces it.  forward() handles it.
+            raise ValueError("generate(): 'text' samples are a training-only construct of the reference; use forward() for them")
         ids = [self.tokenizer_image_token(t) for t in samples["prompts"]]
         pad_id = getattr(self.tokenizer, "pad_token_id", 0) or 0
         ids_arr, mask = P.left_pad_truncate(ids, pad_id, self.max_txt_len)
@@ -248,7 +284,7 @@ class LLAVA_NEXT_VIDEO:
                     row = [int(t) for t, m in zip(ids_arr[i], mask[i]) if m]
                     emb = eng.splice(row, feats[i])
                     try:
-                        seqs.append(eng.seq_alloc(emb.shape[0] + max_new))
+                        seqs.append(eng.seq_alloc(min(emb.shape[0] + max_new, self.geo.max_seq)))
                     except GvlError as e:
                         if e.status == ERR_OOM and seqs:
                             break                      # pool full: run what fits, the rest in the next group
@@ -261,6 +297,26 @@ class LLAVA_NEXT_VIDEO:
                     eng.seq_free(seq)
             b += len(seqs)
         return out
+
+
+def geometry_from_checkpoint_dirs(llm: str, config_path: Optional[str], pretrained_vision_proj_llm_path: Optional[str]) -> TowerGeometry:
+    """Default geometry of an LLM family, completed from the HF config.json next to the weights: the reference builds its language
+    model from `<pretrained_vision_proj_llm_path>/language_model_seperated` (models/llava_next_video.py:149-151), whose config.json
+    carries rope_scaling.{short,long}_factor, both context limits, rope_theta and rms_norm_eps."""
+    import json
+    geo = {"phi3.5": TowerGeometry, "llama3": TowerGeometry.llama3_8b, "vicuna": TowerGeometry.vicuna_7b}[llm]()
+    geo.kv_pages = 0                   # production default: the paged KV pool takes the HBM left once the weights are resident
+    cands = []
+    if pretrained_vision_proj_llm_path:
+        cands.append(os.path.join(pretrained_vision_proj_llm_path, "language_model_seperated", "config.json"))
+    if config_path:
+        cands.append(os.path.join(config_path, "config.json"))
+    for c in cands:
+        if os.path.exists(c):
+            with open(c) as f:
+                geo.apply_hf_config(json.load(f))
+            break
+    return geo
 
 
 def load_reference_checkpoints(llm: str, pretrained_video_path: str, pretrained_vision_proj_llm_path: str):

@@ -30,17 +30,61 @@ def det_tensor(name: str, shape, std: float = 1.0, mean: float = 0.0) -> torch.T
     return torch.from_numpy(det_numpy(name, tuple(shape), std, mean))
 
 
-class _Gen:
-    """name -> tensor factory.  device='cpu': det_tensor (reproducible anywhere, used for parity);
-    device='cuda': torch.randn on the GPU (fast, full-size bench weights; not used for parity)."""
+_M32 = 0xFFFFFFFF
 
-    def __init__(self, seed: str, device="cpu"):
-        self.seed, self.device = seed, torch.device(device)
-        if self.device.type != "cpu":
+
+def _fmix32(x: torch.Tensor) -> torch.Tensor:
+    """murmur3 finaliser on 32-bit values held in int64 lanes (integer ops only: bit-identical on CPU and on the GPU)."""
+    x = x ^ (x >> 16)
+    x = (x * 0x85EBCA6B) & _M32
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & _M32
+    return x ^ (x >> 16)
+
+
+def exact_tensor(name: str, shape, std: float = 1.0, mean: float = 0.0, device="cpu", chunk: int = 1 << 26) -> torch.Tensor:
+    """Counter-based uniform tensor that is BIT-IDENTICAL on every device: element i = f(sha256(name), i) through two
+    murmur3 finalisers in integer arithmetic, 24 random bits -> f32 exactly, then two separately rounded IEEE f32
+    operations (scale, shift).  Used for the full-size goldens: the reference runs on CPU weights in the build container,
+    the HIP path regenerates the same weights on the GPU (no multi-GB fixture, no host->device copy)."""
+    dev = torch.device(device)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    assert n < (1 << 32), "exact_tensor: one tensor holds fewer than 2^32 elements"
+    s = _seed_of(name)
+    s0, s1 = s & _M32, (s >> 32) & _M32
+    scale = float(np.float32(2.0 * np.sqrt(3.0) * std))
+    shift = float(np.float32(mean))
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        i = torch.arange(lo, hi, dtype=torch.int64, device=dev)
+        h = _fmix32(i ^ s0)
+        h = _fmix32((h + s1) & _M32)
+        u = (h >> 8).to(torch.float32) * (1.0 / 16777216.0) - 0.5          # exact: 24-bit fraction, |u| < 0.5
+        u.mul_(scale)
+        if shift != 0.0:
+            u.add_(shift)
+        out[lo:hi] = u
+    return out.reshape(tuple(int(d) for d in shape))
+
+
+class _Gen:
+    """name -> tensor factory.
+    exact=True : exact_tensor on `device` (bit-identical on CPU and GPU; full-size parity goldens);
+    device='cpu': det_tensor (numpy PCG64 stream; the small round-1 goldens);
+    device='cuda': torch.randn on the GPU (fast full-size bench weights; not used for parity)."""
+
+    def __init__(self, seed: str, device="cpu", exact=False):
+        self.seed, self.device, self.exact = seed, torch.device(device), exact
+        if self.device.type != "cpu" and not exact:
             self.g = torch.Generator(device=self.device)
             self.g.manual_seed(_seed_of(seed) % (2 ** 31))
 
     def __call__(self, name, shape, std=0.02, mean=0.0):
+        if self.exact:
+            return exact_tensor(self.seed + "/" + name, shape, std, mean, self.device)
         if self.device.type == "cpu":
             return det_tensor(self.seed + "/" + name, shape, std, mean)
         t = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
@@ -48,9 +92,9 @@ class _Gen:
         return t
 
 
-def clip_weights(hidden=1024, inter=4096, layers=24, image=336, patch=14, seed="clip", device="cpu", prefix="vision_model."):
+def clip_weights(hidden=1024, inter=4096, layers=24, image=336, patch=14, seed="clip", device="cpu", prefix="vision_model.", exact=False):
     """State-dict keys of CLIPVisionModel (models/modeling_clip.py; SURVEY §8b weight contract)."""
-    g = _Gen(seed, device)
+    g = _Gen(seed, device, exact)
     P = (image // patch) ** 2 + 1
     W = {
         prefix + "embeddings.class_embedding": g("cls", (hidden,), 0.5),
@@ -77,10 +121,10 @@ def clip_weights(hidden=1024, inter=4096, layers=24, image=336, patch=14, seed="
     return W
 
 
-def iv2_weights(dim=1408, inter=6144, depth=40, frames=8, image=224, patch=14, seed="iv2", device="cpu"):
+def iv2_weights(dim=1408, inter=6144, depth=40, frames=8, image=224, patch=14, seed="iv2", device="cpu", exact=False):
     """State-dict keys of PretrainInternVideo2 that the hot path reads (models/internvideo2.py:766-1040).
     `depth` = number of block weight sets generated (the forward uses depth-1 of them)."""
-    g = _Gen(seed, device)
+    g = _Gen(seed, device, exact)
     L = (image // patch) ** 2
     W = {
         "cls_token": g("cls", (1, 1, dim), 0.5),
@@ -107,9 +151,9 @@ def iv2_weights(dim=1408, inter=6144, depth=40, frames=8, image=224, patch=14, s
     return W
 
 
-def projector_weights(llm="phi3.5", llm_hidden=3072, clip_hidden=1024, iv2_dim=1408, seed="proj", device="cpu"):
+def projector_weights(llm="phi3.5", llm_hidden=3072, clip_hidden=1024, iv2_dim=1408, seed="proj", device="cpu", exact=False):
     """multi_modal_projector / video_projecter / newline tensors (models/llava_next_video.py:26-54,122-145)."""
-    g = _Gen(seed, device)
+    g = _Gen(seed, device, exact)
     W = {}
     if llm == "phi3.5":
         cin = 4 * clip_hidden
@@ -133,10 +177,10 @@ def projector_weights(llm="phi3.5", llm_hidden=3072, clip_hidden=1024, iv2_dim=1
 
 
 def llm_weights(kind="phi3", hidden=3072, inter=8192, layers=32, heads=32, kv_heads=32, vocab=32366,
-                lm_head_bias=True, seed="llm", device="cpu"):
+                lm_head_bias=True, seed="llm", device="cpu", exact=False):
     """State-dict keys of Phi3ForCausalLM / LlamaForCausalLM; lm_head has a bias after
     reset_embeddings (models/llava_next_video.py:263)."""
-    g = _Gen(seed, device)
+    g = _Gen(seed, device, exact)
     d = hidden // heads
     sw = hidden ** -0.5
     W = {"model.embed_tokens.weight": g("embed", (vocab, hidden), 0.5),
@@ -168,3 +212,22 @@ def longrope_factors(head_dim=96):
     short = [1.0 + 0.2 * i / max(n - 1, 1) for i in range(n)]
     long = [1.0 + 63.0 * i / max(n - 1, 1) for i in range(n)]
     return short, long
+
+
+LORA_TARGETS = {"phi3": ("self_attn.qkv_proj", "self_attn.o_proj", "mlp.gate_up_proj", "mlp.down_proj"),
+                "llama": ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.up_proj", "mlp.down_proj",
+                          "mlp.gate_proj")}       # models/llava_next_video.py:219-222
+
+
+def lora_wrap(W, kind="phi3", r=128, seed="lora", device="cpu", exact=False, std=0.02):
+    """A plain LLM state dict -> the key layout of the reference's fine-tuned checkpoints: peft==0.3.0 wraps the model, so every key
+    gains the `base_model.model.` prefix and each target projection gains `lora_A.default.weight` [r, in] / `lora_B.default.weight`
+    [out, r] (models/llava_next_video.py:212-229; SURVEY §8b weight contract [ext])."""
+    g = _Gen(seed, device, exact)
+    out = {"base_model.model." + k: v for k, v in W.items()}
+    for k, v in W.items():
+        if k.endswith(".weight") and any(k.endswith(t + ".weight") for t in LORA_TARGETS[kind]):
+            base = "base_model.model." + k[: -len(".weight")]
+            out[base + ".lora_A.default.weight"] = g(k + ".A", (r, v.shape[1]), std)
+            out[base + ".lora_B.default.weight"] = g(k + ".B", (v.shape[0], r), std)
+    return out

@@ -69,7 +69,23 @@ def pack_clip(W: Dict[str, torch.Tensor], layers_run: int, prefix: str = "vision
     return out
 
 
-def pack_iv2(W: Dict[str, torch.Tensor], blocks_run: int, frames: int, ckpt_frames: Optional[int] = None) -> Dict[str, torch.Tensor]:
+def iv2_ckpt_frames(pos_rows: int, frames: int, tokens_per_frame: Optional[int] = None) -> int:
+    """Temporal size of a checkpoint's pos_embed [1, 1 + T*L, C].  With L known it is (rows-1)/L; otherwise the grid is square,
+    so T is the candidate -- the target `frames` first, then the reference's orig_t_size=4
+    (interpolate_pos_embed_internvideo2_new(..., orig_t_size=4), models/llava_next_video.py:131) -- whose L is a perfect square."""
+    n = pos_rows - 1
+    if tokens_per_frame:
+        if n % tokens_per_frame:
+            raise ValueError(f"iv2 pos_embed has {pos_rows} rows: not 1 + T*{tokens_per_frame}")
+        return n // tokens_per_frame
+    for t in (frames, 4):
+        if t > 0 and n % t == 0 and math.isqrt(n // t) ** 2 == n // t:
+            return t
+    raise ValueError(f"cannot infer the temporal size of an iv2 pos_embed with {pos_rows} rows; pass ckpt_frames / tokens_per_frame")
+
+
+def pack_iv2(W: Dict[str, torch.Tensor], blocks_run: int, frames: int, ckpt_frames: Optional[int] = None,
+             tokens_per_frame: Optional[int] = None) -> Dict[str, torch.Tensor]:
     out = {}
     pw = W["patch_embed.proj.weight"]
     Cd = pw.shape[0]
@@ -79,7 +95,9 @@ def pack_iv2(W: Dict[str, torch.Tensor], blocks_run: int, frames: int, ckpt_fram
     out["iv2.patch.b"] = W["patch_embed.proj.bias"].to(bf).float()      # bf16 module: the conv adds a bf16 bias
     out["iv2.cls"] = W["cls_token"].reshape(-1).to(bf)
     pos = W["pos_embed"]
-    if ckpt_frames is not None and ckpt_frames != frames:
+    if ckpt_frames is None:      # the released checkpoint is `-f4`: 4 temporal positions, interpolated to frames_per_seg at load
+        ckpt_frames = iv2_ckpt_frames(pos.shape[1], frames, tokens_per_frame)
+    if ckpt_frames != frames:
         pos = interpolate_pos_embed_t(pos, ckpt_frames, frames)
     out["iv2.pos"] = pos.reshape(-1, Cd).to(bf)
     for i in range(blocks_run):
@@ -126,6 +144,22 @@ def _strip_peft(W: Dict[str, torch.Tensor], alpha: float, r: int) -> Dict[str, t
             Bm = W[k.replace("lora_A", "lora_B")]
             out[base] = out[base].float() + (alpha / r) * (Bm.float() @ v.float())
     return out
+
+
+def reset_embeddings(W: Dict[str, torch.Tensor], n_new: int, lm_head_bias: bool = True) -> Dict[str, torch.Tensor]:
+    """LLAVA_NEXT_VIDEO.reset_embeddings (models/llava_next_video.py:231-268) on a BASE language-model state dict: the embedding and
+    the lm_head grow by n_new rows filled with the mean row; the new lm_head is an nn.Linear with a bias (its random default init is
+    replaced by zeros here -- the fine-tuned checkpoint overwrites it).  No-op when the dict already has the grown vocabulary."""
+    W = dict(W)
+    ek = next(k for k in W if k.endswith("embed_tokens.weight"))
+    hk = next(k for k in W if k.endswith("lm_head.weight"))
+    for k in (ek, hk):
+        w = W[k].float()
+        W[k] = torch.cat([w, w.mean(0, keepdim=True).expand(n_new, -1)], 0).to(W[k].dtype)
+    bk = hk[: -len("weight")] + "bias"
+    if lm_head_bias and bk not in W:
+        W[bk] = torch.zeros(W[hk].shape[0], dtype=torch.float32, device=W[hk].device)
+    return W
 
 
 def rope_tables(head_dim: int, max_seq: int, theta: float, factors: Optional[Sequence[float]], max_pos: int, orig_max_pos: int,

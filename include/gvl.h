@@ -74,6 +74,12 @@ int gvl_device_info(char* arch_out, int arch_len, int* num_cus);
 int gvl_load_weight(gvl_ctx* ctx, const char* name, const void* data, int dtype, const int64_t* shape,
                     int ndim, int is_device);
 int gvl_finalize_weights(gvl_ctx* ctx);               /* checks every required tensor is present */
+/* All packed tensors from ONE file written by tools/pack_checkpoint.py (`gvl-packed-1`: a safetensors container whose tensor
+ * names are the packed names above; LoRA merged, q/k/v fused, K padded, pos-embed interpolated, RoPE tables built offline).
+ * The C++ twin of `nn.Module.load_state_dict(torch.load(...))` (inference.py:156-162, models/llava_next_video.py:117-151) for a
+ * host that has no Python: the file is mapped read-only and every tensor goes through gvl_load_weight.  Synchronous.  Call
+ * gvl_finalize_weights afterwards.  *n_loaded (may be NULL) receives the number of tensors. */
+int gvl_load_packed(gvl_ctx* ctx, const char* path, int* n_loaded);
 
 /* ---- vision hot path ------------------------------------------------------------------------ */
 /* vision_tower(px, output_hidden_states=True).hidden_states[-2][:, 1:]
@@ -110,6 +116,11 @@ int gvl_splice(gvl_ctx* ctx, const int64_t* ids_host, int n_ids, const uint16_t*
  *                 (eos < 0 disables).  Synchronises the stream before returning. */
 int gvl_seq_alloc(gvl_ctx* ctx, int max_tokens, int* seq_id);
 int gvl_seq_free(gvl_ctx* ctx, int seq_id);
+/* Paged KV pool of this ctx (replaces transformers' DynamicCache, models/modeling_phi3.py:1291 [ext]): pages of 64 tokens over all
+ * layers.  cfg.kv_pages > 0 fixes the pool size at gvl_create; cfg.kv_pages <= 0 sizes it in gvl_finalize_weights from the HBM
+ * that is free once the weights are resident (env GVL_KV_FRACTION, default 0.85 of it, minus 4 GiB) -- on a 288 GB MI355X about
+ * 670 k Phi-3.5 tokens.  Any out pointer may be NULL. */
+int gvl_kv_info(const gvl_ctx* ctx, int* total_pages, int* free_pages, int64_t* pool_bytes, int* max_live_seqs);
 int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int seq_len, float* last_logits,
                 void* stream);
 int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t* out_ids_host,
@@ -141,6 +152,21 @@ int gvl_decode_steps(gvl_ctx* ctx, const int* seq_ids, int n_seqs, int n_steps, 
 int gvl_seq_read(gvl_ctx* ctx, int seq_id, int first, int32_t* out_ids_host, int cap, int* n_gen, void* stream);
 /* teacher-forced single step (parity tests): appends token `tok`, returns logits f32 [vocab]. */
 int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, void* stream);
+
+/* ---- multi-GPU exchange (SURVEY.md §8 e) -------------------------------------------------------------------------------------
+ * The reference's inference is single-GPU (inference.py:17); sharding the frame batch over the GPUs of a node is this build's
+ * addition: every rank encodes its segments, ONE all-gather moves the per-segment token blocks (llava_next_video.py:563) to
+ * every rank.  RCCL is loaded with dlopen("librccl.so.1") on first use; a host without RCCL gets GVL_ERR_STATE.
+ *   gvl_comm_unique_id : ncclGetUniqueId on rank 0; the 128 bytes travel to the other ranks by the host's own means
+ *   gvl_comm_init      : ncclCommInitRank on the ctx's device (collective over all ranks)
+ *   gvl_allgather_visual : local bf16 [rows_per_rank, hidden] -> all bf16 [world * rows_per_rank, hidden] (rank order) with
+ *                        ncclAllGather on the caller's stream; `comm` = an ncclComm_t the host already owns, or NULL for the
+ *                        ctx's communicator; world == 1 degenerates to one device copy. */
+int gvl_comm_unique_id(char id_out[128]);
+int gvl_comm_init(gvl_ctx* ctx, const char id[128], int rank, int world);
+int gvl_comm_destroy(gvl_ctx* ctx);
+int gvl_allgather_visual(gvl_ctx* ctx, void* comm, const uint16_t* local, int rows_per_rank, int hidden, uint16_t* all,
+                         void* stream);
 
 /* ---- training forward ---------------------------------------------------------- */
 /* LLAVA_NEXT_VIDEO.forward(samples)["loss"] for ONE sample (llava_next_video.py:598-614): the causal-LM loss of

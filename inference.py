@@ -100,7 +100,7 @@ def main(argv=None):
     np.random.seed(args.seed)
     if args.synthetic:
         if args.synthetic_scale == "full":
-            geo = TowerGeometry() if args.llm == "phi3.5" else TowerGeometry.llama3_8b()
+            geo = {"phi3.5": TowerGeometry, "llama3": TowerGeometry.llama3_8b, "vicuna": TowerGeometry.vicuna_7b}[args.llm]()
         else:
             geo = TowerGeometry(llm=args.llm, clip_layers=3, iv2_depth=3, hidden=512, inter=1024, layers=2, heads=4, kv_heads=4, vocab=2048,
                                 max_seq=4608, max_prefill=4096, kv_pages=80)
@@ -124,10 +124,8 @@ def main(argv=None):
                                  num_temporal_tokens=args.num_temporal_tokens, lora=args.lora, llm=args.llm,
                                  attn_implementation=args.attn_implementation, config_path=args.config_path, tokenizer_path=args.tokenizer_path,
                                  pretrained_video_path=args.pretrained_video_path,
-                                 pretrained_vision_proj_llm_path=args.pretrained_vision_proj_llm_path, device=args.device)
-        ckpt = torch.load(args.ckpt_path, map_location="cpu")["model"]
-        from grounded_video_llm_amd.model import load_reference_checkpoints
-        model.load_ckpt(ckpt, load_reference_checkpoints(args.llm, args.pretrained_video_path, args.pretrained_vision_proj_llm_path))
+                                 pretrained_vision_proj_llm_path=args.pretrained_vision_proj_llm_path, device=args.device,
+                                 ckpt_path=args.ckpt_path)          # base + fine-tuned overlay packed once (inference.py:156-162)
         frames, fps, vlen, duration = read_frames(args.video_path, args.num_frames)
 
     kw = {"do_sample": args.do_sample, "num_beams": args.num_beams, "max_new_tokens": args.max_new_tokens, "temperature": args.temperature, "top_p": args.top_p}

@@ -515,28 +515,45 @@ def _apply_rope(t, cos, sin, emu):
     return _r(_r(t * cos, emu) + _r(_rot_half(t) * sin, emu), emu)
 
 
+LORA_SCALE = 256.0 / 128.0     # lora_alpha / r, models/llava_next_video.py:217-218
+
+
+def _wlin(W, name: str, x, emu):
+    """One decoder projection `name` (no bias).  If the state dict carries peft LoRA factors for it
+    (`<name>.lora_A.default.weight` [r, in], `<name>.lora_B.default.weight` [out, r]) the UN-merged
+    peft==0.3.0 forward [ext, restated from its published algorithm -- parity unpinned] is evaluated:
+        result = F.linear(x, W);  result += lora_B(lora_A(dropout(x))) * scaling        (dropout = identity in eval)
+    exactly as the reference runs it at inference (the adapters are never merged, models/llava_next_video.py:212-224)."""
+    y = _lin(x, W[name + ".weight"], None, emu)
+    a = W.get(name + ".lora_A.default.weight")
+    if a is not None:
+        d = _lin(_lin(x, a, None, emu), W[name + ".lora_B.default.weight"], None, emu)
+        y = _r(y + _r(d * LORA_SCALE, emu), emu)
+    return y
+
+
 def _qkv(cfg: LLMConfig, W, p, h, emu):
     H, KV, d = cfg.heads, cfg.kv_heads, cfg.head_dim
     if cfg.kind == "phi3":
-        qkv = _lin(h, W[p + "self_attn.qkv_proj.weight"], None, emu)     # fused :659-663
+        qkv = _wlin(W, p + "self_attn.qkv_proj", h, emu)                  # fused :659-663
         q, k, v = qkv[..., : H * d], qkv[..., H * d: H * d + KV * d], qkv[..., H * d + KV * d:]
     else:
-        q = _lin(h, W[p + "self_attn.q_proj.weight"], None, emu)          # modeling_llama.py:432-434
-        k = _lin(h, W[p + "self_attn.k_proj.weight"], None, emu)
-        v = _lin(h, W[p + "self_attn.v_proj.weight"], None, emu)
+        q = _wlin(W, p + "self_attn.q_proj", h, emu)                       # modeling_llama.py:432-434
+        k = _wlin(W, p + "self_attn.k_proj", h, emu)
+        v = _wlin(W, p + "self_attn.v_proj", h, emu)
     return q, k, v
 
 
 def _mlp(cfg: LLMConfig, W, p, h, emu):
     if cfg.kind == "phi3":
-        gu = _lin(h, W[p + "mlp.gate_up_proj.weight"], None, emu)         # :459-464, gate = first half
+        gu = _wlin(W, p + "mlp.gate_up_proj", h, emu)                     # :459-464, gate = first half
         g, u = gu.chunk(2, dim=-1)
         a = _r(u * _r(F.silu(g), emu), emu)
-        return _lin(a, W[p + "mlp.down_proj.weight"], None, emu)
-    g = _lin(h, W[p + "mlp.gate_proj.weight"], None, emu)                 # modeling_llama.py:236
-    u = _lin(h, W[p + "mlp.up_proj.weight"], None, emu)
+        return _wlin(W, p + "mlp.down_proj", a, emu)
+    g = _wlin(W, p + "mlp.gate_proj", h, emu)                             # modeling_llama.py:236
+    u = _wlin(W, p + "mlp.up_proj", h, emu)
     a = _r(_r(F.silu(g), emu) * u, emu)
-    return _lin(a, W[p + "mlp.down_proj.weight"], None, emu)
+    return _wlin(W, p + "mlp.down_proj", a, emu)
 
 
 def llm_forward(cfg: LLMConfig, W, x: torch.Tensor, emu=False, cache=None, pos0: int = 0, last_only=False):
@@ -574,7 +591,7 @@ def llm_forward(cfg: LLMConfig, W, x: torch.Tensor, emu=False, cache=None, pos0:
         s = s.masked_fill((ki > qi)[None], float("-inf"))
         o = _r(_r(torch.softmax(s.float(), dim=-1), emu) @ vv, emu)
         o = o.transpose(0, 1).reshape(S, H * d)
-        x = _r(x + _lin(o, W[p + "self_attn.o_proj.weight"], None, emu), emu)
+        x = _r(x + _wlin(W, p + "self_attn.o_proj", o, emu), emu)
         h = _rmsnorm(x, W[p + "post_attention_layernorm.weight"], cfg.rms_eps, emu)
         x = _r(x + _mlp(cfg, W, p, h, emu), emu)
     if last_only:

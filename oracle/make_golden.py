@@ -393,8 +393,165 @@ def g_pre(ns):
     save("preprocess", dict(cases=meta, pillow=PIL.__version__), **arrays)
 
 
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[0] at REAL width and depth (missing #1): Phi-3.5, 8 frames / 1 segment, the reference's own
+# modules on CPU in fp32 -- CLIP 24 L (hidden_states[-2] = 23 layers), InternVideo2 40 blocks (39 run, S = 2049),
+# encode_images + prepare_multimodal_inputs, Phi-3.5 32 L with the O(n^2) greedy of SURVEY §8(c) for 12 tokens.
+# Weights come from synth.exact_tensor (bit-identical on CPU and GPU), so the fixture holds outputs only.
+C0_NEW_TOKENS = 12
+
+
+def c0_ids(n_text=100, slot=36):
+    """Prompt ids of the C0 clip: n_text ids U[3, 32000) from a fixed numpy stream, -200 at the template's image slot."""
+    ids = np.random.RandomState(42).randint(3, 32000, size=n_text).tolist()
+    ids[slot] = -200
+    return ids
+
+
+def _stream_load(module, gen_W):
+    """load_state_dict without holding two copies of every tensor for long: gen_W() builds the dict, tensors are moved in one by one."""
+    W = gen_W()
+    sd = module.state_dict()
+    missing = [k for k in sd if k not in W and not k.startswith(_IV2_EXTRA)]
+    assert not missing, missing[:10]
+    with torch.no_grad():
+        for k in list(W.keys()):
+            assert k in sd, k
+            sd[k].copy_(W.pop(k).reshape(sd[k].shape))
+    return module.eval()
+
+
+def g_c0(ns):
+    import copy
+    import time
+    L = ns.llava
+    t00 = time.time()
+
+    class Skel(L.LLAVA_NEXT_VIDEO):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+
+        def get_input_embeddings(self):
+            return self.embed
+
+    hid = 3072
+    sk = Skel()
+    sk.llm, sk.dtype = "phi3.5", torch.float32
+    c = copy.deepcopy(L.CLIP_VIT_LARGE_PATCH14_336_CONFIG)
+    c._attn_implementation = "eager"
+    assert c.num_hidden_layers == 24 and c.hidden_size == 1024 and c.intermediate_size == 4096
+    sk.vision_tower = _stream_load(ns.clip.CLIPVisionModel(c), lambda: synth.clip_weights(seed="c0.clip", exact=True))
+    sk.video_encoder = _stream_load(_iv2(ns, 1408, 40, 16, 48 / 11, 224, 8), lambda: synth.iv2_weights(seed="c0.iv2", exact=True))
+    assert sk.video_encoder.blocks[0].mlp.fc1.weight.shape[0] == 6144 and len(sk.video_encoder.blocks) == 40
+    Wp = synth.projector_weights("phi3.5", hid, 1024, 1408, seed="c0.proj", exact=True)
+    sk.video_projecter = load_into(L.Video_Projecter(1408, hid), {k[len("video_projecter."):]: v for k, v in Wp.items() if k.startswith("video_projecter.")})
+    sk.multi_modal_projector = load_into(L.Phi3_5_Projecter(), {k[len("multi_modal_projector."):]: v for k, v in Wp.items() if k.startswith("multi_modal_projector.")})
+    sk.glb_GN, sk.sub_GN = Wp["glb_GN"], Wp["sub_GN"]
+    sk.config = type("C", (), {"hidden_size": hid})()
+    print(f"[c0] vision modules built {time.time() - t00:.0f}s", flush=True)
+
+    sp = synth.exact_tensor("c0.sp", (1, 1, 3, 336, 336))
+    tp = synth.exact_tensor("c0.tp", (1, 8, 3, 224, 224))
+    t0 = time.time()
+    clip_pen = sk.vision_tower(sp[0], output_hidden_states=True).hidden_states[-2][:, 1:]            # llava_next_video.py:504-505
+    t_clip = time.time() - t0
+    t0 = time.time()
+    tseg = tp.reshape(1, 1, 8, 3, 224, 224).permute(0, 1, 3, 2, 4, 5).flatten(0, 1)                   # (b s) c f h w, :527-529
+    iv2_out = sk.video_encoder(tseg, None, False, x_vis_return_idx=-2, x_vis_only=True)[:, 1:, :]      # :532
+    t_iv2 = time.time() - t0
+    # the same module in bf16 on the CPU (what `video_encoder.to(bfloat16)` computes, :134): how far a bf16 evaluation of the
+    # REFERENCE is from its own fp32 evaluation at this depth -- the yardstick for the HIP path's tolerance
+    vb = copy.deepcopy(sk.video_encoder).to(torch.bfloat16)
+    iv2_bf = vb(tseg, None, False, x_vis_return_idx=-2, x_vis_only=True)[:, 1:, :].float()
+    del vb
+    t0 = time.time()
+    feats = sk.encode_images({"spatial_pixel_values": sp, "temporal_pixel_values": tp})               # [1, 285, 3072]
+    t_enc = time.time() - t0
+    assert list(feats.shape) == [1, 285, hid]
+    print(f"[c0] clip {t_clip:.1f}s iv2 {t_iv2:.1f}s encode_images {t_enc:.1f}s; iv2 bf16-vs-fp32 rel "
+          f"{float((iv2_bf - iv2_out).abs().max() / iv2_out.abs().max()):.3e}", flush=True)
+    del sk.vision_tower, sk.video_encoder
+
+    # ---- Phi-3.5-mini, 32 layers, vocab 32064 + 302 with the lm_head bias of reset_embeddings (:263)
+    short, long = synth.longrope_factors(96)
+    cfg = _phi_cfg(ns, 3072, 8192, 32, 32, 32, 32366, short, long)
+    m = ns.phi3.Phi3ForCausalLM(cfg)
+    m.lm_head = torch.nn.Linear(3072, 32366, bias=True)
+    _stream_load(m, lambda: synth.llm_weights("phi3", seed="c0.llm", exact=True))
+    sk.embed = m.get_input_embeddings()
+    print(f"[c0] phi built {time.time() - t00:.0f}s", flush=True)
+    ids = c0_ids()
+    tid = torch.tensor([ids])
+    emb, _, mask = sk.prepare_multimodal_inputs(tid, tid.clone(), torch.ones_like(tid), feats, ["vid"])   # :568-596
+    S = emb.shape[1]
+    assert S == len(ids) - 1 + 285 and bool(mask.all())
+    e = sk.embed.weight
+    seq = emb.clone()
+    gid, top1, top2, id2, steplog = [], [], [], [], []
+    t_llm = []
+    for step in range(C0_NEW_TOKENS):
+        t0 = time.time()
+        lg = m(inputs_embeds=seq, use_cache=False).logits[0, -1].float()
+        t_llm.append(time.time() - t0)
+        t2 = torch.topk(lg, 2)
+        gid.append(int(t2.indices[0])); id2.append(int(t2.indices[1]))
+        top1.append(float(t2.values[0])); top2.append(float(t2.values[1]))
+        steplog.append(lg.clone())
+        seq = torch.cat([seq, e[gid[-1]][None, None]], dim=1)
+        print(f"[c0] greedy step {step}: id {gid[-1]} margin {top1[-1] - top2[-1]:.4f} ({t_llm[-1]:.1f}s)", flush=True)
+    steplog = torch.stack(steplog)                                                      # [12, 32366]
+    # bf16 evaluation of the reference LLM on the same prefix (teacher-forced on the fp32 ids): last-row logits per step
+    mb = m.to(torch.bfloat16)
+    seqb = seq[:, :S + C0_NEW_TOKENS - 1].to(torch.bfloat16)
+    lb = mb(inputs_embeds=seqb, use_cache=False).logits[0, S - 1:].float()              # rows S-1 .. S+10 = the 12 predicting rows
+    assert lb.shape[0] == C0_NEW_TOKENS
+    scale = float(steplog.abs().max())
+    print(f"[c0] phi bf16-vs-fp32 logits rel {float((lb - steplog).abs().max()) / scale:.3e} (scale {scale:.3f}); "
+          f"bf16 argmax agrees on {int((lb.argmax(-1) == steplog.argmax(-1)).sum())}/12 steps", flush=True)
+    timing = dict(threads=torch.get_num_threads(), clip_s=t_clip, iv2_s=t_iv2, encode_images_s=t_enc, llm_forward_s=t_llm)
+    save("c0_full", dict(seeds=dict(clip="c0.clip", iv2="c0.iv2", proj="c0.proj", llm="c0.llm", sp="c0.sp", tp="c0.tp"), ids=ids,
+                         S=S, new_tokens=C0_NEW_TOKENS, stride=dict(clip=[7, 5], iv2=[17, 11], feats=[1, 8], emb=[3, 16], logits=4),
+                         reference_cpu_fp32_timing=timing, greedy_ids=gid, second_ids=id2),
+         clip_penultimate=clip_pen[:, ::7, ::5], iv2_out=iv2_out[:, ::17, ::11], iv2_out_bf16ref=iv2_bf[:, ::17, ::11],
+         feats=feats[:, :, ::8], emb=emb[:, ::3, ::16],
+         logits_step0=steplog[0], logits_last=steplog[-1], logits_steps=steplog[:, ::4], logits_steps_bf16ref=lb[:, ::4],
+         top1=np.array(top1), top2=np.array(top2))
+
+
+def full_layer_ids(n=64, vocab=64):
+    return [int(v) for v in np.random.RandomState(7).randint(0, vocab, size=n)]
+
+
+def g_llama_full(ns):
+    """Full-width single Llama-3-8B decoder layer (4096 / 14336, 32 q-heads / 8 kv-heads x 128, theta 5e5; SURVEY §8c G2, VERDICT r1
+    missing #3): logits of every position of a 64-token sequence whose inputs are embedding rows, so that the HIP prefill path
+    (rows 0..62 / 0..63) AND its paged-KV decode step (row 63 from the token id) are both checked against the reference."""
+    from transformers import LlamaConfig
+    cfg = dict(kind="llama", hidden=4096, inter=14336, layers=1, heads=32, kv_heads=8, vocab=64, rope_theta=500000.0)
+    c = LlamaConfig(vocab_size=64, hidden_size=4096, intermediate_size=14336, num_hidden_layers=1, num_attention_heads=32,
+                    num_key_value_heads=8, rms_norm_eps=1e-5, max_position_embeddings=8192, pad_token_id=0, bos_token_id=1,
+                    eos_token_id=2, attention_bias=False)
+    c.rope_theta = 500000.0
+    c.rope_scaling = None
+    c.pretraining_tp = 1
+    c.attention_dropout = 0.0
+    c.mlp_bias = False
+    c._attn_implementation = "eager"
+    m = ns.llama.LlamaForCausalLM(c)
+    m.lm_head = torch.nn.Linear(4096, 64, bias=True)
+    load_into(m, synth.llm_weights("llama", 4096, 14336, 1, 32, 8, 64, True, seed="g.llama.full", exact=True))
+    ids = full_layer_ids()
+    x = m.get_input_embeddings().weight[torch.tensor(ids)][None]
+    logits = m(inputs_embeds=x, use_cache=False).logits
+    mb = m.to(torch.bfloat16)
+    lb = mb(inputs_embeds=x.to(torch.bfloat16), use_cache=False).logits.float()
+    print("llama full layer: bf16-vs-fp32 rel", float((lb - logits).abs().max() / logits.abs().max()))
+    save("llama_full_layer", dict(cfg=cfg, seed="g.llama.full", exact=True, ids=ids), logits=logits, logits_bf16ref=lb)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["int", "clip", "iv2", "phi3", "llama", "glue", "pre", "train"]
     ns = ref_shims.load_reference() if any(w != "pre" for w in which) else None
     for w in which:
-        {"int": g_int, "clip": g_clip, "iv2": g_iv2, "phi3": g_phi3, "llama": g_llama, "glue": g_glue, "pre": g_pre, "train": g_train}[w](ns)
+        {"int": g_int, "clip": g_clip, "iv2": g_iv2, "phi3": g_phi3, "llama": g_llama, "glue": g_glue, "pre": g_pre, "train": g_train, "c0": g_c0,
+         "llama_full": g_llama_full}[w](ns)

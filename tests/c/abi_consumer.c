@@ -14,6 +14,18 @@ int main(void) {
   int di = gvl_device_info(arch, (int)sizeof arch, &cus);
   int rc = gvl_create(&cfg, &ctx);
   printf("device_info=%d arch=%s cus=%d create=%d err=%s\n", di, arch, cus, rc, gvl_last_error(NULL));
+  /* the entry points a non-Python host needs to run the whole path must link from C and reject a NULL ctx without crashing:
+   * weights from ONE packed file, KV pool query, the visual-token exchange */
+  {
+    int n = -1, tp = -1;
+    char uid[128];
+    memset(uid, 0, sizeof uid);
+    if (gvl_load_packed(NULL, "/nonexistent.gvl.safetensors", &n) != GVL_ERR_ARG) return 4;
+    if (gvl_kv_info(NULL, &tp, NULL, NULL, NULL) != GVL_ERR_ARG) return 5;
+    if (gvl_allgather_visual(NULL, NULL, NULL, 0, 0, NULL, NULL) != GVL_ERR_ARG) return 6;
+    if (gvl_comm_init(NULL, uid, 0, 1) != GVL_ERR_ARG) return 7;
+    if (gvl_comm_destroy(NULL) != GVL_ERR_ARG) return 8;
+  }
   if (di == GVL_ERR_NOGPU) return (rc == GVL_ERR_NOGPU && ctx == NULL) ? 0 : 2;   /* no GPU: must refuse */
   if (rc == 0 && ctx) gvl_destroy(ctx);                                           /* GPU present: an all-zero config is a valid empty ctx or an ARG error */
   return (rc == 0 || rc == GVL_ERR_ARG) ? 0 : 3;

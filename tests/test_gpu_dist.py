@@ -1,0 +1,66 @@
+"""-m gpu: first contact with RCCL on a 1-GPU box (missing #5): the nccl backend of torch.distributed at world_size 1
+and libgvl's own communicator (gvl_comm_init / gvl_allgather_visual through the C ABI) both run a REAL (degenerate) all-gather on the
+device -- library load, communicator init, bf16 dtype, stream ordering -- before the driver's N > 1 runs do.  The multi-rank
+arithmetic of the plan is covered on CPU by tests/test_dist_cpu.py (gloo, world_size 2)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, bf, tiny_geo  # noqa: E402
+from grounded_video_llm_amd import dist as gdist, engine as E  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def nccl_world1():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    yield
+    torch.distributed.destroy_process_group()
+
+
+def test_torch_nccl_allgather_visual_world1(nccl_world1):
+    L, H, n = 285, 3072, 12
+    g = torch.Generator(device=DEV); g.manual_seed(1)
+    local = torch.randn((n * L, H), device=DEV, generator=g).to(bf)
+    out = gdist.allgather_visual(local, n, L, None, force_collective=True)        # all_gather_into_tensor on RCCL, bf16, padded blocks
+    assert out.dtype == bf and torch.equal(out, local)
+
+
+def test_bench_exchange_path_world1(nccl_world1):
+    """bench.py's per-step exchange (ONE all-gather for the step's clip rounds + segment-order re-assembly) on the nccl backend."""
+    import bench
+    st = bench.Stepper.__new__(bench.Stepper)
+    st.world, st.rank, st.dev, st.L = 1, 0, torch.device(DEV), 285
+    g = torch.Generator(device=DEV); g.manual_seed(2)
+    vis = [torch.randn((12 * 285, 3072), device=DEV, generator=g).to(bf) for _ in range(4)]
+    side = torch.cuda.Stream(DEV)                                                    # the bench runs the exchange on its vision stream
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got = st._exchange_multi(vis, force=True)
+    torch.cuda.current_stream().wait_stream(side)
+    assert len(got) == 4 and all(torch.equal(a, b) for a, b in zip(got, vis))
+
+
+def test_c_abi_rccl_communicator_world1():
+    """gvl_comm_unique_id / gvl_comm_init / gvl_allgather_visual: what a non-Python host calls (include/gvl.h)."""
+    eng = E.Engine(tiny_geo(), DEV, towers=())
+    local = (torch.arange(7 * 64, device=DEV, dtype=torch.float32).view(7, 64) / 17).to(bf)
+    assert torch.equal(eng.allgather_visual(local), local)          # no communicator yet: single-rank copy
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128 and uid != bytes(128)
+    eng.comm_init(uid, 0, 1)
+    s = torch.cuda.Stream(DEV)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        out = eng.allgather_visual(local)                             # ncclAllGather on the caller's (side) stream
+    torch.cuda.current_stream().wait_stream(s)
+    assert out.shape == local.shape and torch.equal(out, local)
+    with pytest.raises(E.L.GvlError):
+        eng.comm_init(uid, 0, 1)                                      # already initialised
+    eng.close()

@@ -88,8 +88,21 @@ def test_generate_matches_oracle(llm):
         Wt.save_packed(path, packed)
         m2 = LLAVA_NEXT_VIDEO(stage="sft", max_txt_len=64, num_frames=4, num_segs=2, num_temporal_tokens=300, lora=False, llm=llm,
                               geometry=g2, tokenizer=tok, packed_weights=path, device=DEV)
-        assert m2.generate(samples, do_sample=False, num_beams=1, max_new_tokens=10) == texts
+        assert m2.generate(samples, do_sample=False, num_beams=1, max_new_tokens=10) == texts       # weights came through gvl_load_packed (C++)
         m2.engine.close()
+        # the C++ reader agrees tensor by tensor with the Python one, and refuses a file that is not a packed weight file
+        e3 = E.Engine(g2, DEV)
+        assert e3.load_packed_file(path) == len(packed)
+        from safetensors.torch import save_file
+        other = os.path.join(td, "other.safetensors")
+        save_file({"x": torch.zeros(4)}, other)
+        with pytest.raises(E.L.GvlError, match="not a gvl packed"):
+            e3.load_packed_file(other)
+        with open(os.path.join(td, "trunc.safetensors"), "wb") as f:
+            f.write(open(path, "rb").read()[:1000])
+        with pytest.raises(E.L.GvlError):
+            e3.load_packed_file(os.path.join(td, "trunc.safetensors"))
+        e3.close()
 
 
 @pytest.mark.parametrize("llm", ["phi3.5", "llama3"])

@@ -339,3 +339,76 @@ def test_forward_loss_matches_reference_golden():
     with pytest.raises(RuntimeError):
         eng.forward_loss(x, [-100] * 69 + [c["vocab"]])
     eng.close()
+
+
+def test_llama3_8b_full_width_layer_prefill_and_decode():
+    """Full-width Llama-3-8B decoder layer (4096 / 14336, GQA 32/8 heads of 128, theta 5e5) against the reference's own
+    LlamaForCausalLM (tests/golden/llama_full_layer.npz, weights from synth.exact_tensor regenerated ON THE GPU): every row of a
+    64-token prefill is checked through teacher-forced prefixes -- prefill(63 rows) -> row 62, then ONE paged-KV decode step on the
+    64th token -> row 63 -- plus the 64-row prefill's last row.  SURVEY §8c G2 / models/modeling_llama.py:699-760, :417-497."""
+    meta, g = load_golden("llama_full_layer")
+    c = meta["cfg"]
+    geo = tiny_geo(llm="llama3", hidden=c["hidden"], inter=c["inter"], layers=1, heads=c["heads"], kv_heads=c["kv_heads"], vocab=c["vocab"],
+                   rope_theta=c["rope_theta"], rope_orig_max_pos=0, max_seq=256, max_prefill=128, kv_pages=4)
+    W = synth.llm_weights("llama", c["hidden"], c["inter"], 1, c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"], device=DEV, exact=True)
+    eng = llm_engine(geo, W)
+    ids = meta["ids"]
+    x = W["model.embed_tokens.weight"].to(bf)[torch.tensor(ids, device=DEV)]
+    gold, gold_bf = g["logits"][0], g["logits_bf16ref"][0]
+    scale = float(np.abs(gold).max())
+    ref_bf_err = float(np.abs(gold_bf - gold).max()) / scale
+    print(f"[parity] llama full layer: the reference's own bf16 evaluation is {ref_bf_err:.2e} from its fp32 evaluation")
+    seq = eng.seq_alloc(128)
+    l64 = eng.prefill(seq, x, want_logits=True).clone()
+    eng.seq_free(seq)
+    e_pf = check(l64, gold[63], 1e-2, "llama-3-8B full-width layer, prefill S=64 last row vs reference (fp32)")
+    seq = eng.seq_alloc(128)
+    l63 = eng.prefill(seq, x[:63], want_logits=True).clone()
+    check(l63, gold[62], 1e-2, "llama-3-8B full-width layer, prefill S=63 last row vs reference (fp32)")
+    ld = eng.decode_step_logits(seq, ids[63])
+    eng.seq_free(seq)
+    e_dec = check(ld, gold[63], 1e-2, "llama-3-8B full-width layer, paged-KV decode step (row 63) vs reference (fp32)")
+    assert max(e_pf, e_dec) <= max(4e-3, 1.5 * ref_bf_err), "HIP path is further from fp32 than 1.5x the reference's own bf16 evaluation"
+    eng.close()
+
+
+@pytest.mark.parametrize("case", ["tiny", "full_width"])
+def test_lora_merged_on_device_equals_unmerged_peft_forward(case):
+    """a11' (models/llava_next_video.py:212-229): the reference runs peft LoRA UN-merged, y = W x + 2 B(A x); libgvl merges
+    W' = W + 2 B A at load (weights.pack_llm on peft-keyed state dicts).  HIP logits from the merged weights vs the oracle's
+    un-merged forward (oracle._wlin, restated from peft 0.3.0 -- peft is absent here, so this pins the ALGEBRA, not peft's code).
+    The two differ only by where bf16 rounding happens (W' is rounded once; the un-merged path rounds Wx, Ax, B(Ax) separately)."""
+    if case == "tiny":
+        c = dict(hidden=64, inter=128, layers=2, heads=4, kv_heads=4, vocab=100); r, S, tol = 8, 24, TINY_TOL
+    else:
+        c = dict(hidden=3072, inter=8192, layers=1, heads=32, kv_heads=32, vocab=64); r, S, tol = 128, 64, 1e-2
+    geo = _phi_geo(c, max_seq=256, max_prefill=128, kv_pages=4)
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.lora." + case)
+    Wp = synth.lora_wrap(W, "phi3", r=r, seed="t.lora.ab." + case, std=0.5 * c["hidden"] ** -0.5)
+    assert sum("lora_A" in k for k in Wp) == 4 * c["layers"]
+    from grounded_video_llm_amd import weights as Wt
+    eng = E.Engine(geo, DEV, towers=("llm",))
+    eng.load_packed(Wt.pack_llm(Wp, "phi3", geo.layers, geo.heads, geo.kv_heads, geo.max_seq, geo.rope_theta, geo.rope_short, geo.rope_long,
+                                geo.rope_max_pos, geo.rope_orig_max_pos, lora_alpha=2.0 * r, lora_r=r))
+    eng.finalize()
+    x = synth.det_tensor("t.lora.x." + case, (S, c["hidden"]), 0.5)
+    Wo = {k[len("base_model.model."):]: v for k, v in Wp.items()}
+    ocfg = _ocfg(geo)
+    ref32 = O.llm_forward(ocfg, Wo, x, False, None, 0, last_only=True)[0]          # un-merged peft forward, fp32
+    ref_emu = O.llm_forward(ocfg, Wo, x, True, None, 0, last_only=True)[0]         # un-merged, bf16 roundings of the reference GPU path
+    base32 = O.llm_forward(ocfg, W, x, False, None, 0, last_only=True)[0]          # without the adapters: they must matter
+    scale = float(ref32.abs().max())
+    assert float((ref32 - base32).abs().max()) > 0.05 * scale, "the LoRA factors of this test do not change the logits"
+    seq = eng.seq_alloc(S + 8)
+    got = eng.prefill(seq, x.to(DEV).to(bf), want_logits=True)
+    check_bf16_class(got, ref32, ref_emu, tol, f"LoRA {case}: merged-on-device prefill logits vs un-merged peft forward (fp32)")
+    # one decode step through the merged GEMV path
+    tok = 5
+    lg = eng.decode_step_logits(seq, tok)
+    e = W["model.embed_tokens.weight"].to(bf).float()
+    xx = torch.cat([x.to(bf).float(), e[tok][None]], 0)
+    ref32d = O.llm_forward(ocfg, Wo, xx, False, None, 0, last_only=True)[0]
+    ref_emud = O.llm_forward(ocfg, Wo, xx, True, None, 0, last_only=True)[0]
+    check_bf16_class(lg, ref32d, ref_emud, tol, f"LoRA {case}: merged decode step vs un-merged peft forward (fp32)")
+    eng.seq_free(seq)
+    eng.close()

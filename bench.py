@@ -415,6 +415,17 @@ def main():
         decode_tok_s_batched = cps * (args.new_tokens - 1) / (time.perf_counter() - tb)
         for q in seqs:
             eng.seq_free(q)
+    # the decode path at the width it is built for: 16 sequences share one weight stream per step (skinny MFMA GEMM, gvl_decode.hip)
+    decode_tok_s_16 = None
+    if os.environ.get("GVL_BENCH_DECODE16", "1") != "0":
+        vis = st.encode()
+        seqs = [st.llm(vis)[0] for _ in range(16)]
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        eng.decode_greedy_batch(seqs, args.new_tokens, None)
+        decode_tok_s_16 = 16 * (args.new_tokens - 1) / (time.perf_counter() - tb)
+        for q in seqs:
+            eng.seq_free(q)
     eng.prof_enable(True)
     st.step()
     prof = {}
@@ -472,6 +483,7 @@ def main():
                           "parallelism": "1 GPU" if world == 1 else f"frame-batch sharded over {world} GPUs + all-gather of visual tokens, LLM replica per clip"},
                "decode_tokens_per_s": None if decode_tok_s is None else round(world * decode_tok_s, 1),
                "decode_tokens_per_s_batched": None if decode_tok_s_batched is None else round(world * decode_tok_s_batched, 1),
+               "decode_tokens_per_s_16seq": None if decode_tok_s_16 is None else round(world * decode_tok_s_16, 1),
                "clips_per_s_incl_pixel_h2d": None if clips_per_s_h2d is None else round(clips_per_s_h2d, 4), "single_clip_latency_ms": round(latency_ms, 2), "mode": args.mode, "ids_match_serial": same_ids,
                "roofline": roofline, "stages": stages, "kv_pool": eng.kv_info()}
         if per_rank is not None:

@@ -721,7 +721,7 @@ static int launch_gemv_b(const GemvArgs& a, int R, int blocks, size_t lds, hipSt
 int gvl_launch_gemv(const GemvArgs& a_in, hipStream_t st) {
   GemvArgs a = a_in;
   if (a.batch <= 0) a.batch = 1;
-  if (a.K % 8 || a.K > 32768 || a.batch > GVL_MAX_DECODE_BATCH || a.batch == 3) return -1;
+  if (a.K % 8 || a.K > 32768 || a.batch > GVL_MAX_VALU_BATCH || a.batch == 3) return -1;
   if (a.batch == 1) { a.x_stride = 0; a.out_stride = 0; a.q_stride = 0; }
   const size_t lds = (size_t)a.K * 2 * a.batch;
   if (lds > 159 * 1024) return -1;
@@ -762,7 +762,8 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a) {
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
     *a.tok_ptrs[b] = idx;
-    if (a.out_lists[b]) a.out_lists[b][a.steps[b]] = idx;
+    if (a.ngen_ptrs[b]) { const int g = *a.ngen_ptrs[b]; if (a.out_lists[b]) a.out_lists[b][g] = idx; *a.ngen_ptrs[b] = g + 1; }
+    if (a.pos_ptrs[b]) (*a.pos_ptrs[b])++;
   }
 }
 int gvl_launch_argmax(const ArgmaxArgs& a, hipStream_t st) {

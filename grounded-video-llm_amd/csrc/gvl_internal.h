@@ -12,6 +12,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 #define GVL_KV_PAGE 64          // tokens per KV page == key tile of the attention kernels
+constexpr int GVL_MAX_DECODE_BATCH = 16;  // sequences decoded together: the weight stream is read ONCE for all of them;
+                                          // = the 16 columns of the MFMA B operand of the skinny decode GEMM (gvl_decode.hip)
+constexpr int GVL_MAX_VALU_BATCH = 4;     // the round-1 VALU GEMV (fallback for K % 256 != 0 geometries) holds B vectors in LDS: 1, 2 or 4
+constexpr int GVL_MAX_PREFILL_BATCH = 4;  // sequences whose rows share one pass of the prefill GEMMs
 
 // ---- device helpers ---------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -139,8 +143,8 @@ double gvl_attn_flops(const AttnArgs& a);
 struct DecodeAttnArgs {
   const bf16_t* q;        // [batch][H][D], q_stride elements apart
   const bf16_t* Kt; const bf16_t* Vt;   // page pools (one layer)
-  const int* tables[4];   // per sequence: [max_pages]
-  const int* pos_ptrs[4]; // per sequence, device: index of the new token (the cache holds *pos + 1 tokens, new one included)
+  const int* tables[GVL_MAX_DECODE_BATCH];   // per sequence: [max_pages]
+  const int* pos_ptrs[GVL_MAX_DECODE_BATCH]; // per sequence, device: index of the new token (the cache holds *pos + 1 tokens, new one included)
   float* part;            // workspace [batch][H][nsplit][D+2]
   int* counters;          // [batch][H] arrival tickets, zero between launches (the merging block re-arms them)
   bf16_t* out;            // [batch][H*Dout], out_stride elements apart
@@ -187,7 +191,6 @@ int gvl_launch_bcast_row(const bf16_t* row, bf16_t* dst, int n, int stride_rows,
 int gvl_launch_gather_rows(const bf16_t* table, const int* ids, bf16_t* dst, int n, int cols, hipStream_t st);
 int gvl_launch_strip_cls(const void* x, void* y, int n, int S, int C, int elem_bytes, hipStream_t st);
 // decode-side
-constexpr int GVL_MAX_DECODE_BATCH = 4;   // sequences decoded together: the weight stream is read ONCE for all of them
 struct GemvArgs {
   const bf16_t* W; int N, K;      // [N][K]
   const bf16_t* x;                // [batch][K] bf16, rows x_stride elements apart
@@ -203,20 +206,30 @@ struct GemvArgs {
   int rope_on; const float *cos_s, *sin_s, *cos_l, *sin_l; int rope_switch;
   const int* pos_ptrs[GVL_MAX_DECODE_BATCH]; const int* tables[GVL_MAX_DECODE_BATCH];   // per sequence of the batch
   bf16_t *Q, *Kt, *Vt; int H, KV, Dr, D; int q_stride;
+  // skinny-GEMM path only (gvl_launch_dgemm): the LAST block of the launch writes tail_xn[b][:] = bf16(tail_norm_w * bf16(out_bf16[b][:] * rstd))
+  // for b < batch -- the RMSNorm in front of the NEXT projection, done once by the producer of the residual stream
+  const bf16_t* tail_norm_w; float tail_eps; bf16_t* tail_xn; int tail_stride; int* tail_counter;
 };
 int gvl_launch_gemv(const GemvArgs& a, hipStream_t st);
+// the same projection as ONE MFMA skinny GEMM for 1..16 sequences (gvl_decode.hip); -1 when the geometry needs the VALU kernel
+int gvl_launch_dgemm(const GemvArgs& a, hipStream_t st);
 // greedy sampling for `batch` logit rows (stride n): token -> *tok_ptrs[b] and out_lists[b][steps[b]]
 // small host int list passed to kernels by value (stream ordered, no host / staging buffer lifetime)
-struct IntList { int v[GVL_MAX_DECODE_BATCH * 64]; int n; };
+struct IntList { int v[256]; int n; };
 // dst[r] = table[host_ids[r]], ids travel in the kernel arguments (256 per launch)
 int gvl_launch_gather_rows_host_ids(const bf16_t* table, const int* host_ids, int n, bf16_t* dst, int cols, hipStream_t st);
 // loss tail of the training forward: nll[r] = logsumexp(logits[r]) - logits[r][targets[r]] (f32 on bf16 logits)
 int gvl_launch_ce_rows(const bf16_t* logits, int ld, const int* targets, float* nll, int n, int V, hipStream_t st);
-struct ArgmaxArgs { const float* logits; int n, batch; int* tok_ptrs[GVL_MAX_DECODE_BATCH]; int* out_lists[GVL_MAX_DECODE_BATCH]; int steps[GVL_MAX_DECODE_BATCH]; };
+// token -> *tok_ptrs[b] and out_lists[b][*ngen_ptrs[b]]; then (*ngen_ptrs[b])++ and, when non-null, (*pos_ptrs[b])++ (the step's
+// bookkeeping lives on the device: a decode step's launches carry no host-side counters)
+struct ArgmaxArgs { const float* logits; int n, batch; int* tok_ptrs[GVL_MAX_DECODE_BATCH]; int* out_lists[GVL_MAX_DECODE_BATCH];
+                    int* ngen_ptrs[GVL_MAX_DECODE_BATCH]; int* pos_ptrs[GVL_MAX_DECODE_BATCH]; };
 int gvl_launch_argmax(const ArgmaxArgs& a, hipStream_t st);
 // x[b][:] = table[*tok_ptrs[b]][:]  and  (*pos_ptrs[b])++ helpers of the batched decode loop
 struct TokPtrs { const int* p[GVL_MAX_DECODE_BATCH]; int n; };
 int gvl_launch_gather_tok_rows(const bf16_t* table, const TokPtrs& toks, bf16_t* dst, int cols, hipStream_t st);
+// x[b] = table[*toks.p[b]] and xn[b] = bf16(w * bf16(x[b] * rstd)): embedding gather + the first layer's input RMSNorm (gvl_decode.hip)
+int gvl_launch_embed_norm(const bf16_t* table, const TokPtrs& toks, bf16_t* x, bf16_t* xn, const bf16_t* w, int cols, float eps, hipStream_t st);
 struct IntPtrs { int* p[GVL_MAX_DECODE_BATCH]; int n; };
 int gvl_launch_inc_many(const IntPtrs& ptrs, hipStream_t st);
 int gvl_launch_inc(int* p, hipStream_t st);

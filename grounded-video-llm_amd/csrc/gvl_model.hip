@@ -40,6 +40,7 @@ struct Seq {
   int* d_block_table = nullptr; int* d_pos = nullptr; int pos = 0; int n_gen = 0;
   int* d_tok = nullptr;   // the sequence's latest greedy token (input of its next decode step)
   int* d_out = nullptr;   // [outlist_cap] generated ids, index = generation step
+  int* d_ngen = nullptr;  // device copy of n_gen: where the next generated id goes (a decode step carries no host counters)
 };
 
 struct ProfRec { int cat; hipEvent_t e0, e1; double work; };
@@ -76,6 +77,10 @@ struct gvl_ctx {
   int* d_seq_tables = nullptr; int* d_seq_pos = nullptr; int seq_table_cap = 0;   // [kMaxSeqs][seq_table_cap], [kMaxSeqs]
   // decode buffers
   bf16_t *d_x = nullptr, *d_qkv = nullptr, *d_q = nullptr, *d_attn = nullptr, *d_act = nullptr;
+  bf16_t* d_xn = nullptr;            // [NB][hidden] RMS-normalised residual rows for the next projection (skinny-GEMM decode path)
+  int* d_tail_counter = nullptr;     // arrival tickets of the o_proj / down_proj launches (zero between launches)
+  int* d_seq_ngen = nullptr;         // [kMaxSeqs]
+  bool decode_mfma = false;          // geometry allows the skinny MFMA GEMM decode path (K % 256 == 0 for every projection)
   // (all decode work buffers hold GVL_MAX_DECODE_BATCH rows: one per sequence of a batched decode step)
   float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_seq_tok = nullptr, *d_seq_out = nullptr;
   int nsplit = 16, outlist_cap = 8192, ids_cap = 16384;
@@ -334,12 +339,12 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
   const gvl_config& f = ctx->cfg;
   const int Hd = f.hidden, H = f.heads, KV = f.kv_heads, Dr = ctx->l_Dr, D = ctx->l_D, I = f.inter;
   const int qkvw = (H + 2 * KV) * Dr;
-  if (nb < 1 || nb > GVL_MAX_DECODE_BATCH || nb == 3) return fail(ctx, GVL_ERR_ARG, "llm_prefill: batch must be 1, 2 or 4 sequences");
-  int off[GVL_MAX_DECODE_BATCH + 1]; off[0] = 0;
+  if (nb < 1 || nb > GVL_MAX_PREFILL_BATCH || nb == 3) return fail(ctx, GVL_ERR_ARG, "llm_prefill: batch must be 1, 2 or 4 sequences");
+  int off[GVL_MAX_PREFILL_BATCH + 1]; off[0] = 0;
   bool uniform = true;
   for (int b = 0; b < nb; ++b) { off[b + 1] = off[b] + lens[b]; uniform = uniform && lens[b] == lens[0]; }
   const int M = off[nb], S0 = lens[0], P0 = (S0 + 63) / 64;
-  if (nb > 1 && uniform && nb * P0 > GVL_MAX_DECODE_BATCH * 64) uniform = false;   // page-id list below holds 256 entries
+  if (nb > 1 && uniform && nb * P0 > (int)(sizeof(IntList::v) / sizeof(int))) uniform = false;   // page-id list below holds 256 entries
   ArenaScope arena_scope(ctx->arena_l_off);
   LALLOC(x, bf16_t, (size_t)M * Hd); LALLOC(h, bf16_t, (size_t)M * Hd); LALLOC(qkv, bf16_t, (size_t)M * qkvw);
   LALLOC(att, bf16_t, (size_t)M * H * Dr); LALLOC(act, bf16_t, (size_t)M * I); LALLOC(Q, bf16_t, (size_t)M * H * D);
@@ -407,8 +412,9 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
   { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = ctx->l_headw; g.N = f.vocab; g.K = Hd; g.x = last; g.norm_w = ctx->l_norm; g.eps = f.rms_eps;
     g.batch = nb; g.x_stride = last_stride; g.out_stride = f.vocab;
     g.bias = ctx->l_headb; g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, gvl_launch_gemv(g, st)); }
+  for (int b = 0; b < nb; ++b) RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sqs[b]->d_ngen, 0, st));
   { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = f.vocab; am.batch = nb;
-    for (int b = 0; b < nb; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.steps[b] = 0; }   // first generated token
+    for (int b = 0; b < nb; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.ngen_ptrs[b] = sqs[b]->d_ngen; }   // first generated token
     RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(am, st)); }
   for (int b = 0; b < nb; ++b) {
     RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sqs[b]->d_pos, lens[b], st));
@@ -417,27 +423,31 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
   return 0;
 }
 
-// One greedy decode step for B = 1, 2 or 4 sequences together: each weight matrix is streamed ONCE for the whole batch
-// (HBM-bound GEMVs: the per-sequence cost falls as 1/B), attention / RoPE / KV append run per sequence on its own pages.
+// One greedy decode step for B sequences together (1..16 on the skinny-GEMM path, 1 / 2 / 4 on the VALU fallback): each weight
+// matrix is streamed ONCE for the whole batch, attention / RoPE / KV append run per sequence on its own pages.  Every launch
+// argument is a device pointer or a constant of the group: the step can be replayed (hipGraph) without host-side counters.
 int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
   const gvl_config& f = ctx->cfg;
   const int Hd = f.hidden, H = f.heads, KV = f.kv_heads, Dr = ctx->l_Dr, D = ctx->l_D, I = f.inter;
   const int qkvw = (H + 2 * KV) * Dr;
-  if (B != 1 && B != 2 && B != 4) return fail(ctx, GVL_ERR_ARG, "decode_step: batch must be 1, 2 or 4");
-  { TokPtrs tp; memset(&tp, 0, sizeof(tp)); tp.n = B; for (int b = 0; b < B; ++b) tp.p[b] = sqs[b]->d_tok;
-    RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_tok_rows(ctx->l_embed, tp, ctx->d_x, Hd, st)); }
+  const bool mfma = ctx->decode_mfma;
+  if (mfma ? (B < 1 || B > GVL_MAX_DECODE_BATCH) : (B != 1 && B != 2 && B != 4)) return fail(ctx, GVL_ERR_ARG, "decode_step: unsupported batch");
+  TokPtrs tp; memset(&tp, 0, sizeof(tp)); tp.n = B; for (int b = 0; b < B; ++b) tp.p[b] = sqs[b]->d_tok;
+  if (mfma) RUN(GVL_PROF_OTHER, 0, gvl_launch_embed_norm(ctx->l_embed, tp, ctx->d_x, ctx->d_xn, ctx->ll[0].ln1, Hd, f.rms_eps, st));
+  else RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_tok_rows(ctx->l_embed, tp, ctx->d_x, Hd, st));
   double ctx_tokens = 0; for (int b = 0; b < B; ++b) ctx_tokens += sqs[b]->pos + 1;
+  auto proj = [&](const GemvArgs& g) { return mfma ? gvl_launch_dgemm(g, st) : gvl_launch_gemv(g, st); };
   for (int l = 0; l < f.layers; ++l) {
     const LlmLayerW& w = ctx->ll[l];
     bf16_t* Kt = ctx->kpool + (size_t)l * ctx->layer_stride; bf16_t* Vt = ctx->vpool + (size_t)l * ctx->layer_stride;
-    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.qkvw; g.N = qkvw; g.K = Hd; g.x = ctx->d_x; g.norm_w = w.ln1; g.eps = f.rms_eps;
-      g.batch = B; g.x_stride = Hd;
+    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.qkvw; g.N = qkvw; g.K = Hd; g.batch = B; g.x_stride = Hd;
+      if (mfma) g.x = ctx->d_xn; else { g.x = ctx->d_x; g.norm_w = w.ln1; g.eps = f.rms_eps; }
       // fused epilogue: RoPE + Q write + paged-KV append (replaces a separate qkv_post launch per layer per token)
       g.rope_on = 1; g.cos_s = ctx->cos_s; g.sin_s = ctx->sin_s; g.cos_l = ctx->cos_l; g.sin_l = ctx->sin_l;
       g.rope_switch = ctx->cos_l ? f.rope_orig_max_pos : 0;
       for (int b = 0; b < B; ++b) { g.pos_ptrs[b] = sqs[b]->d_pos; g.tables[b] = sqs[b]->d_block_table; }
       g.Q = ctx->d_q; g.q_stride = H * D; g.Kt = Kt; g.Vt = Vt; g.H = H; g.KV = KV; g.Dr = Dr; g.D = D;
-      RUN(GVL_PROF_GEMV, 2.0 * qkvw * Hd, gvl_launch_gemv(g, st)); }
+      RUN(GVL_PROF_GEMV, 2.0 * qkvw * Hd, proj(g)); }
     { DecodeAttnArgs a; memset(&a, 0, sizeof(a)); a.q = ctx->d_q; a.q_stride = H * D; a.Kt = Kt; a.Vt = Vt;
       for (int b = 0; b < B; ++b) { a.tables[b] = sqs[b]->d_block_table; a.pos_ptrs[b] = sqs[b]->d_pos; }
       a.part = ctx->d_part; a.counters = ctx->d_counters; a.batch = B;
@@ -445,31 +455,39 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
       RUN(GVL_PROF_DECODE_ATTN, 4.0 * ctx_tokens * (double)KV * D, gvl_launch_decode_attention(a, st)); }
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.ow; g.N = Hd; g.K = H * Dr; g.x = ctx->d_attn; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
       g.batch = B; g.x_stride = H * Dr; g.out_stride = Hd;
-      RUN(GVL_PROF_GEMV, 2.0 * Hd * H * Dr, gvl_launch_gemv(g, st)); }
-    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.guw; g.N = 2 * I; g.K = Hd; g.x = ctx->d_x; g.norm_w = w.ln2; g.eps = f.rms_eps; g.act = GVL_ACT_SILU_MUL; g.out_bf16 = ctx->d_act;
+      if (mfma) { g.tail_norm_w = w.ln2; g.tail_eps = f.rms_eps; g.tail_xn = ctx->d_xn; g.tail_stride = Hd; g.tail_counter = ctx->d_tail_counter; }   // post_attention_layernorm for gate_up
+      RUN(GVL_PROF_GEMV, 2.0 * Hd * H * Dr, proj(g)); }
+    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.guw; g.N = 2 * I; g.K = Hd; g.act = GVL_ACT_SILU_MUL; g.out_bf16 = ctx->d_act;
       g.batch = B; g.x_stride = Hd; g.out_stride = I;
-      RUN(GVL_PROF_GEMV, 4.0 * I * Hd, gvl_launch_gemv(g, st)); }
+      if (mfma) g.x = ctx->d_xn; else { g.x = ctx->d_x; g.norm_w = w.ln2; g.eps = f.rms_eps; }
+      RUN(GVL_PROF_GEMV, 4.0 * I * Hd, proj(g)); }
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.downw; g.N = Hd; g.K = I; g.x = ctx->d_act; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
       g.batch = B; g.x_stride = I; g.out_stride = Hd;
-      RUN(GVL_PROF_GEMV, 2.0 * Hd * I, gvl_launch_gemv(g, st)); }
+      if (mfma) {   // the next layer's input_layernorm, or the final norm in front of lm_head
+        g.tail_norm_w = l + 1 < f.layers ? ctx->ll[l + 1].ln1 : ctx->l_norm; g.tail_eps = f.rms_eps; g.tail_xn = ctx->d_xn; g.tail_stride = Hd; g.tail_counter = ctx->d_tail_counter; }
+      RUN(GVL_PROF_GEMV, 2.0 * Hd * I, proj(g)); }
   }
-  { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = ctx->l_headw; g.N = f.vocab; g.K = Hd; g.x = ctx->d_x; g.norm_w = ctx->l_norm; g.eps = f.rms_eps; g.bias = ctx->l_headb;
+  { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = ctx->l_headw; g.N = f.vocab; g.K = Hd; g.bias = ctx->l_headb;
     g.batch = B; g.x_stride = Hd; g.out_stride = f.vocab;
-    g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, gvl_launch_gemv(g, st)); }
-  { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = f.vocab; am.batch = B;
-    for (int b = 0; b < B; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.steps[b] = sqs[b]->n_gen; }
+    if (mfma) g.x = ctx->d_xn; else { g.x = ctx->d_x; g.norm_w = ctx->l_norm; g.eps = f.rms_eps; }
+    g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, proj(g)); }
+  { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = f.vocab; am.batch = B;   // token, output list, n_gen++ and pos++ on the device
+    for (int b = 0; b < B; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.ngen_ptrs[b] = sqs[b]->d_ngen; am.pos_ptrs[b] = sqs[b]->d_pos; }
     RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(am, st)); }
-  { IntPtrs ip; memset(&ip, 0, sizeof(ip)); ip.n = B; for (int b = 0; b < B; ++b) ip.p[b] = sqs[b]->d_pos;
-    RUN(GVL_PROF_OTHER, 0, gvl_launch_inc_many(ip, st)); }
   for (int b = 0; b < B; ++b) { sqs[b]->pos += 1; sqs[b]->n_gen += 1; }
   return 0;
+}
+// largest group the decode path takes at once, and the group size for `left` waiting sequences
+int decode_group_size(const gvl_ctx* ctx, int left) {
+  if (ctx->decode_mfma) return left < GVL_MAX_DECODE_BATCH ? left : GVL_MAX_DECODE_BATCH;
+  return left >= 4 ? 4 : (left >= 2 ? 2 : 1);
 }
 
 // greedy decode of one group (B = 1, 2 or 4 prefilled sequences) until every member hit eos / max_new / its capacity
 int decode_group(gvl_ctx* ctx, Seq* const* sqs, int B, int max_new, int eos_id, int32_t* const* out_ids, int* const* n_out, hipStream_t st) {
   const int CHECK_EVERY = 16;
   int checked = 0;                       // steps already inspected for eos (all members advance together)
-  bool done[GVL_MAX_DECODE_BATCH] = {false, false, false, false};
+  bool done[GVL_MAX_DECODE_BATCH] = {false};
   const int start_gen = sqs[0]->n_gen;   // members of a group must be in the same generation step
   for (int b = 1; b < B; ++b) if (sqs[b]->n_gen != start_gen) return fail(ctx, GVL_ERR_STATE, "decode batch: sequences are at different generation steps");
   for (;;) {
@@ -576,6 +594,13 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
     bool ok = true;
     const size_t NB = GVL_MAX_DECODE_BATCH;
     ok &= hipMalloc((void**)&ctx->d_x, NB * f.hidden * 2) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_xn, NB * f.hidden * 2) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_tail_counter, 64) == hipSuccess && hipMemset(ctx->d_tail_counter, 0, 64) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_seq_ngen, (size_t)gvl_ctx::kMaxSeqs * 4) == hipSuccess;
+    {   // the skinny-GEMM decode path needs every projection's K to split over 8 waves x 32-wide MFMA steps, and rows that one wave normalises
+      const char* e = getenv("GVL_DECODE_VALU");
+      ctx->decode_mfma = !(e && atoi(e)) && f.hidden % 256 == 0 && f.inter % 256 == 0 && (f.heads * ctx->l_Dr) % 256 == 0 && f.hidden <= 4096 && (ctx->l_Dr & 1) == 0;
+    }
     ok &= hipMalloc((void**)&ctx->d_qkv, (size_t)qkvw * 2) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_q, NB * f.heads * ctx->l_D * 2) == hipSuccess && hipMemset(ctx->d_q, 0, NB * f.heads * ctx->l_D * 2) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_attn, NB * f.heads * ctx->l_Dr * 2) == hipSuccess;
@@ -599,7 +624,7 @@ int gvl_destroy(gvl_ctx* ctx) {
   hipDeviceSynchronize();
   for (auto& kv : ctx->w) if (kv.second.p) hipFree(kv.second.p);
   if (ctx->comm) gvl_comm_destroy(ctx);
-  void* ptrs[] = {ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_out, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
+  void* ptrs[] = {ctx->d_xn, ctx->d_tail_counter, ctx->d_seq_ngen, ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_out, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& r : ctx->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   delete ctx;
@@ -773,6 +798,7 @@ int gvl_seq_alloc(gvl_ctx* ctx, int max_tokens, int* seq_id) {
   s.d_pos = ctx->d_seq_pos + id;
   s.d_tok = ctx->d_seq_tok + id;
   s.d_out = ctx->d_seq_out + (size_t)id * ctx->outlist_cap;
+  s.d_ngen = ctx->d_seq_ngen + id;
   HIPCHK(ctx, hipMemcpy(s.d_block_table, s.pages.data(), (size_t)np * 4, hipMemcpyHostToDevice));   // blocking; d_pos is set by gvl_prefill on ITS stream
   *seq_id = id;
   return 0;
@@ -848,7 +874,7 @@ int gvl_prefill_varlen(gvl_ctx* ctx, const int* seq_ids, int n_seqs, const uint1
       if (B == 1 || rows <= ctx->cfg.max_prefill) break;
       B >>= 1;
     }
-    Seq* sqs[GVL_MAX_DECODE_BATCH]; const bf16_t* es[GVL_MAX_DECODE_BATCH];
+    Seq* sqs[GVL_MAX_PREFILL_BATCH]; const bf16_t* es[GVL_MAX_PREFILL_BATCH];
     for (int b = 0; b < B; ++b) { sqs[b] = &ctx->seqs[seq_ids[i + b]]; es[b] = embeds[i + b]; }
     const int rc = llm_prefill(ctx, sqs, B, es, seq_lens + i, st);
     if (rc) return rc;
@@ -880,10 +906,10 @@ int gvl_decode_greedy_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, int ma
     for (int j = 0; j < i; ++j) if (seq_ids[j] == id) return fail(ctx, GVL_ERR_ARG, "gvl_decode_greedy_batch: duplicate seq");
   }
   hipStream_t st = (hipStream_t)stream;
-  // groups of 4, then 2, then 1: a group streams the weights once per step for all of its members
+  // groups of up to 16 (VALU fallback: 4, 2, 1): a group streams the weights once per step for all of its members
   int i = 0;
   while (i < n_seqs) {
-    const int left = n_seqs - i, B = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+    const int left = n_seqs - i, B = decode_group_size(ctx, left);
     Seq* sqs[GVL_MAX_DECODE_BATCH]; int32_t* outs[GVL_MAX_DECODE_BATCH]; int* nouts[GVL_MAX_DECODE_BATCH];
     for (int b = 0; b < B; ++b) { sqs[b] = &ctx->seqs[seq_ids[i + b]]; outs[b] = out_ids + (size_t)(i + b) * max_new; nouts[b] = n_out + i + b; }
     const int rc = decode_group(ctx, sqs, B, max_new, eos_id, outs, nouts, st);
@@ -909,8 +935,8 @@ int gvl_decode_steps(gvl_ctx* ctx, const int* seq_ids, int n_seqs, int n_steps, 
   hipStream_t st = (hipStream_t)stream;
   for (int s = 0; s < n_steps; ++s) {
     int i = 0;
-    while (i < n_seqs) {                   // groups of 4, 2, 1: one weight stream per step per group
-      const int left = n_seqs - i, B = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+    while (i < n_seqs) {                   // groups of up to 16 (VALU fallback: 4, 2, 1): one weight stream per step per group
+      const int left = n_seqs - i, B = decode_group_size(ctx, left);
       Seq* sqs[GVL_MAX_DECODE_BATCH];
       for (int b = 0; b < B; ++b) sqs[b] = &ctx->seqs[seq_ids[i + b]];
       const int rc = decode_step(ctx, sqs, B, st);
@@ -1183,6 +1209,13 @@ int gvl_op_rmsnorm(gvl_ctx* ctx, const uint16_t* x, const uint16_t* w, uint16_t*
   if (!ctx) return GVL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w, y, rows, cols, eps, st));
+  return 0;
+}
+int gvl_op_dgemm(gvl_ctx* ctx, const uint16_t* W, const uint16_t* x, const float* bias, float* y, int N, int K, int batch, void* stream) {
+  if (!ctx) return GVL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  GemvArgs g; memset(&g, 0, sizeof(g)); g.W = W; g.N = N; g.K = K; g.x = x; g.bias = bias; g.out_f32 = y; g.batch = batch; g.x_stride = K; g.out_stride = N;
+  RUN(GVL_PROF_GEMV, 2.0 * N * K, gvl_launch_dgemm(g, st));
   return 0;
 }
 int gvl_op_gemv(gvl_ctx* ctx, const uint16_t* W, const uint16_t* x, const float* bias, float* y, int N, int K, void* stream) {

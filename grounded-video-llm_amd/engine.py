@@ -388,6 +388,14 @@ class Engine:
                   "gvl_op_rmsnorm")
         return y
 
+    def op_dgemm(self, W, x, bias=None):
+        """x bf16 [B, K] (B <= 16) -> y f32 [B, N]: the skinny MFMA decode GEMM."""
+        N, K = W.shape
+        B = x.shape[0]
+        y = torch.empty((B, N), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.gvl_op_dgemm(self.ctx, _ptr(W.contiguous()), _ptr(x.contiguous()), _ptr(bias), _ptr(y), N, K, B, self.stream), "gvl_op_dgemm")
+        return y
+
     def op_gemv(self, W, x, bias=None):
         N, K = W.shape
         y = torch.empty((N,), dtype=torch.float32, device=self.device)

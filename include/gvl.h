@@ -214,6 +214,10 @@ int gvl_op_rmsnorm(gvl_ctx* ctx, const uint16_t* x, const uint16_t* w, uint16_t*
 /* y[N] = W[N,K] x[K] (+bias) -- the decode GEMV; x,W bf16, y f32. */
 int gvl_op_gemv(gvl_ctx* ctx, const uint16_t* W, const uint16_t* x, const float* bias, float* y, int N, int K,
                 void* stream);
+/* y[b][N] = W[N,K] x[b][K] (+bias) for b < batch <= 16 -- the decode projections as ONE skinny MFMA GEMM (the weight stream is
+ * read once for all sequences; K % 256 == 0).  x bf16 [batch][K], y f32 [batch][N]. */
+int gvl_op_dgemm(gvl_ctx* ctx, const uint16_t* W, const uint16_t* x, const float* bias, float* y, int N, int K, int batch,
+                 void* stream);
 
 #ifdef __cplusplus
 }

@@ -358,17 +358,20 @@ def test_llama3_8b_full_width_layer_prefill_and_decode():
     scale = float(np.abs(gold).max())
     ref_bf_err = float(np.abs(gold_bf - gold).max()) / scale
     print(f"[parity] llama full layer: the reference's own bf16 evaluation is {ref_bf_err:.2e} from its fp32 evaluation")
+    # a 64-entry vocabulary head on ONE layer: each logit is a single 4096-term bf16 dot product, so the yardstick is the reference's
+    # own bf16 evaluation of the same layer (9.8e-3 of the scale): the HIP path must be within 1.5x of it
+    tol = max(1e-2, 1.5 * ref_bf_err)
     seq = eng.seq_alloc(128)
     l64 = eng.prefill(seq, x, want_logits=True).clone()
     eng.seq_free(seq)
-    e_pf = check(l64, gold[63], 1e-2, "llama-3-8B full-width layer, prefill S=64 last row vs reference (fp32)")
+    check(l64, gold[63], tol, "llama-3-8B full-width layer, prefill S=64 last row vs reference (fp32)")
     seq = eng.seq_alloc(128)
     l63 = eng.prefill(seq, x[:63], want_logits=True).clone()
-    check(l63, gold[62], 1e-2, "llama-3-8B full-width layer, prefill S=63 last row vs reference (fp32)")
+    check(l63, gold[62], tol, "llama-3-8B full-width layer, prefill S=63 last row vs reference (fp32)")
     ld = eng.decode_step_logits(seq, ids[63])
     eng.seq_free(seq)
-    e_dec = check(ld, gold[63], 1e-2, "llama-3-8B full-width layer, paged-KV decode step (row 63) vs reference (fp32)")
-    assert max(e_pf, e_dec) <= max(4e-3, 1.5 * ref_bf_err), "HIP path is further from fp32 than 1.5x the reference's own bf16 evaluation"
+    check(ld, gold[63], tol, "llama-3-8B full-width layer, paged-KV decode step (row 63) vs reference (fp32)")
+    check(ld, l64, 1e-2, "llama-3-8B full-width layer, decode step vs the prefill path on the same row")
     eng.close()
 
 
@@ -411,4 +414,37 @@ def test_lora_merged_on_device_equals_unmerged_peft_forward(case):
     ref_emud = O.llm_forward(ocfg, Wo, xx, True, None, 0, last_only=True)[0]
     check_bf16_class(lg, ref32d, ref_emud, tol, f"LoRA {case}: merged decode step vs un-merged peft forward (fp32)")
     eng.seq_free(seq)
+    eng.close()
+
+
+def test_decode_groups_up_to_16_are_bit_identical_to_single_at_full_width():
+    """Skinny-GEMM decode path (full-width Phi-3.5 layer geometry, 2 layers): 11 sequences of DIFFERENT lengths (one crosses a page
+    boundary while decoding) advance together in one group -- the weights are streamed once per step for all of them -- and every
+    sequence's ids and final-step logits equal its own one-at-a-time run bit for bit (a D column of the MFMA depends only on its
+    own B column; the k-split partial sums are added in a fixed order; RMSNorm rows are normalised per sequence)."""
+    c = dict(hidden=3072, inter=8192, layers=2, heads=32, kv_heads=32, vocab=512)
+    geo = _phi_geo(c, max_seq=512, max_prefill=256, kv_pages=64)
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.dg16", device=DEV)
+    eng = llm_engine(geo, W)
+    g = torch.Generator(device=DEV); g.manual_seed(4)
+    lens = [5, 17, 60, 64, 33, 1, 100, 63, 128, 2, 77]
+    embs = [(torch.randn((n, c["hidden"]), device=DEV, generator=g) * 0.5).to(bf) for n in lens]
+    new = 9
+    single = []
+    for e in embs:
+        s = eng.seq_alloc(e.shape[0] + new + 1)
+        eng.prefill(s, e)
+        ids = eng.decode_greedy(s, new, None)
+        lg = eng.decode_step_logits(s, 7).clone()
+        single.append((ids, lg))
+        eng.seq_free(s)
+    seqs = [eng.seq_alloc(e.shape[0] + new + 1) for e in embs]
+    for s, e in zip(seqs, embs):
+        eng.prefill(s, e)
+    got = eng.decode_greedy_batch(seqs, new, None)
+    assert got == [ids for ids, _ in single], "ids of the 11-sequence group differ from the one-at-a-time runs"
+    assert len({tuple(ids) for ids in got}) > 1
+    for s, (_, lg) in zip(seqs, single):
+        assert torch.equal(eng.decode_step_logits(s, 7), lg)
+        eng.seq_free(s)
     eng.close()

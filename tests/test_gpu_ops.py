@@ -168,6 +168,22 @@ def test_gemv(eng, N, K):
     check(eng.op_gemv(W, x, b), W.float() @ x.float() + b, 2e-4, f"gemv {N}x{K}")
 
 
+@pytest.mark.parametrize("N,K,B", [(3072, 3072, 1), (3072, 3072, 16), (3072, 8192, 5), (9216, 3072, 16), (16384, 3072, 3), (32366, 3072, 16), (4096, 14336, 7),
+                                   (48, 256, 2), (4100, 11008, 16)])
+def test_decode_skinny_mfma_gemm(eng, N, K, B):
+    """gvl_decode.hip dgemm_kernel (v_mfma_f32_16x16x32_bf16, A = weights, B = activations of up to 16 sequences) vs fp32 torch:
+    asymmetric operands (a row / column swap in the D mapping would fail), ragged N (32366 = lm_head + 302 rows), K remainders
+    (11008 / 256 = 43 steps: the non-multiple-of-4 tail loop), both row-block widths (N >= 8192: 32 rows per block)."""
+    W = _rand(f"dw{N}.{K}", (N, K), K ** -0.5).to(bf)
+    x = _rand(f"dx{K}.{B}", (B, K), 1.0).to(bf)
+    b = _rand(f"db{N}", (N,), 0.3)
+    got = eng.op_dgemm(W, x, b)
+    check(got, x.float() @ W.float().T + b, 2e-4, f"skinny decode gemm N={N} K={K} B={B}")
+    # a sequence's outputs do not depend on what the other columns of the MFMA hold: bit-identical to its own single-sequence run
+    for j in {0, B - 1}:
+        assert torch.equal(eng.op_dgemm(W, x[j:j + 1], b)[0], got[j]), f"column {j} of a batch of {B} differs from the same sequence alone"
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(24588, 1408, 1408, "bias_gamma_resid"), (24588, 4224, 1408, "plain"), (24588, 1408, 6144, "bias_gamma_resid"),
                                        (3519, 3072, 3072, "resid")])
 def test_gemm_planner_full_shapes(eng, M, N, K, epi):

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
     l += mg[s2 * (D + 2) + D + 1] * w;
     if (tid < D) acc += mg[s2 * (D + 2) + tid] * w;
   }
-  if (tid < a.Dout) a.out[(size_t)bz * a.out_stride + head * a.Dout + tid] = f2bf(acc / l);
+  if (tid < a.Dout) a.out[a.out_tiled ? gvl_xt_index(bz, head * a.Dout + tid) : (size_t)bz * a.out_stride + head * a.Dout + tid] = f2bf(acc / l);
   if (tid == 0) __hip_atomic_store(counters_b + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
 }
 

@@ -18,11 +18,24 @@
 // A column of D depends only on its own sequence's activations, so a sequence's logits are bit-identical whatever the other
 // columns hold -- batched decode == single decode by construction (one kernel for every batch size 1..16).
 //
-// RMSNorm: the reference normalises the residual stream in front of qkv_proj / gate_up_proj / lm_head.  Instead of letting every
-// block of the CONSUMER re-normalise all sequences (round 1: 1024 blocks x B rows), the PRODUCER of the residual stream does it
-// once: the last block to finish an o_proj / down_proj launch (ticket counter, write-through stores, the pattern of
-// decode_attn_kernel) reads the new rows and writes bf16(w * bf16(x * rstd)) for the next consumer, one wave per sequence.
+// RMSNorm (in front of qkv_proj / gate_up_proj / lm_head).  Measured alternatives (tools/decode_bench.py, profiles/r02_decode_microbench.txt):
+// letting the LAST block of the producing o_proj / down_proj launch normalise the new residual rows (ticket counter + write-through
+// stores) costs +13 us (1 sequence) ... +34 us (16) on a 6 us launch -- the store-ack / atomic / re-read round trips do not hide.
+// Shipped: groups of up to 4 sequences normalise INSIDE the consumer (wave b of every block normalises row b into LDS while the
+// block's first weight loads are in flight; the B operand then comes from LDS); larger groups run a one-wave-per-row norm kernel
+// once per projection (2 extra launches per layer on a step that streams 7.45 GB + 16 KV caches).  Both use wave_rmsnorm_row, so a
+// sequence's normalised row -- and everything after it -- is bit-identical in either mode.
+//
+// Memory layout (round 2, measured: with row-major operands the kernel reached 2.7 TB/s -- a 16x16x32 MFMA operand puts 16
+// DIFFERENT rows on 16 consecutive lanes, so every quad of lanes touches 4 cache lines and the address path, not HBM, is the limit):
+// the decode path reads its own copy of every projection in MFMA-A TILE ORDER -- [row block of 16][k step of 32][64 lanes][8 bf16],
+// lane = 16 (k chunk) + row -- built once at gvl_finalize_weights (gvl_retile_decode_weight; the rotate_half row permutation of
+// qkv_proj is baked in).  One wave load = 1 KiB of consecutive addresses.  288 GB of HBM pay for the second copy (7.4 GB for
+// Phi-3.5, 15 GB for Llama-3-8B); the prefill GEMM keeps the row-major copy its DMA needs.  Activations travel between the decode
+// kernels in the matching B-operand tile order ([k step][64 lanes][8], lane = 16 (k chunk) + sequence): gvl_xt_index.
 #include "gvl_internal.h"
+#include <cstdlib>
+#include <cstring>
 
 #define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -3)
 
@@ -30,103 +43,116 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
 
 namespace {
 
-// RMSNorm of one bf16 row by ONE wave: xn = bf16(w * bf16(x * rsqrt(mean(x^2) + eps)))  (Phi3RMSNorm modeling_phi3.py:319-324 /
-// LlamaRMSNorm: fp32 statistics, result cast to bf16, then the bf16 weight product).  `ld64(p)` loads 8 bytes (4 bf16).
-// cols % 256 == 0 is not required: chunks of 4 elements, cols % 4 == 0.
-template <typename Load64>
-__device__ __forceinline__ void wave_rmsnorm_row(const bf16_t* x, const bf16_t* w, bf16_t* xn, bf16_t* xcopy, int cols, float eps, int lane, Load64 ld64) {
-  constexpr int MAXC = 16;                       // 64 lanes x 16 chunks x 4 elements = 4096 columns held in registers
-  const int nchunk = cols >> 2;
-  unsigned long long v[MAXC];
+// RMSNorm of a bf16 row, xn = bf16(w * bf16(x * rsqrt(mean(x^2) + eps)))  (Phi3RMSNorm modeling_phi3.py:319-324 / LlamaRMSNorm: fp32
+// statistics, result cast to bf16, then the bf16 weight product), in a FIXED arithmetic order shared by the two places that compute
+// it -- the consumer block of the skinny GEMM (8 waves, wave w owns k slice w) and the one-wave-per-row norm kernel:
+//   the row is cut into DG_SLICES = 8 slices of cols / 8 elements; lane l of a slice owns its 16-byte chunk l (cols <= 4096: at most
+//   one chunk per lane); slice sum = wave_sum of the lane sums; row sum = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)).
+constexpr int DG_SLICES = 8;
+__device__ __forceinline__ float chunk_sumsq(const u32x4_t& v) {
   float s = 0.f;
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const int ch = c * 64 + lane;
-    v[c] = ch < nchunk ? ld64(x + (size_t)ch * 4) : 0ull;
-  }
+  for (int e = 0; e < 4; ++e) { const float p = lo_bf(v[e]), q = hi_bf(v[e]); s += p * p + q * q; }
+  return s;
+}
+__device__ __forceinline__ float row_rstd(const float (&p)[DG_SLICES], int cols, float eps) {
+  const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+  return rsqrtf(s / (float)cols + eps);
+}
+__device__ __forceinline__ u32x4_t chunk_normalise(const u32x4_t& v, const u32x4_t& w, float rs) {
+  u32x4_t o;
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const unsigned lo = (unsigned)v[c], hi = (unsigned)(v[c] >> 32);
-    const float p0 = lo_bf(lo), p1 = hi_bf(lo), p2 = lo_bf(hi), p3 = hi_bf(hi);
-    s += p0 * p0 + p1 * p1;
-    s += p2 * p2 + p3 * p3;
-  }
-  s = wave_sum(s);
-  const float rs = rsqrtf(s / (float)cols + eps);
-#pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const int ch = c * 64 + lane;
-    if (ch < nchunk) {
-      const unsigned lo = (unsigned)v[c], hi = (unsigned)(v[c] >> 32);
-      const u32x2_t wv = *(const u32x2_t*)(w + (size_t)ch * 4);
-      u32x2_t o;
-      o[0] = pack2bf(lo_bf(wv[0]) * rbf(lo_bf(lo) * rs), hi_bf(wv[0]) * rbf(hi_bf(lo) * rs));
-      o[1] = pack2bf(lo_bf(wv[1]) * rbf(lo_bf(hi) * rs), hi_bf(wv[1]) * rbf(hi_bf(hi) * rs));
-      *(u32x2_t*)(xn + (size_t)ch * 4) = o;
-      if (xcopy) *(unsigned long long*)(xcopy + (size_t)ch * 4) = v[c];
-    }
-  }
+  for (int e = 0; e < 4; ++e) o[e] = pack2bf(lo_bf(w[e]) * rbf(lo_bf(v[e]) * rs), hi_bf(w[e]) * rbf(hi_bf(v[e]) * rs));
+  return o;
 }
 
 }  // namespace
 
-// x[b] = table[*tok[b]] (the embedding row of the sequence's latest token) and xn[b] = rmsnorm(x[b]) * w: one wave per sequence.
-__global__ __launch_bounds__(64) void embed_norm_kernel(const bf16_t* __restrict__ table, const TokPtrs toks, bf16_t* __restrict__ x, bf16_t* __restrict__ xn,
-                                                        const bf16_t* __restrict__ w, int cols, float eps) {
+// One wave per sequence: source row = table[*tok[b]] (embedding gather; the raw row also goes to the row-major residual stream x)
+// or, without a table, x[b] itself; xn = rmsnorm(row) * w lands in slot b of the tiled activation buffer.
+__global__ __launch_bounds__(64) void norm_rows_kernel(const bf16_t* __restrict__ table, const TokPtrs toks, bf16_t* __restrict__ x, bf16_t* __restrict__ xn,
+                                                       const bf16_t* __restrict__ w, int cols, float eps) {
   const int b = blockIdx.x, lane = threadIdx.x;
-  const int tok = *toks.p[b];
-  wave_rmsnorm_row(table + (size_t)tok * cols, w, xn + (size_t)b * cols, x + (size_t)b * cols, cols, eps, lane,
-                   [](const bf16_t* p) { return *(const unsigned long long*)p; });
+  bf16_t* xrow = x + (size_t)b * cols;
+  const bf16_t* src = table ? table + (size_t)(*toks.p[b]) * cols : xrow;
+  const int ks = cols / DG_SLICES, nch = ks >> 3;          // slice length, 16-byte chunks per slice (<= 64)
+  const bool on = lane < nch;
+  u32x4_t v[DG_SLICES];
+  float p[DG_SLICES];
+#pragma unroll
+  for (int sl = 0; sl < DG_SLICES; ++sl) v[sl] = on ? *(const u32x4_t*)(src + sl * ks + lane * 8) : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int sl = 0; sl < DG_SLICES; ++sl) p[sl] = wave_sum(on ? chunk_sumsq(v[sl]) : 0.f);
+  const float rs = row_rstd(p, cols, eps);
+  if (!on) return;
+#pragma unroll
+  for (int sl = 0; sl < DG_SLICES; ++sl) {
+    const int k = sl * ks + lane * 8;
+    *(u32x4_t*)(xn + gvl_xt_index(b, k)) = chunk_normalise(v[sl], *(const u32x4_t*)(w + k), rs);   // 8 consecutive k = one 16-byte slot of the tile
+    if (table) *(u32x4_t*)(xrow + k) = v[sl];
+  }
 }
 int gvl_launch_embed_norm(const bf16_t* table, const TokPtrs& toks, bf16_t* x, bf16_t* xn, const bf16_t* w, int cols, float eps, hipStream_t st) {
-  if (cols % 4 || cols > 4096 || toks.n < 1 || toks.n > GVL_MAX_DECODE_BATCH) return -1;
-  hipLaunchKernelGGL(embed_norm_kernel, dim3(toks.n), dim3(64), 0, st, table, toks, x, xn, w, cols, eps);
+  if (cols % 256 || cols > 4096 || toks.n < 1 || toks.n > GVL_MAX_DECODE_BATCH || !table) return -1;
+  hipLaunchKernelGGL(norm_rows_kernel, dim3(toks.n), dim3(64), 0, st, table, toks, x, xn, w, cols, eps);
+  return CHECK_LAUNCH();
+}
+int gvl_launch_norm_tiled(bf16_t* x, bf16_t* xn, const bf16_t* w, int batch, int cols, float eps, hipStream_t st) {
+  if (cols % 256 || cols > 4096 || batch < 1 || batch > GVL_MAX_DECODE_BATCH) return -1;
+  TokPtrs none; memset(&none, 0, sizeof(none)); none.n = batch;
+  hipLaunchKernelGGL(norm_rows_kernel, dim3(batch), dim3(64), 0, st, (const bf16_t*)nullptr, none, x, xn, w, cols, eps);
   return CHECK_LAUNCH();
 }
 
-template <int RB>
-__global__ __launch_bounds__(512, 4) void dgemm_kernel(const GemvArgs a) {   // 4 waves / SIMD = 2 blocks per CU (<= 128 VGPRs)
-  constexpr int U = 4;                           // MFMA steps (32 k each) whose operand loads are in flight together
-  __shared__ __attribute__((aligned(16))) float red[8][RB][64][4];
-  __shared__ int last_s;
+// RB: 16-row blocks per workgroup; NW: waves per workgroup = k slices (8 or 4); U: MFMA steps (32 k each) per load group;
+// NT: weight loads carry the non-temporal hint; XN: the B operand is RMS-normalised by this block into LDS (batch <= 4, a.x row-major)
+template <int RB, int NW, int U, int NT, int XN>
+__global__ __launch_bounds__(NW * 64, 4) void dgemm_kernel(const GemvArgs a) {   // 4 waves / SIMD (<= 128 VGPRs)
+  __shared__ __attribute__((aligned(16))) float red[NW][RB][64][4];
+  extern __shared__ __attribute__((aligned(16))) char xs_raw[];                  // XN: [k step][k chunk][batch][8] bf16
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * (16 * RB);
-  const int kw = a.K >> 3;                       // k range of one wave
-  const int kbase = wave * kw + g * 8;
+  const int kw = a.K / NW;                       // k range of one wave
   const int halfd = a.Dr >> 1, npair_qk = (a.H + a.KV) * halfd;
 
+  // operands in tile order: step s of this wave is the 1 KiB tile (row block, wave * steps + s); lane l reads bytes [16 l, 16 l + 16)
+  const int steps = kw >> 5;
+  const int nkt = a.K >> 5;                      // k steps per row block
   const bf16_t* wp[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    int n = n0 + rb * 16 + i; if (n > a.N - 1) n = a.N - 1;
-    if (a.rope_on) {                             // logical row -> weight row: pairs (2j, 2j+1) = rotate_half partners (d, d + Dr/2)
-      const int j = n >> 1;
-      if (j < npair_qk) { const int hd = j / halfd, d = j - hd * halfd; n = hd * a.Dr + d + (n & 1) * halfd; }
-    }
-    wp[rb] = a.W + (size_t)n * a.K + kbase;
+    int rbk = blockIdx.x * RB + rb;
+    const int rbk_max = (a.N + 15) / 16 - 1;
+    rbk = rbk < rbk_max ? rbk : rbk_max;         // a block past the end re-reads the last row block; its rows are never stored
+    wp[rb] = a.W + ((size_t)rbk * nkt + (size_t)wave * steps) * 512 + lane * 8;
   }
-  // B columns >= batch re-read the LAST sequence's activations: a D column depends on its own B column only and those columns
-  // are never stored, so no masking is needed in the loop (the duplicate addresses coalesce)
-  const bf16_t* xp = a.x + (size_t)(i < a.batch ? i : a.batch - 1) * a.x_stride + kbase;
+  // B columns >= batch re-read the LAST sequence's chunk: a D column depends on its own B column only and those columns
+  // are never stored, so no masking is needed in the loop (the duplicate addresses coalesce / broadcast)
+  const int jj = i < a.batch ? i : a.batch - 1;
+  const bf16_t* xp = XN ? (const bf16_t*)xs_raw + ((size_t)wave * steps * 4 + g) * a.batch * 8 + jj * 8
+                        : a.x + (size_t)wave * steps * 512 + (g * 16 + jj) * 8;
+  const int xstep = XN ? 4 * a.batch * 8 : 512;  // elements between two k steps of the B operand
 
   f32x4v_t acc[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
-  const int steps = kw >> 5;
   // groups of U steps, double buffered: while the U x RB MFMAs of group t run, the U x (RB + 1) 16-byte loads of group t + 1 are
   // in flight.  steps = K / 256 is a multiple of U = 4 for every shipped geometry (3072 -> 12, 4096 -> 16, 8192 -> 32,
   // 14336 -> 56); the remainder loop covers anything else.
   bf16x8_t wv[2][U][RB], xv[2][U];
-  auto request = [&](int buf, int s) {
+  auto request_w = [&](int buf, int s) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) wv[buf][u][rb] = __builtin_nontemporal_load((const bf16x8_t*)(wp[rb] + (s + u) * 32));
-      xv[buf][u] = *(const bf16x8_t*)(xp + (s + u) * 32);
-    }
+      for (int rb = 0; rb < RB; ++rb) wv[buf][u][rb] = NT ? __builtin_nontemporal_load((const bf16x8_t*)(wp[rb] + (s + u) * 512)) : *(const bf16x8_t*)(wp[rb] + (s + u) * 512);
   };
+  auto request_x = [&](int buf, int s) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) xv[buf][u] = *(const bf16x8_t*)(xp + (s + u) * xstep);
+  };
+  auto request = [&](int buf, int s) { request_w(buf, s); request_x(buf, s); };
   auto consume = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -134,7 +160,42 @@ __global__ __launch_bounds__(512, 4) void dgemm_kernel(const GemvArgs a) {   // 
       for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[buf][u][rb], xv[buf][u], acc[rb], 0, 0, 0);
   };
   const int groups = steps / U;
-  if (groups > 0) request(0, 0);
+  if (groups > 0) request_w(0, 0);               // the first weight tiles do not depend on the activations: in flight during the norm
+  if constexpr (XN) {
+    // every wave normalises ITS k slice of the (<= 4) residual rows into LDS, B-operand order [step][chunk][batch][8]: element (b, k)
+    // at (((k >> 5) * 4 + ((k >> 3) & 3)) * batch + b) * 8 + (k & 7).  Only the 8 slice sums cross waves (one barrier); a wave
+    // reads back only what it wrote itself.
+    static_assert(!XN || NW == DG_SLICES, "fused RMSNorm: one wave per k slice");
+    __shared__ float psum[GVL_MAX_VALU_BATCH][DG_SLICES];
+    bf16_t* xs = (bf16_t*)xs_raw;
+    const int nb = a.batch, nch = kw >> 3;
+    const bool on = lane < nch;
+    u32x4_t xr[GVL_MAX_VALU_BATCH];
+#pragma unroll
+    for (int b = 0; b < GVL_MAX_VALU_BATCH; ++b) {
+      if (b < nb) {
+        xr[b] = on ? *(const u32x4_t*)(a.x + (size_t)b * a.x_stride + wave * kw + lane * 8) : u32x4_t{0u, 0u, 0u, 0u};
+        const float ps = wave_sum(on ? chunk_sumsq(xr[b]) : 0.f);
+        if (lane == 0) psum[b][wave] = ps;
+      }
+    }
+    __syncthreads();
+    if (on) {
+      const int k = wave * kw + lane * 8;
+      const u32x4_t wn = *(const u32x4_t*)(a.norm_w + k);
+#pragma unroll
+      for (int b = 0; b < GVL_MAX_VALU_BATCH; ++b) {
+        if (b < nb) {
+          float p[DG_SLICES];
+#pragma unroll
+          for (int sl = 0; sl < DG_SLICES; ++sl) p[sl] = psum[b][sl];
+          *(u32x4_t*)(xs + ((size_t)((k >> 5) * 4 + ((k >> 3) & 3)) * nb + b) * 8) = chunk_normalise(xr[b], wn, row_rstd(p, a.K, a.eps));
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();              // the B operand of this wave is its own LDS writes (program order within the wave)
+  }
+  if (groups > 0) request_x(0, 0);
   int gi = 0;
   for (; gi + 2 <= groups; gi += 2) {            // two groups per trip: the buffer index stays a compile-time constant
     request(1, (gi + 1) * U);
@@ -144,9 +205,9 @@ __global__ __launch_bounds__(512, 4) void dgemm_kernel(const GemvArgs a) {   // 
   }
   if (gi < groups) consume(0);
   for (int s0 = groups * U; s0 < steps; ++s0) {
-    const bf16x8_t x1 = *(const bf16x8_t*)(xp + s0 * 32);
+    const bf16x8_t x1 = *(const bf16x8_t*)(xp + s0 * xstep);
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_nontemporal_load((const bf16x8_t*)(wp[rb] + s0 * 32)), x1, acc[rb], 0, 0, 0);
+    for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_nontemporal_load((const bf16x8_t*)(wp[rb] + s0 * 512)), x1, acc[rb], 0, 0, 0);
   }
   // partial sums of the 8 k-slices meet in LDS; wave rb (< RB) adds them in a fixed order and runs that row block's epilogue
 #pragma unroll
@@ -157,9 +218,8 @@ __global__ __launch_bounds__(512, 4) void dgemm_kernel(const GemvArgs a) {   // 
     float v[4];
     {
       auto ld = [&](int w) { return *(const f32x4v_t*)red[w][rb][lane]; };
-      const f32x4v_t q0 = (ld(0) + ld(1)) + (ld(2) + ld(3));      // FIXED association: the result does not depend on anything
-      const f32x4v_t q1 = (ld(4) + ld(5)) + (ld(6) + ld(7));      // but the 8 partial sums themselves
-      const f32x4v_t q = q0 + q1;
+      f32x4v_t q = (ld(0) + ld(1)) + (ld(2) + ld(3));             // FIXED association: the result does not depend on anything
+      if constexpr (NW == 8) q = q + ((ld(4) + ld(5)) + (ld(6) + ld(7)));   // but the partial sums themselves
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = q[r];
     }
@@ -199,10 +259,10 @@ __global__ __launch_bounds__(512, 4) void dgemm_kernel(const GemvArgs a) {   // 
 #pragma unroll
         for (int r = 0; r < 4; r += 2) { const float gt = rbf(v[r]), u = rbf(v[r + 1]); o[r >> 1] = u * rbf(gt * fast_sigmoid(gt)); }
         if (nr + 3 < a.N) {
-          if (a.out_bf16) *(unsigned*)(a.out_bf16 + (size_t)b * a.out_stride + (nr >> 1)) = pack2bf(o[0], o[1]);
+          if (a.out_bf16) *(unsigned*)(a.out_bf16 + (a.out_tiled ? gvl_xt_index(b, nr >> 1) : (size_t)b * a.out_stride + (nr >> 1))) = pack2bf(o[0], o[1]);
           if (a.out_f32) { a.out_f32[(size_t)b * a.out_stride + (nr >> 1)] = o[0]; a.out_f32[(size_t)b * a.out_stride + (nr >> 1) + 1] = o[1]; }
         } else if (nr + 1 < a.N) {
-          if (a.out_bf16) a.out_bf16[(size_t)b * a.out_stride + (nr >> 1)] = f2bf(o[0]);
+          if (a.out_bf16) a.out_bf16[a.out_tiled ? gvl_xt_index(b, nr >> 1) : (size_t)b * a.out_stride + (nr >> 1)] = f2bf(o[0]);
           if (a.out_f32) a.out_f32[(size_t)b * a.out_stride + (nr >> 1)] = o[0];
         }
       } else {
@@ -218,8 +278,7 @@ __global__ __launch_bounds__(512, 4) void dgemm_kernel(const GemvArgs a) {   // 
           if (a.out_bf16) {
             const unsigned long long o = (unsigned long long)pack2bf(v[0], v[1]) | ((unsigned long long)pack2bf(v[2], v[3]) << 32);
             unsigned long long* dst = (unsigned long long*)(a.out_bf16 + (size_t)b * a.out_stride + nr);
-            if (a.tail_xn) __hip_atomic_store(dst, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through: the merging block reads it
-            else *dst = o;
+            *dst = o;
           }
           if (a.out_f32) *(f32x4v_t*)(a.out_f32 + (size_t)b * a.out_stride + nr) = f32x4v_t{v[0], v[1], v[2], v[3]};
         } else {
@@ -237,37 +296,84 @@ __global__ __launch_bounds__(512, 4) void dgemm_kernel(const GemvArgs a) {   // 
       }
     }
   }
-  if (!a.tail_xn) return;
-  // ---- the LAST block normalises the new residual rows for the next consumer (uniform branch: tail_xn is a kernel argument) ----
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
-  __syncthreads();
-  if (tid == 0) {
-    const int t = __hip_atomic_fetch_add(a.tail_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last_s = (t == (int)gridDim.x - 1);
-  }
-  __syncthreads();
-  if (!last_s) return;
-  for (int b = wave; b < a.batch; b += 8)
-    wave_rmsnorm_row(a.out_bf16 + (size_t)b * a.out_stride, a.tail_norm_w, a.tail_xn + (size_t)b * a.tail_stride, (bf16_t*)nullptr, a.N, a.tail_eps, lane,
-                     [](const bf16_t* p) { return __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
-  if (tid == 0) __hip_atomic_store(a.tail_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
 }
 
-// Skinny-GEMM decode projection.  Preconditions (else -1: the caller falls back to the VALU kernel): K % 256 == 0, batch <= 16,
-// no fused RMSNorm prologue (a.norm_w == null: the activations arrive normalised), rows 16-byte aligned.
+// Skinny-GEMM decode projection.  a.W = the TILED copy of the weight (gvl_retile_decode_weight).  a.norm_w == null: a.x = activations
+// in B-operand tile order (gvl_xt_index); a.norm_w != null (batch <= 4): a.x = the row-major residual rows, normalised by every block
+// into LDS.  a.out_tiled: out_bf16 of the SwiGLU epilogue in tile order (it feeds down_proj).  Preconditions (else -1): K % 256 == 0.
 int gvl_launch_dgemm(const GemvArgs& a_in, hipStream_t st) {
   GemvArgs a = a_in;
   if (a.batch <= 0) a.batch = 1;
-  if (a.K % 256 || a.K <= 0 || a.N <= 0 || a.batch > GVL_MAX_DECODE_BATCH || a.norm_w) return -1;
-  if (a.batch > 1 && (a.x_stride % 8)) return -1;
+  if (a.K % 256 || a.K <= 0 || a.N <= 0 || a.batch > GVL_MAX_DECODE_BATCH) return -1;
   if (((uintptr_t)a.x & 15) || ((uintptr_t)a.W & 15)) return -1;
+  if (a.out_tiled && a.act != GVL_ACT_SILU_MUL) return -1;
+  if (a.norm_w && (a.batch > GVL_MAX_VALU_BATCH || a.K > 4096 || (a.batch > 1 && a.x_stride % 4))) return -1;
   if (a.rope_on && ((a.Dr & 1) || (a.N & 3))) return -1;
   if (a.act == GVL_ACT_SILU_MUL && (a.N & 3)) return -1;
-  if (a.tail_xn && (!a.out_bf16 || !a.tail_norm_w || !a.tail_counter || (a.N & 3) || a.N > 4096 || a.act != GVL_ACT_NONE || a.rope_on)) return -1;
-  if (a.batch == 1) { a.x_stride = 0; }
-  const int RB = a.N >= 8192 ? 2 : 1;
+  // variant (experiments: GVL_DGEMM_VARIANT = rb*1000 + nw*100 + u*10 + nt; 0 = the measured default)
+  static const int env_variant = [] { const char* e = getenv("GVL_DGEMM_VARIANT"); return e ? atoi(e) : 0; }();
+  int variant = a.variant ? a.variant : env_variant;
+  if (variant == 0) variant = (a.N >= 16384 ? 2000 : 1000) + 800 + 40 + 1;   // measured (tools/decode_bench.py, profiles/r02_decode_microbench.txt)
+  const int RB = variant / 1000, NW = (variant / 100) % 10;
+  if (a.K % (NW * 32)) return -1;
   const int blocks = (a.N + 16 * RB - 1) / (16 * RB);
-  if (RB == 2) hipLaunchKernelGGL(dgemm_kernel<2>, dim3(blocks), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL(dgemm_kernel<1>, dim3(blocks), dim3(512), 0, st, a);
+  const size_t lds = a.norm_w ? (size_t)a.batch * a.K * 2 : 0;
+  if (a.norm_w) {
+    switch (variant) {
+#define DG_CASE(rb, nw, u, nt) case rb * 1000 + nw * 100 + u * 10 + nt: hipLaunchKernelGGL((dgemm_kernel<rb, nw, u, nt, 1>), dim3(blocks), dim3(nw * 64), lds, st, a); break;
+      DG_CASE(1, 8, 4, 1) DG_CASE(2, 8, 4, 1)
+#undef DG_CASE
+      default: return -1;
+    }
+    return CHECK_LAUNCH();
+  }
+  switch (variant) {
+#define DG_CASE(rb, nw, u, nt) case rb * 1000 + nw * 100 + u * 10 + nt: hipLaunchKernelGGL((dgemm_kernel<rb, nw, u, nt, 0>), dim3(blocks), dim3(nw * 64), 0, st, a); break;
+    DG_CASE(1, 8, 4, 1) DG_CASE(2, 8, 4, 1) DG_CASE(1, 4, 4, 1) DG_CASE(2, 4, 4, 1) DG_CASE(1, 8, 2, 1) DG_CASE(2, 8, 2, 1)
+#undef DG_CASE
+    default: return -1;
+  }
+  return CHECK_LAUNCH();
+}
+
+// ---- tile-order copies --------------------------------------------------------------------------------------------------------
+// W [N][K] row-major -> Wt [ceil(N/16)][K/32][64][8]: lane l of tile (rbk, s) = row rbk*16 + (l & 15) (through the rotate_half pair
+// permutation when Dr > 0: logical rows (2j, 2j+1) = weight rows (hd*Dr + d, hd*Dr + d + Dr/2) for the q and k heads), k chunk l >> 4.
+// Rows >= N are zero.
+__global__ void retile_weight_kernel(const bf16_t* __restrict__ W, bf16_t* __restrict__ Wt, int N, int K, int Dr, int n_qk_heads) {
+  const long total = (long)((N + 15) / 16) * (K / 32) * 64;
+  const int halfd = Dr >> 1, npair_qk = n_qk_heads * halfd;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int l = (int)(idx & 63);
+    const long tile = idx >> 6;
+    const int s = (int)(tile % (K / 32));
+    const int rbk = (int)(tile / (K / 32));
+    int n = rbk * 16 + (l & 15);
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (n < N) {
+      if (Dr > 0) { const int j = n >> 1; if (j < npair_qk) { const int hd = j / halfd, d = j - hd * halfd; n = hd * Dr + d + (n & 1) * halfd; } }
+      v = *(const u32x4_t*)(W + (size_t)n * K + s * 32 + (l >> 4) * 8);
+    }
+    *(u32x4_t*)(Wt + (size_t)idx * 8) = v;
+  }
+}
+int gvl_retile_decode_weight(const bf16_t* W, bf16_t* Wt, int N, int K, int Dr, int n_qk_heads, hipStream_t st) {
+  if (K % 32 || N <= 0) return -1;
+  const long total = (long)((N + 15) / 16) * (K / 32) * 64;
+  long blocks = (total + 255) / 256; if (blocks > 65535 * 8) blocks = 65535 * 8;
+  hipLaunchKernelGGL(retile_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, st, W, Wt, N, K, Dr, n_qk_heads);
+  return CHECK_LAUNCH();
+}
+// x [batch][cols] row-major -> tile order (operator-level tests)
+__global__ void rows_to_tiled_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ xt, int batch, int cols, int stride) {
+  const long total = (long)batch * cols;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(idx / cols), k = (int)(idx - (long)b * cols);
+    xt[gvl_xt_index(b, k)] = x[(size_t)b * stride + k];
+  }
+}
+int gvl_launch_rows_to_tiled(const bf16_t* x, bf16_t* xt, int batch, int cols, int stride, hipStream_t st) {
+  if (cols % 32 || batch < 1 || batch > GVL_MAX_DECODE_BATCH) return -1;
+  hipLaunchKernelGGL(rows_to_tiled_kernel, dim3((unsigned)(((long)batch * cols + 255) / 256)), dim3(256), 0, st, x, xt, batch, cols, stride);
   return CHECK_LAUNCH();
 }

@@ -147,8 +147,8 @@ struct DecodeAttnArgs {
   const int* pos_ptrs[GVL_MAX_DECODE_BATCH]; // per sequence, device: index of the new token (the cache holds *pos + 1 tokens, new one included)
   float* part;            // workspace [batch][H][nsplit][D+2]
   int* counters;          // [batch][H] arrival tickets, zero between launches (the merging block re-arms them)
-  bf16_t* out;            // [batch][H*Dout], out_stride elements apart
-  int H, KV, D, Dout, nsplit, batch, q_stride, out_stride;
+  bf16_t* out;            // [batch][H*Dout], out_stride elements apart; out_tiled: B-operand tile order (gvl_xt_index) for the skinny decode GEMM
+  int H, KV, D, Dout, nsplit, batch, q_stride, out_stride, out_tiled;
   float scale;
 };
 int gvl_launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st);
@@ -206,10 +206,14 @@ struct GemvArgs {
   int rope_on; const float *cos_s, *sin_s, *cos_l, *sin_l; int rope_switch;
   const int* pos_ptrs[GVL_MAX_DECODE_BATCH]; const int* tables[GVL_MAX_DECODE_BATCH];   // per sequence of the batch
   bf16_t *Q, *Kt, *Vt; int H, KV, Dr, D; int q_stride;
-  // skinny-GEMM path only (gvl_launch_dgemm): the LAST block of the launch writes tail_xn[b][:] = bf16(tail_norm_w * bf16(out_bf16[b][:] * rstd))
-  // for b < batch -- the RMSNorm in front of the NEXT projection, done once by the producer of the residual stream
-  const bf16_t* tail_norm_w; float tail_eps; bf16_t* tail_xn; int tail_stride; int* tail_counter;
+  int variant;                    // skinny-GEMM path: kernel variant (0 = default; tools/decode_bench.py)
+  int out_tiled;                  // skinny-GEMM path: the SwiGLU epilogue writes out_bf16 in B-operand tile order (it feeds down_proj)
 };
+// B-operand tile order of the decode activations: element (sequence j < 16, column k) of a [16][cols] matrix lives at
+// [k / 32][lane = 16 * ((k / 8) % 4) + j][k % 8] -- one k step of the MFMA is 1 KiB of consecutive addresses
+__host__ __device__ __forceinline__ size_t gvl_xt_index(int j, int k) { return ((size_t)(k >> 5) * 64 + (size_t)(((k >> 3) & 3) * 16 + j)) * 8 + (k & 7); }
+int gvl_retile_decode_weight(const bf16_t* W, bf16_t* Wt, int N, int K, int Dr, int n_qk_heads, hipStream_t st);
+int gvl_launch_rows_to_tiled(const bf16_t* x, bf16_t* xt, int batch, int cols, int stride, hipStream_t st);
 int gvl_launch_gemv(const GemvArgs& a, hipStream_t st);
 // the same projection as ONE MFMA skinny GEMM for 1..16 sequences (gvl_decode.hip); -1 when the geometry needs the VALU kernel
 int gvl_launch_dgemm(const GemvArgs& a, hipStream_t st);
@@ -230,6 +234,8 @@ struct TokPtrs { const int* p[GVL_MAX_DECODE_BATCH]; int n; };
 int gvl_launch_gather_tok_rows(const bf16_t* table, const TokPtrs& toks, bf16_t* dst, int cols, hipStream_t st);
 // x[b] = table[*toks.p[b]] and xn[b] = bf16(w * bf16(x[b] * rstd)): embedding gather + the first layer's input RMSNorm (gvl_decode.hip)
 int gvl_launch_embed_norm(const bf16_t* table, const TokPtrs& toks, bf16_t* x, bf16_t* xn, const bf16_t* w, int cols, float eps, hipStream_t st);
+// xn (B-operand tile order) = rmsnorm(x[b]) * w for the row-major residual rows x [batch][cols]: one wave per sequence (gvl_decode.hip)
+int gvl_launch_norm_tiled(bf16_t* x, bf16_t* xn, const bf16_t* w, int batch, int cols, float eps, hipStream_t st);
 struct IntPtrs { int* p[GVL_MAX_DECODE_BATCH]; int n; };
 int gvl_launch_inc_many(const IntPtrs& ptrs, hipStream_t st);
 int gvl_launch_inc(int* p, hipStream_t st);

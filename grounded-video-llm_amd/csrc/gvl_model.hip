@@ -33,7 +33,8 @@ struct Tensor { void* p = nullptr; int dtype = 0; int64_t numel = 0; std::vector
 
 struct ClipLayerW { const float *ln1w, *ln1b, *ln2w, *ln2b, *qkvb, *outb, *fc1b, *fc2b; const bf16_t *qkvw, *outw, *fc1w, *fc2w; };
 struct Iv2BlockW { const bf16_t *n1, *n2, *qkvw, *qn, *kn, *projw, *fc1w, *fc2w; const float *projb, *ls1, *ls2, *fc1b, *fc2b; };
-struct LlmLayerW { const bf16_t *ln1, *ln2, *qkvw, *ow, *guw, *downw; };
+struct LlmLayerW { const bf16_t *ln1, *ln2, *qkvw, *ow, *guw, *downw;
+                   const bf16_t *qkvd, *od, *gud, *downd; };   // decode copies in MFMA tile order (gvl_decode.hip); null on the VALU fallback
 
 struct Seq {
   bool used = false; int max_tokens = 0, n_pages = 0; std::vector<int> pages;
@@ -78,9 +79,10 @@ struct gvl_ctx {
   // decode buffers
   bf16_t *d_x = nullptr, *d_qkv = nullptr, *d_q = nullptr, *d_attn = nullptr, *d_act = nullptr;
   bf16_t* d_xn = nullptr;            // [NB][hidden] RMS-normalised residual rows for the next projection (skinny-GEMM decode path)
-  int* d_tail_counter = nullptr;     // arrival tickets of the o_proj / down_proj launches (zero between launches)
   int* d_seq_ngen = nullptr;         // [kMaxSeqs]
   bool decode_mfma = false;          // geometry allows the skinny MFMA GEMM decode path (K % 256 == 0 for every projection)
+  const bf16_t* l_headd = nullptr;   // lm_head in tile order
+  std::vector<void*> dw_allocs;      // tile-order weight copies owned by the ctx
   // (all decode work buffers hold GVL_MAX_DECODE_BATCH rows: one per sequence of a batched decode step)
   float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_seq_tok = nullptr, *d_seq_out = nullptr;
   int nsplit = 16, outlist_cap = 8192, ids_cap = 16384;
@@ -433,15 +435,21 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
   const bool mfma = ctx->decode_mfma;
   if (mfma ? (B < 1 || B > GVL_MAX_DECODE_BATCH) : (B != 1 && B != 2 && B != 4)) return fail(ctx, GVL_ERR_ARG, "decode_step: unsupported batch");
   TokPtrs tp; memset(&tp, 0, sizeof(tp)); tp.n = B; for (int b = 0; b < B; ++b) tp.p[b] = sqs[b]->d_tok;
-  if (mfma) RUN(GVL_PROF_OTHER, 0, gvl_launch_embed_norm(ctx->l_embed, tp, ctx->d_x, ctx->d_xn, ctx->ll[0].ln1, Hd, f.rms_eps, st));
-  else RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_tok_rows(ctx->l_embed, tp, ctx->d_x, Hd, st));
+  // RMSNorm in front of qkv / gate_up / lm_head: groups of <= 4 normalise inside the consumer (LDS, like the VALU kernel), larger
+  // groups run one norm launch per projection whose output every block of the consumer shares (gvl_decode.hip header)
+  const bool fused_norm = !mfma || B <= GVL_MAX_VALU_BATCH;
+  if (fused_norm) RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_tok_rows(ctx->l_embed, tp, ctx->d_x, Hd, st));
+  else RUN(GVL_PROF_OTHER, 0, gvl_launch_embed_norm(ctx->l_embed, tp, ctx->d_x, ctx->d_xn, ctx->ll[0].ln1, Hd, f.rms_eps, st));
   double ctx_tokens = 0; for (int b = 0; b < B; ++b) ctx_tokens += sqs[b]->pos + 1;
   auto proj = [&](const GemvArgs& g) { return mfma ? gvl_launch_dgemm(g, st) : gvl_launch_gemv(g, st); };
+  auto normed_input = [&](GemvArgs& g, const bf16_t* w) {       // the projection reads rmsnorm(d_x) * w
+    if (fused_norm) { g.x = ctx->d_x; g.norm_w = w; g.eps = f.rms_eps; } else g.x = ctx->d_xn;
+  };
   for (int l = 0; l < f.layers; ++l) {
     const LlmLayerW& w = ctx->ll[l];
     bf16_t* Kt = ctx->kpool + (size_t)l * ctx->layer_stride; bf16_t* Vt = ctx->vpool + (size_t)l * ctx->layer_stride;
-    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.qkvw; g.N = qkvw; g.K = Hd; g.batch = B; g.x_stride = Hd;
-      if (mfma) g.x = ctx->d_xn; else { g.x = ctx->d_x; g.norm_w = w.ln1; g.eps = f.rms_eps; }
+    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? w.qkvd : w.qkvw; g.N = qkvw; g.K = Hd; g.batch = B; g.x_stride = Hd;
+      normed_input(g, w.ln1);
       // fused epilogue: RoPE + Q write + paged-KV append (replaces a separate qkv_post launch per layer per token)
       g.rope_on = 1; g.cos_s = ctx->cos_s; g.sin_s = ctx->sin_s; g.cos_l = ctx->cos_l; g.sin_l = ctx->sin_l;
       g.rope_switch = ctx->cos_l ? f.rope_orig_max_pos : 0;
@@ -451,25 +459,25 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
     { DecodeAttnArgs a; memset(&a, 0, sizeof(a)); a.q = ctx->d_q; a.q_stride = H * D; a.Kt = Kt; a.Vt = Vt;
       for (int b = 0; b < B; ++b) { a.tables[b] = sqs[b]->d_block_table; a.pos_ptrs[b] = sqs[b]->d_pos; }
       a.part = ctx->d_part; a.counters = ctx->d_counters; a.batch = B;
-      a.out = ctx->d_attn; a.out_stride = H * Dr; a.H = H; a.KV = KV; a.D = D; a.Dout = Dr; a.nsplit = ctx->nsplit; a.scale = 1.0f / sqrtf((float)Dr);
+      a.out = ctx->d_attn; a.out_stride = H * Dr; a.out_tiled = mfma ? 1 : 0; a.H = H; a.KV = KV; a.D = D; a.Dout = Dr; a.nsplit = ctx->nsplit; a.scale = 1.0f / sqrtf((float)Dr);
       RUN(GVL_PROF_DECODE_ATTN, 4.0 * ctx_tokens * (double)KV * D, gvl_launch_decode_attention(a, st)); }
-    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.ow; g.N = Hd; g.K = H * Dr; g.x = ctx->d_attn; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
+    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? w.od : w.ow; g.N = Hd; g.K = H * Dr; g.x = ctx->d_attn; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
       g.batch = B; g.x_stride = H * Dr; g.out_stride = Hd;
-      if (mfma) { g.tail_norm_w = w.ln2; g.tail_eps = f.rms_eps; g.tail_xn = ctx->d_xn; g.tail_stride = Hd; g.tail_counter = ctx->d_tail_counter; }   // post_attention_layernorm for gate_up
       RUN(GVL_PROF_GEMV, 2.0 * Hd * H * Dr, proj(g)); }
-    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.guw; g.N = 2 * I; g.K = Hd; g.act = GVL_ACT_SILU_MUL; g.out_bf16 = ctx->d_act;
-      g.batch = B; g.x_stride = Hd; g.out_stride = I;
-      if (mfma) g.x = ctx->d_xn; else { g.x = ctx->d_x; g.norm_w = w.ln2; g.eps = f.rms_eps; }
+    if (!fused_norm) RUN(GVL_PROF_OTHER, 0, gvl_launch_norm_tiled(ctx->d_x, ctx->d_xn, w.ln2, B, Hd, f.rms_eps, st));     // post_attention_layernorm
+    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? w.gud : w.guw; g.N = 2 * I; g.K = Hd; g.act = GVL_ACT_SILU_MUL; g.out_bf16 = ctx->d_act;
+      g.batch = B; g.x_stride = Hd; g.out_stride = I; g.out_tiled = mfma ? 1 : 0;
+      normed_input(g, w.ln2);
       RUN(GVL_PROF_GEMV, 4.0 * I * Hd, proj(g)); }
-    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = w.downw; g.N = Hd; g.K = I; g.x = ctx->d_act; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
+    { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? w.downd : w.downw; g.N = Hd; g.K = I; g.x = ctx->d_act; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
       g.batch = B; g.x_stride = I; g.out_stride = Hd;
-      if (mfma) {   // the next layer's input_layernorm, or the final norm in front of lm_head
-        g.tail_norm_w = l + 1 < f.layers ? ctx->ll[l + 1].ln1 : ctx->l_norm; g.tail_eps = f.rms_eps; g.tail_xn = ctx->d_xn; g.tail_stride = Hd; g.tail_counter = ctx->d_tail_counter; }
       RUN(GVL_PROF_GEMV, 2.0 * Hd * I, proj(g)); }
+    if (!fused_norm)   // the next layer's input_layernorm, or the final norm in front of lm_head
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_norm_tiled(ctx->d_x, ctx->d_xn, l + 1 < f.layers ? ctx->ll[l + 1].ln1 : ctx->l_norm, B, Hd, f.rms_eps, st));
   }
-  { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = ctx->l_headw; g.N = f.vocab; g.K = Hd; g.bias = ctx->l_headb;
+  { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? ctx->l_headd : ctx->l_headw; g.N = f.vocab; g.K = Hd; g.bias = ctx->l_headb;
     g.batch = B; g.x_stride = Hd; g.out_stride = f.vocab;
-    if (mfma) g.x = ctx->d_xn; else { g.x = ctx->d_x; g.norm_w = ctx->l_norm; g.eps = f.rms_eps; }
+    normed_input(g, ctx->l_norm);
     g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, proj(g)); }
   { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = f.vocab; am.batch = B;   // token, output list, n_gen++ and pos++ on the device
     for (int b = 0; b < B; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.ngen_ptrs[b] = sqs[b]->d_ngen; am.pos_ptrs[b] = sqs[b]->d_pos; }
@@ -595,7 +603,6 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
     const size_t NB = GVL_MAX_DECODE_BATCH;
     ok &= hipMalloc((void**)&ctx->d_x, NB * f.hidden * 2) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_xn, NB * f.hidden * 2) == hipSuccess;
-    ok &= hipMalloc((void**)&ctx->d_tail_counter, 64) == hipSuccess && hipMemset(ctx->d_tail_counter, 0, 64) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_seq_ngen, (size_t)gvl_ctx::kMaxSeqs * 4) == hipSuccess;
     {   // the skinny-GEMM decode path needs every projection's K to split over 8 waves x 32-wide MFMA steps, and rows that one wave normalises
       const char* e = getenv("GVL_DECODE_VALU");
@@ -623,8 +630,9 @@ int gvl_destroy(gvl_ctx* ctx) {
   if (!ctx) return 0;
   hipDeviceSynchronize();
   for (auto& kv : ctx->w) if (kv.second.p) hipFree(kv.second.p);
+  for (void* p : ctx->dw_allocs) if (p) hipFree(p);
   if (ctx->comm) gvl_comm_destroy(ctx);
-  void* ptrs[] = {ctx->d_xn, ctx->d_tail_counter, ctx->d_seq_ngen, ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_out, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
+  void* ptrs[] = {ctx->d_xn, ctx->d_seq_ngen, ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_out, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& r : ctx->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   delete ctx;
@@ -693,14 +701,6 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
     if (phi) { NEED("sub_gn", GVL_F32, cin, &ctx->sub_gn); NEED("glb_gn", GVL_BF16, cin, &ctx->glb_gn); }
     else NEED("newline", GVL_BF16, Hd, &ctx->newline);
   }
-  if (ctx->has_llm && !ctx->kpool) {          // cfg.kv_pages <= 0: size the pool from what is free NOW (weights resident)
-    const char* fe = getenv("GVL_KV_FRACTION");
-    const double frac = fe ? atof(fe) : 0.85;
-    const int pages = auto_kv_pages(ctx, frac > 0 && frac <= 1 ? frac : 0.85, (size_t)4 << 30);
-    if (pages <= 0) return fail(ctx, GVL_ERR_HIP, "hipMemGetInfo failed");
-    const int rc = alloc_kv_pool(ctx, pages);
-    if (rc) return rc;
-  }
   if (ctx->has_llm) {
     const int Hd = f.hidden, I = f.inter, Dr = ctx->l_Dr, qkvw = (f.heads + 2 * f.kv_heads) * Dr;
     NEED("llm.embed", GVL_BF16, (int64_t)f.vocab * Hd, &ctx->l_embed); NEED("llm.norm.w", GVL_BF16, Hd, &ctx->l_norm);
@@ -718,6 +718,39 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
       NEED(LN("gu.w"), GVL_BF16, (int64_t)2 * I * Hd, &w.guw); NEED(LN("down.w"), GVL_BF16, (int64_t)Hd * I, &w.downw);
 #undef LN
     }
+    // decode copies in MFMA tile order (one wave load = 1 KiB of consecutive addresses; the rotate_half row permutation of qkv
+    // is baked in): 288 GB of HBM pay for the second copy of the LLM -- the prefill GEMM keeps the row-major one
+    for (void* p : ctx->dw_allocs) if (p) hipFree(p);
+    ctx->dw_allocs.clear();
+    if (ctx->decode_mfma) {
+      auto tiled = [&](const bf16_t* W, int N, int K, int dr, int nqk, const bf16_t** out) -> int {
+        void* p = nullptr;
+        const size_t bytes = (size_t)((N + 15) / 16) * 16 * K * 2;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, GVL_ERR_OOM, "hipMalloc(decode weight copy) failed"); }
+        ctx->dw_allocs.push_back(p);
+        if (gvl_retile_decode_weight(W, (bf16_t*)p, N, K, dr, nqk, nullptr)) return fail(ctx, GVL_ERR_HIP, "retile launch failed");
+        *out = (const bf16_t*)p;
+        return 0;
+      };
+      for (int l = 0; l < f.layers; ++l) {
+        LlmLayerW& w = ctx->ll[l];
+        int rc = tiled(w.qkvw, qkvw, Hd, Dr, f.heads + f.kv_heads, &w.qkvd);
+        if (!rc) rc = tiled(w.ow, Hd, f.heads * Dr, 0, 0, &w.od);
+        if (!rc) rc = tiled(w.guw, 2 * I, Hd, 0, 0, &w.gud);
+        if (!rc) rc = tiled(w.downw, Hd, I, 0, 0, &w.downd);
+        if (rc) return rc;
+      }
+      { const int rc = tiled(ctx->l_headw, f.vocab, Hd, 0, 0, &ctx->l_headd); if (rc) return rc; }
+      HIPCHK(ctx, hipDeviceSynchronize());
+    }
+  }
+  if (ctx->has_llm && !ctx->kpool) {          // cfg.kv_pages <= 0: size the pool from what is free NOW (weights resident)
+    const char* fe = getenv("GVL_KV_FRACTION");
+    const double frac = fe ? atof(fe) : 0.85;
+    const int pages = auto_kv_pages(ctx, frac > 0 && frac <= 1 ? frac : 0.85, (size_t)4 << 30);
+    if (pages <= 0) return fail(ctx, GVL_ERR_HIP, "hipMemGetInfo failed");
+    const int rc = alloc_kv_pool(ctx, pages);
+    if (rc) return rc;
   }
   ctx->finalized = true;
   return 0;
@@ -1214,8 +1247,50 @@ int gvl_op_rmsnorm(gvl_ctx* ctx, const uint16_t* x, const uint16_t* w, uint16_t*
 int gvl_op_dgemm(gvl_ctx* ctx, const uint16_t* W, const uint16_t* x, const float* bias, float* y, int N, int K, int batch, void* stream) {
   if (!ctx) return GVL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  GemvArgs g; memset(&g, 0, sizeof(g)); g.W = W; g.N = N; g.K = K; g.x = x; g.bias = bias; g.out_f32 = y; g.batch = batch; g.x_stride = K; g.out_stride = N;
-  RUN(GVL_PROF_GEMV, 2.0 * N * K, gvl_launch_dgemm(g, st));
+  if (N <= 0 || K <= 0 || K % 256 || batch < 1 || batch > GVL_MAX_DECODE_BATCH) return fail(ctx, GVL_ERR_ARG, "gvl_op_dgemm: K % 256 == 0 and 1 <= batch <= 16");
+  // operator-level entry (tests / microbenchmarks): the operands arrive row-major and are re-tiled here; the model keeps tiled copies
+  void *wt = nullptr, *xt = nullptr;
+  HIPCHK(ctx, hipMalloc(&wt, (size_t)((N + 15) / 16) * 16 * K * 2));
+  if (hipMalloc(&xt, (size_t)16 * K * 2) != hipSuccess) { hipFree(wt); return fail(ctx, GVL_ERR_OOM, "gvl_op_dgemm: hipMalloc"); }
+  int rc = gvl_retile_decode_weight(W, (bf16_t*)wt, N, K, 0, 0, st);
+  if (!rc) rc = gvl_launch_rows_to_tiled(x, (bf16_t*)xt, batch, K, K, st);
+  GemvArgs g; memset(&g, 0, sizeof(g)); g.W = (const bf16_t*)wt; g.N = N; g.K = K; g.x = (const bf16_t*)xt; g.bias = bias; g.out_f32 = y; g.batch = batch; g.x_stride = K; g.out_stride = N;
+  if (!rc) { ProfScope _ps(ctx, GVL_PROF_GEMV, 2.0 * N * K, st); rc = gvl_launch_dgemm(g, st); }
+  hipStreamSynchronize(st);
+  hipFree(wt); hipFree(xt);
+  if (rc) return fail(ctx, rc == -1 ? GVL_ERR_ARG : GVL_ERR_HIP, "gvl_op_dgemm: launch failed");
+  return 0;
+}
+// micro-benchmark of the decode projection kernels on synthetic operands (tools/decode_bench.py): mode 0 = skinny MFMA GEMM (variant:
+// see gvl_launch_dgemm), 1 = round-1 VALU GEMV (batch 1, 2, 4), 2 / 3 = the same two with the fused RMSNorm prologue (batch <= 4).  `rounds` distinct weight matrices are cycled so that the
+// Infinity Cache cannot hold the stream; returns the average microseconds per launch.
+int gvl_op_decode_bench(gvl_ctx* ctx, int N, int K, int batch, int mode, int variant, int rounds, int iters, double* us_per_launch, void* stream) {
+  if (!ctx || !us_per_launch || N <= 0 || K <= 0 || K % 256 || batch < 1 || batch > GVL_MAX_DECODE_BATCH || rounds < 1 || iters < 1) return fail(ctx, GVL_ERR_ARG, "gvl_op_decode_bench: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t wbytes = (size_t)((N + 15) / 16) * 16 * K * 2;
+  char *w = nullptr, *x = nullptr, *y = nullptr;
+  HIPCHK(ctx, hipMalloc((void**)&w, wbytes * rounds));
+  HIPCHK(ctx, hipMalloc((void**)&x, (size_t)16 * K * 2));
+  HIPCHK(ctx, hipMalloc((void**)&y, (size_t)16 * N * 4));
+  hipMemsetAsync(w, 0x11, wbytes * rounds, st); hipMemsetAsync(x, 0x22, (size_t)16 * K * 2, st);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  int rc = 0;
+  for (int pass = 0; pass < 2 && !rc; ++pass) {          // pass 0 = warm-up
+    if (pass == 1) hipEventRecord(e0, st);
+    for (int it = 0; it < (pass ? iters : 3) && !rc; ++it) {
+      GemvArgs g; memset(&g, 0, sizeof(g)); g.W = (const bf16_t*)(w + wbytes * (it % rounds)); g.N = N; g.K = K; g.x = (const bf16_t*)x; g.out_f32 = (float*)y;
+      g.batch = batch; g.x_stride = K; g.out_stride = N; g.variant = variant;
+      if (mode == 2 || mode == 3) { g.norm_w = (const bf16_t*)x; g.eps = 1e-5f; }   // fused RMSNorm prologue: 2 = skinny GEMM (LDS), 3 = VALU GEMV
+      rc = (mode == 1 || mode == 3) ? gvl_launch_gemv(g, st) : gvl_launch_dgemm(g, st);
+    }
+    if (pass == 1) hipEventRecord(e1, st);
+  }
+  hipStreamSynchronize(st);
+  float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  hipFree(w); hipFree(x); hipFree(y);
+  if (rc) return fail(ctx, rc == -1 ? GVL_ERR_ARG : GVL_ERR_HIP, "gvl_op_decode_bench: launch failed (unsupported variant / geometry)");
+  *us_per_launch = 1e3 * ms / iters;
   return 0;
 }
 int gvl_op_gemv(gvl_ctx* ctx, const uint16_t* W, const uint16_t* x, const float* bias, float* y, int N, int K, void* stream) {

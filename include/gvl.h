@@ -218,6 +218,10 @@ int gvl_op_gemv(gvl_ctx* ctx, const uint16_t* W, const uint16_t* x, const float*
  * read once for all sequences; K % 256 == 0).  x bf16 [batch][K], y f32 [batch][N]. */
 int gvl_op_dgemm(gvl_ctx* ctx, const uint16_t* W, const uint16_t* x, const float* bias, float* y, int N, int K, int batch,
                  void* stream);
+/* measurement only (tools/decode_bench.py): average microseconds per launch of one decode projection [N,K] x `batch` sequences on
+ * synthetic operands; mode 0 = skinny MFMA GEMM (variant 0 = default), 1 = VALU GEMV; `rounds` distinct weight copies are cycled. */
+int gvl_op_decode_bench(gvl_ctx* ctx, int N, int K, int batch, int mode, int variant, int rounds, int iters, double* us_per_launch,
+                        void* stream);
 
 #ifdef __cplusplus
 }

@@ -315,6 +315,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--new-tokens", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plain", action="store_true", help="timed region only (warmup + steps clips in the process): the target of the rocprofv3 passes")
     ap.add_argument("--clips-per-step", type=int, default=int(os.environ.get("GVL_BENCH_CPS", "4")),
                     help="pipelined mode: clips per GPU per step; their greedy decode is batched (one weight stream per token for all of them)")
     ap.add_argument("--mode", choices=["pipelined", "serial"], default="pipelined",
@@ -373,6 +374,13 @@ def main():
         dt = float(tt.item())
     clips_per_s = world * args.steps * cps / dt
 
+    if args.plain:
+        if rank == 0:
+            print(json.dumps({"metric": "clips/sec (plain run for profiling)", "value": round(clips_per_s, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "mode": args.mode, "clips_in_process": (args.steps + args.warmup) * cps + (cps if args.mode == "pipelined" else 0)}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     # ---- untimed extras: PCIe-inclusive rate, single-clip latency, decode-only rate, per-kernel-family profile, CPU baseline -----
     # The boundary takes DEVICE pixel tensors (`value` above); here every clip's 74 MB of f32 pixels is first copied from pinned
     # host memory on the vision stream, as a caller holding CPU-preprocessed frames would (inference.py:119-120 of the reference).

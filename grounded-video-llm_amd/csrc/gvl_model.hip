@@ -491,13 +491,41 @@ int decode_group_size(const gvl_ctx* ctx, int left) {
   return left >= 4 ? 4 : (left >= 2 ? 2 : 1);
 }
 
-// greedy decode of one group (B = 1, 2 or 4 prefilled sequences) until every member hit eos / max_new / its capacity
+// A decode step's launches carry device pointers and group constants only, so ONE captured step can be replayed for the following
+// tokens of the same group (hipGraph): the host pays one graph launch instead of ~165 kernel launches per token.
+struct StepGraph {
+  hipGraph_t g = nullptr; hipGraphExec_t e = nullptr; bool failed = false;
+  ~StepGraph() { if (e) hipGraphExecDestroy(e); if (g) hipGraphDestroy(g); }
+};
+int decode_step_replay(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st, StepGraph& sg) {
+  static const int graph_on = [] { const char* e = getenv("GVL_DECODE_GRAPH"); return e ? atoi(e) : 0; }();
+  if (!graph_on || ctx->prof || st == nullptr || sg.failed) return decode_step(ctx, sqs, B, st);
+  if (!sg.e) {
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); sg.failed = true; return decode_step(ctx, sqs, B, st); }
+    const int rc = decode_step(ctx, sqs, B, st);               // recorded, not executed; the host counters advance once
+    const hipError_t ce = hipStreamEndCapture(st, &sg.g);
+    if (rc) return rc;
+    if (ce != hipSuccess || hipGraphInstantiate(&sg.e, sg.g, nullptr, nullptr, 0) != hipSuccess) {
+      (void)hipGetLastError(); sg.failed = true; sg.e = nullptr;
+      for (int b = 0; b < B; ++b) { sqs[b]->pos -= 1; sqs[b]->n_gen -= 1; }
+      return decode_step(ctx, sqs, B, st);
+    }
+    HIPCHK(ctx, hipGraphLaunch(sg.e, st));
+    return 0;
+  }
+  HIPCHK(ctx, hipGraphLaunch(sg.e, st));
+  for (int b = 0; b < B; ++b) { sqs[b]->pos += 1; sqs[b]->n_gen += 1; }
+  return 0;
+}
+
+// greedy decode of one group (prefilled sequences at the same generation step) until every member hit eos / max_new / its capacity
 int decode_group(gvl_ctx* ctx, Seq* const* sqs, int B, int max_new, int eos_id, int32_t* const* out_ids, int* const* n_out, hipStream_t st) {
   const int CHECK_EVERY = 16;
   int checked = 0;                       // steps already inspected for eos (all members advance together)
   bool done[GVL_MAX_DECODE_BATCH] = {false};
   const int start_gen = sqs[0]->n_gen;   // members of a group must be in the same generation step
   for (int b = 1; b < B; ++b) if (sqs[b]->n_gen != start_gen) return fail(ctx, GVL_ERR_STATE, "decode batch: sequences are at different generation steps");
+  StepGraph sg;
   for (;;) {
     const int n_gen = sqs[0]->n_gen;
     bool full = n_gen >= max_new;
@@ -517,7 +545,7 @@ int decode_group(gvl_ctx* ctx, Seq* const* sqs, int B, int max_new, int eos_id, 
       checked = n_gen;
       if (all_done) return 0;
     }
-    int rc = decode_step(ctx, sqs, B, st);
+    int rc = decode_step_replay(ctx, sqs, B, st, sg);
     if (rc) return rc;
   }
 }

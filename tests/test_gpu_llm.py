@@ -1,9 +1,13 @@
 """-m gpu: LLM prefill / paged-KV decode / greedy loop through the C ABI vs goldens and the oracle.
 north_star tolerance: bf16 logits within 1e-2 relative (of the logit scale) -- asserted at full width
 (test_phi3_full_width_layer).  The tiny hidden=64 models average bf16 rounding over 64-term dot products
-instead of 3072-term ones, so a single 1-ulp flip is worth ~1e-2 of the logit scale there: those cases use
-2e-2.  Greedy ids must be identical wherever the reference's top-1 margin exceeds the tolerance."""
-TINY_TOL = 2e-2
+instead of 3072-term ones, so a single 1-ulp flip is worth ~1e-2 of the logit scale there: the per-case bounds
+below are <= 1.5 x the error observed on MI355X (round 2: phi tiny 9.5e-3, S=4100 1.17e-2, llama tiny 1.69e-2 vs the reference
+goldens).  Greedy ids must be identical wherever the reference's top-1 margin exceeds the tolerance."""
+TINY_TOL = 2e-2            # decode-step / LoRA cases (bounded through check_bf16_class against the bf16-emulating oracle)
+PHI_TINY_TOL = 1.4e-2      # observed 9.5e-3 (golden) / 6.9e-3 (oracle emu)
+PHI_LONG_TOL = 1.75e-2     # observed 1.17e-2
+LLAMA_TINY_TOL = 2e-2      # observed 1.69e-2
 import numpy as np
 import pytest
 import torch
@@ -37,12 +41,12 @@ def test_phi3_tiny_prefill_decode_greedy():
     # prefill logits (last row) vs the reference golden and vs the oracle
     seq = eng.seq_alloc(64)
     logits = eng.prefill(seq, x.to(DEV).to(bf), want_logits=True)
-    check(logits, g["logits"][0, -1], TINY_TOL, "phi3 tiny prefill last logits vs reference golden")
+    check(logits, g["logits"][0, -1], PHI_TINY_TOL, "phi3 tiny prefill last logits vs reference golden")
     ocfg = _ocfg(geo)
     cache, cache32 = [None] * geo.layers, [None] * geo.layers
     ref = O.llm_forward(ocfg, W, x, True, cache, 0, last_only=True)[0]
     O.llm_forward(ocfg, W, x, False, cache32, 0, last_only=True)
-    check(logits, ref, TINY_TOL, "phi3 tiny prefill last logits vs oracle(emu)")
+    check(logits, ref, 1.05e-2, "phi3 tiny prefill last logits vs oracle(emu)")
     # teacher-forced decode steps through the paged KV cache
     e = W["model.embed_tokens.weight"].to(bf).float()
     n = x.shape[0]
@@ -81,7 +85,7 @@ def test_phi3_longrope_switch_and_crossing():
     xl = synth.det_tensor(meta["xl"], meta["xl_shape"], 0.5)[0]
     seq = eng.seq_alloc(4200)
     logits = eng.prefill(seq, xl.to(DEV).to(bf), want_logits=True)
-    check(logits, g["logits_long"][0, -1], TINY_TOL, "phi3 tiny S=4100 (long factors) last logits vs reference golden")
+    check(logits, g["logits_long"][0, -1], PHI_LONG_TOL, "phi3 tiny S=4100 (long factors) last logits vs reference golden")
     eng.seq_free(seq)
     # crossing: prefill 4090 (short), then 12 teacher-forced steps across position 4096
     ocfg = _ocfg(geo)
@@ -114,7 +118,7 @@ def test_llama_tiny_gqa():
     x = synth.det_tensor(meta["x"], meta["x_shape"], 0.5)[0]
     seq = eng.seq_alloc(64)
     logits = eng.prefill(seq, x.to(DEV).to(bf), want_logits=True)
-    check(logits, g["logits"][0, -1], TINY_TOL, "llama tiny (GQA 4/2) prefill last logits vs reference golden")
+    check(logits, g["logits"][0, -1], LLAMA_TINY_TOL, "llama tiny (GQA 4/2) prefill last logits vs reference golden")
     ocfg = _ocfg(geo)
     cache, cache32 = [None] * geo.layers, [None] * geo.layers
     O.llm_forward(ocfg, W, x, True, cache, 0, last_only=True)

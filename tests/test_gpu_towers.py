@@ -1,7 +1,9 @@
 """-m gpu: the vision towers + glue through the C ABI vs (a) the committed goldens produced by the
 reference's own modules and (b) the CPU oracle in bf16-emulation mode on the same seeded inputs.
-Tolerances: the HIP path computes in bf16 with fp32 accumulation (as the reference GPU path does);
-vs the fp32 goldens we allow 3e-2 of the output scale, vs the bf16-emulating oracle 2e-2."""
+Tolerances (of the output scale): the HIP path computes in bf16 with fp32 accumulation (as the reference GPU path does); every
+bound below is <= 1.5 x the error observed on MI355X in round 2 (profiles/r02_parity_observed.txt) -- the kernels are
+deterministic, so the margin only has to absorb future re-orderings of fp32 sums, not run-to-run noise.  The full-depth
+stacks (23 / 39 layers) are pinned in tests/test_gpu_c0.py."""
 import pytest
 import torch
 
@@ -23,7 +25,7 @@ def _clip_engine(c, seed):
     return eng, W
 
 
-@pytest.mark.parametrize("name,tol_g,tol_o", [("clip_tiny", 3e-2, 2e-2), ("clip_full_layer", 3e-2, 2e-2)])
+@pytest.mark.parametrize("name,tol_g,tol_o", [("clip_tiny", 8.8e-3, 7.4e-3), ("clip_full_layer", 5.8e-3, 3.9e-3)])   # observed 5.9e-3 / 5.0e-3, 3.8e-3 / 2.6e-3
 def test_clip(name, tol_g, tol_o):
     meta, g = load_golden(name)
     c = meta["cfg"]
@@ -47,22 +49,22 @@ def _iv2_engine(c, seed, max_segs=2):
     return eng, W
 
 
-@pytest.mark.parametrize("name", ["iv2_tiny", "iv2_full_block"])
-def test_iv2(name):
+@pytest.mark.parametrize("name,tol_g,tol_o", [("iv2_tiny", 1.8e-2, 9.9e-3), ("iv2_full_block", 1.26e-2, 6.1e-3)])   # observed 1.22e-2 / 6.6e-3, 8.4e-3 / 4.1e-3
+def test_iv2(name, tol_g, tol_o):
     meta, g = load_golden(name)
     c = meta["cfg"]
     eng, W = _iv2_engine(c, meta["seed"])
     px = synth.det_tensor(meta["px"], meta["px_shape"])
     got = eng.iv2_encode(px.to(DEV))
     st = meta.get("stride", [1, 1])
-    check(got[:, ::st[0], ::st[1]], g["out"], 3e-2, f"{name} vs reference golden (fp32)")
+    check(got[:, ::st[0], ::st[1]], g["out"], tol_g, f"{name} vs reference golden (fp32)")
     ref = O.iv2_encode(px, W, c["depth"], c["heads"], emu=True)
-    check(got, ref, 2e-2, f"{name} vs oracle (bf16 emulation)")
+    check(got, ref, tol_o, f"{name} vs oracle (bf16 emulation)")
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["glue_phi3_5", "glue_llama3"])
-def test_encode_segments_and_splice(name):
+@pytest.mark.parametrize("name,tol_g,tol_o", [("glue_phi3_5", 9.2e-3, 6.0e-3), ("glue_llama3", 6.9e-3, 8.2e-3)])   # observed 6.1e-3 / 4.0e-3, 4.6e-3 / 5.4e-3
+def test_encode_segments_and_splice(name, tol_g, tol_o):
     """encode_images + prepare_multimodal_inputs on the 2-segment skeleton."""
     meta, g = load_golden(name)
     llm, hid = meta["llm"], meta["hidden"]
@@ -90,12 +92,12 @@ def test_encode_segments_and_splice(name):
     vis = eng.encode_segments(sp[0].to(DEV), tseg.to(DEV))
     assert list(vis.shape) == meta["feats_shape"][1:]
     s = meta["stride"]
-    check(vis[None][:, ::s[0], ::s[1]], g["feats"], 3e-2, f"{name}: encode_images vs reference golden")
+    check(vis[None][:, ::s[0], ::s[1]], g["feats"], tol_g, f"{name}: encode_images vs reference golden")
     ref = O.encode_images(sp, tp, Wc, Wv, Wp, llm, clip_layers=cc["layers"], clip_heads=cc["heads"], iv2_depth=vc["depth"], iv2_heads=vc["heads"], emu=True)
-    check(vis, ref[0], 2e-2, f"{name}: encode_images vs oracle (bf16 emulation)")
+    check(vis, ref[0], tol_o, f"{name}: encode_images vs oracle (bf16 emulation)")
     emb = eng.splice(meta["ids"], vis)
     assert list(emb.shape) == meta["emb_shape"][1:]
-    check(emb[None][:, ::s[0], ::s[1]], g["emb"], 3e-2, f"{name}: spliced inputs_embeds vs reference golden")
+    check(emb[None][:, ::s[0], ::s[1]], g["emb"], tol_g, f"{name}: spliced inputs_embeds vs reference golden")
     # the text rows are pure gathers: bit-exact against the bf16 embedding table
     idx = meta["ids"].index(-200)
     assert torch.equal(emb[:idx].cpu(), emb_w.to(bf)[meta["ids"][:idx]])

@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round-N profiling passes on the GPU box (run through gpurun): kernel traces of the default and the serial bench, the two PMC
+# traffic passes, MFMA-utilisation counters per GEMM shape.  Outputs under gpurun_out/prof_$1/ ; summaries are copied to profiles/ by hand.
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r02}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp
+WHAT=${2:-all}
+db() { find "$1" -name "*.db" | head -1; }
+if [[ $WHAT == all || $WHAT == trace ]]; then
+  rocprofv3 --kernel-trace -d $OUT/default -- python $R/bench.py --no-cpu-baseline > $OUT/default.log 2>&1
+  python $R/tools/rocpd_stats.py "$(db $OUT/default)" $OUT/${TAG}_bench_kernel_stats.txt > /dev/null
+  rocprofv3 --kernel-trace -d $OUT/serial -- python $R/bench.py --plain --mode serial --steps 6 --warmup 1 > $OUT/serial.log 2>&1
+  python $R/tools/rocpd_stats.py "$(db $OUT/serial)" $OUT/${TAG}_bench_kernel_stats_serial.txt > /dev/null
+fi
+if [[ $WHAT == all || $WHAT == pmc ]]; then
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- python $R/bench.py --plain --mode serial --steps 3 --warmup 1 > $OUT/fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- python $R/bench.py --plain --mode serial --steps 3 --warmup 1 > $OUT/write.log 2>&1
+  python $R/tools/pmc_traffic.py "$(db $OUT/fetch)" "$(db $OUT/write)" $OUT/${TAG}_pmc_traffic.json 4 > /dev/null
+fi
+if [[ $WHAT == all || $WHAT == mfma ]]; then
+  : > $OUT/${TAG}_gemm_mfma_util.txt
+  while read name M N K mode; do
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $OUT/mfma_$name -- python $R/tools/gemm_one.py $M $N $K 0 5 $mode > $OUT/mfma_$name.log 2>&1
+    python $R/tools/mfma_util.py "$(db $OUT/mfma_$name)" $name $M $N $K 5 >> $OUT/${TAG}_gemm_mfma_util.txt
+  done <<SHAPES
+clip.patch 27648 1024 640 plain
+iv2.patch 24576 1408 640 bias
+clip.qkv 27696 3072 1024 bias
+clip.fc1 27696 4096 1024 bias_qgelu
+clip.fc2 27696 1024 4096 bias_resid32
+iv2.qkv 24588 4224 1408 plain
+iv2.proj 24588 1408 1408 bias_gamma_resid
+iv2.fc1 24588 6144 1408 bias_gelu
+iv2.fc2 24588 1408 6144 bias_gamma_resid
+phi.qkv 3519 9216 3072 plain
+phi.o 3519 3072 3072 resid
+phi.gu 3519 16384 3072 silu
+phi.down 3519 3072 8192 resid
+sq8192 8192 8192 8192 plain
+SHAPES
+fi
+ls -la $OUT/*.txt $OUT/*.json 2>/dev/null

@@ -1,7 +1,7 @@
 """bench.py -- the reference's headline metric on MI355X: end-to-end clips/s (and grounding-answer
 tokens/s) for the 96-frame Phi-3.5-3.8B configuration (BASELINE.json configs[1]).
 
-A "step" = one pass of the hot path over one batch of synthetic input: for every rank `--clips-per-step` (default 4)
+A "step" = one pass of the hot path over one batch of synthetic input: for every rank `--clips-per-step` (default 8)
 96-frame clips, each (12 x 336^2 spatial frames + 96 x 224^2 temporal frames, already resident in HBM) -> CLIP ViT-L/14-336
 (23 layers) + InternVideo2-1B (39 blocks) -> merge/pool + projectors -> 3420 visual tokens spliced into a
 ~100-token prompt -> Phi-3.5 prefill (S ~ 3520) -> greedy decode of 12 new tokens through the paged KV cache.
@@ -9,7 +9,8 @@ The clips of a step are prefilled one after the other and decoded TOGETHER (gvl_
 streamed once per token for all of them -- the reference batches clips in generate() too, llava_next_video.py:622-647), while
 the vision encode of the next step's clips runs on a second stream (the CLIP tower once over the 12 x 4 key frames of the step --
 gvl_clip_encode -- then InternVideo2 + projectors per clip: gvl_iv2_encode / gvl_build_visual).  `single_clip_latency_ms` (one clip, stages back to back)
-is reported next to `value`; `--clips-per-step 1` gives the one-clip-per-step pipeline (8.6 clips/s).
+is reported next to `value`; `--clips-per-step 1` gives the one-clip-per-step pipeline (8.6 clips/s); 4 / 8 / 12 clips per
+step measured 10.0 / 10.3 / 10.15 clips/s on one box (the decode of a step's clips is ONE skinny-GEMM group of up to 16 sequences).
 Random-init weights of the real architecture, synthetic pixels (no network for checkpoints/datasets).
 
 N > 1 (one process per GPU, RCCL): N clips in flight per step; every clip's 12-segment frame batch is
@@ -316,7 +317,7 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plain", action="store_true", help="timed region only (warmup + steps clips in the process): the target of the rocprofv3 passes")
-    ap.add_argument("--clips-per-step", type=int, default=int(os.environ.get("GVL_BENCH_CPS", "4")),
+    ap.add_argument("--clips-per-step", type=int, default=int(os.environ.get("GVL_BENCH_CPS", "8")),
                     help="pipelined mode: clips per GPU per step; their greedy decode is batched (one weight stream per token for all of them)")
     ap.add_argument("--mode", choices=["pipelined", "serial"], default="pipelined",
                     help="pipelined: 2 clips in flight per GPU (vision of clip k+1 overlaps decode of clip k); serial: one clip at a time")

@@ -66,3 +66,41 @@ def test_rotated_plan_balances_and_reassembles():
             for src, off, cnt in gdist.rotated_gather_index(n, r, world):
                 got += enc[src][off: off + cnt]
             assert got == [(r, u) for u in range(n)], (world, r, got)
+
+
+def _bench_exchange_worker(rank, world, port, cps, q):
+    """bench.py's per-STEP exchange on gloo: each rank 'encodes' the 12 segment blocks of its rotated plan for `cps` clip rounds (block
+    content = a code of (round, clip, segment, row)), ONE all-gather, and must end up with clip == rank's 12 segments in order."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GVL_BENCH_BACKEND="gloo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        L, H = 3, 8
+        st = bench.Stepper.__new__(bench.Stepper)
+        st.world, st.rank, st.dev, st.L = world, rank, torch.device("cpu"), L
+        st.mine = gdist.rotated_encode_plan(12, rank, world)
+        st.gather = gdist.rotated_gather_index(12, rank, world)
+
+        def block(rnd, clip, seg):
+            idx = (rnd * world + clip) * 12 + seg                       # < 72 for cps <= 3: every (block, row) code is an integer <= 216,
+            return (torch.arange(L, dtype=torch.float32)[:, None] + 3.0 * idx).expand(L, H).to(torch.bfloat16)   # exact in bf16, all distinct
+
+        vis_list = [torch.cat([block(rnd, c, u) for c, lo, hi in st.mine for u in range(lo, hi)], 0) for rnd in range(cps)]
+        got = st._exchange_multi(vis_list)
+        ok = len(got) == cps and all(torch.equal(got[rnd], torch.cat([block(rnd, rank, u) for u in range(12)], 0)) for rnd in range(cps))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cps", [1, 3])
+def test_bench_step_exchange_gloo_world2(cps):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_bench_exchange_worker, args=(r, 2, port, cps, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=180) for _ in ps)
+    [p.join(60) for p in ps]
+    assert res == [(0, True), (1, True)]

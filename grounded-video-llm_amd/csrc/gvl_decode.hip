@@ -105,8 +105,11 @@ int gvl_launch_norm_tiled(bf16_t* x, bf16_t* xn, const bf16_t* w, int batch, int
 }
 
 // RB: 16-row blocks per workgroup; NW: waves per workgroup = k slices (8 or 4); U: MFMA steps (32 k each) per load group;
-// NT: weight loads carry the non-temporal hint; XN: the B operand is RMS-normalised by this block into LDS (batch <= 4, a.x row-major)
-template <int RB, int NW, int U, int NT, int XN>
+// NT: weight loads carry the non-temporal hint; XN: the B operand is RMS-normalised by this block into LDS (batch <= 4, a.x row-major);
+// W8: the weights are the FP8 (OCP e4m3, per-row power-of-two scale) tile copy -- 16 bytes per lane feed TWO k steps; the values are
+// widened to bf16 in registers (exact) and the row scale multiplies the fp32 sum (exact): same arithmetic as bf16 weights holding
+// the de-quantised values, at half the HBM bytes
+template <int RB, int NW, int U, int NT, int XN, int W8>
 __global__ __launch_bounds__(NW * 64, 4) void dgemm_kernel(const GemvArgs a) {   // 4 waves / SIMD (<= 128 VGPRs)
   __shared__ __attribute__((aligned(16))) float red[NW][RB][64][4];
   extern __shared__ __attribute__((aligned(16))) char xs_raw[];                  // XN: [k step][k chunk][batch][8] bf16
@@ -126,7 +129,8 @@ __global__ __launch_bounds__(NW * 64, 4) void dgemm_kernel(const GemvArgs a) {  
     int rbk = blockIdx.x * RB + rb;
     const int rbk_max = (a.N + 15) / 16 - 1;
     rbk = rbk < rbk_max ? rbk : rbk_max;         // a block past the end re-reads the last row block; its rows are never stored
-    wp[rb] = a.W + ((size_t)rbk * nkt + (size_t)wave * steps) * 512 + lane * 8;
+    wp[rb] = W8 ? (const bf16_t*)((const char*)a.W + ((size_t)rbk * nkt + (size_t)wave * steps) * 512 + lane * 16)   // 512 bytes per k step
+                : a.W + ((size_t)rbk * nkt + (size_t)wave * steps) * 512 + lane * 8;
   }
   // B columns >= batch re-read the LAST sequence's chunk: a D column depends on its own B column only and those columns
   // are never stored, so no masking is needed in the loop (the duplicate addresses coalesce / broadcast)
@@ -142,11 +146,26 @@ __global__ __launch_bounds__(NW * 64, 4) void dgemm_kernel(const GemvArgs a) {  
   // in flight.  steps = K / 256 is a multiple of U = 4 for every shipped geometry (3072 -> 12, 4096 -> 16, 8192 -> 32,
   // 14336 -> 56); the remainder loop covers anything else.
   bf16x8_t wv[2][U][RB], xv[2][U];
+  auto widen = [](unsigned lo, unsigned hi) {     // 8 fp8 (e4m3) -> 8 bf16, exact
+    typedef float f32x2v_t __attribute__((ext_vector_type(2)));
+    const f32x2v_t a0 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+    const f32x2v_t b0 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+    const u32x4_t p = {pack2bf(a0[0], a0[1]), pack2bf(a1[0], a1[1]), pack2bf(b0[0], b0[1]), pack2bf(b1[0], b1[1])};
+    return __builtin_bit_cast(bf16x8_t, p);
+  };
+  u32x4_t w8[2][U / 2][RB];                       // W8: raw 16-byte pieces (two k steps each), widened at consumption
   auto request_w = [&](int buf, int s) {
+    if constexpr (W8) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+      for (int u = 0; u < U / 2; ++u)
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) wv[buf][u][rb] = NT ? __builtin_nontemporal_load((const bf16x8_t*)(wp[rb] + (s + u) * 512)) : *(const bf16x8_t*)(wp[rb] + (s + u) * 512);
+        for (int rb = 0; rb < RB; ++rb) w8[buf][u][rb] = __builtin_nontemporal_load((const u32x4_t*)((const char*)wp[rb] + (size_t)(s / 2 + u) * 1024));
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) wv[buf][u][rb] = NT ? __builtin_nontemporal_load((const bf16x8_t*)(wp[rb] + (s + u) * 512)) : *(const bf16x8_t*)(wp[rb] + (s + u) * 512);
+    }
   };
   auto request_x = [&](int buf, int s) {
 #pragma unroll
@@ -157,7 +176,12 @@ __global__ __launch_bounds__(NW * 64, 4) void dgemm_kernel(const GemvArgs a) {  
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[buf][u][rb], xv[buf][u], acc[rb], 0, 0, 0);
+      for (int rb = 0; rb < RB; ++rb) {
+        bf16x8_t wa;
+        if constexpr (W8) wa = (u & 1) ? widen(w8[buf][u / 2][rb][2], w8[buf][u / 2][rb][3]) : widen(w8[buf][u / 2][rb][0], w8[buf][u / 2][rb][1]);
+        else wa = wv[buf][u][rb];
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xv[buf][u], acc[rb], 0, 0, 0);
+      }
   };
   const int groups = steps / U;
   if (groups > 0) request_w(0, 0);               // the first weight tiles do not depend on the activations: in flight during the norm
@@ -207,7 +231,14 @@ __global__ __launch_bounds__(NW * 64, 4) void dgemm_kernel(const GemvArgs a) {  
   for (int s0 = groups * U; s0 < steps; ++s0) {
     const bf16x8_t x1 = *(const bf16x8_t*)(xp + s0 * xstep);
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_nontemporal_load((const bf16x8_t*)(wp[rb] + s0 * 512)), x1, acc[rb], 0, 0, 0);
+    for (int rb = 0; rb < RB; ++rb) {
+      bf16x8_t wa;
+      if constexpr (W8) {                          // (steps is even in W8 mode: K % 512 == 0)
+        const u32x2_t piece = *(const u32x2_t*)((const char*)wp[rb] + (size_t)(s0 / 2) * 1024 + (s0 & 1) * 8);
+        wa = widen(piece[0], piece[1]);
+      } else wa = __builtin_nontemporal_load((const bf16x8_t*)(wp[rb] + s0 * 512));
+      acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, x1, acc[rb], 0, 0, 0);
+    }
   }
   // partial sums of the 8 k-slices meet in LDS; wave rb (< RB) adds them in a fixed order and runs that row block's epilogue
 #pragma unroll
@@ -222,6 +253,11 @@ __global__ __launch_bounds__(NW * 64, 4) void dgemm_kernel(const GemvArgs a) {  
       if constexpr (NW == 8) q = q + ((ld(4) + ld(5)) + (ld(6) + ld(7)));   // but the partial sums themselves
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = q[r];
+    }
+    if constexpr (W8) {                           // per-row power-of-two scale of the FP8 copy (exact in fp32)
+      const int n4 = n0 + rb * 16 + g * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= a.wscale[n4 + r < a.N ? n4 + r : a.N - 1];
     }
     const int b = i;                             // this lane's sequence
     const int nr = n0 + rb * 16 + g * 4;         // its 4 consecutive logical rows nr .. nr + 3
@@ -318,18 +354,14 @@ int gvl_launch_dgemm(const GemvArgs& a_in, hipStream_t st) {
   if (a.K % (NW * 32)) return -1;
   const int blocks = (a.N + 16 * RB - 1) / (16 * RB);
   const size_t lds = a.norm_w ? (size_t)a.batch * a.K * 2 : 0;
-  if (a.norm_w) {
-    switch (variant) {
-#define DG_CASE(rb, nw, u, nt) case rb * 1000 + nw * 100 + u * 10 + nt: hipLaunchKernelGGL((dgemm_kernel<rb, nw, u, nt, 1>), dim3(blocks), dim3(nw * 64), lds, st, a); break;
-      DG_CASE(1, 8, 4, 1) DG_CASE(2, 8, 4, 1)
-#undef DG_CASE
-      default: return -1;
-    }
-    return CHECK_LAUNCH();
-  }
-  switch (variant) {
-#define DG_CASE(rb, nw, u, nt) case rb * 1000 + nw * 100 + u * 10 + nt: hipLaunchKernelGGL((dgemm_kernel<rb, nw, u, nt, 0>), dim3(blocks), dim3(nw * 64), 0, st, a); break;
-    DG_CASE(1, 8, 4, 1) DG_CASE(2, 8, 4, 1) DG_CASE(1, 4, 4, 1) DG_CASE(2, 4, 4, 1) DG_CASE(1, 8, 2, 1) DG_CASE(2, 8, 2, 1)
+  if (a.w_fp8 && (a.K % 512 || !a.wscale)) return -1;
+  const int key = variant * 100 + (a.norm_w ? 10 : 0) + (a.w_fp8 ? 1 : 0);
+  switch (key) {
+#define DG_CASE(rb, nw, u, nt, xn, w8) case (rb * 1000 + nw * 100 + u * 10 + nt) * 100 + xn * 10 + w8: \
+      hipLaunchKernelGGL((dgemm_kernel<rb, nw, u, nt, xn, w8>), dim3(blocks), dim3(nw * 64), lds, st, a); break;
+    DG_CASE(1, 8, 4, 1, 0, 0) DG_CASE(2, 8, 4, 1, 0, 0) DG_CASE(1, 4, 4, 1, 0, 0) DG_CASE(2, 4, 4, 1, 0, 0) DG_CASE(1, 8, 2, 1, 0, 0) DG_CASE(2, 8, 2, 1, 0, 0)
+    DG_CASE(1, 8, 4, 1, 1, 0) DG_CASE(2, 8, 4, 1, 1, 0)
+    DG_CASE(1, 8, 4, 1, 0, 1) DG_CASE(2, 8, 4, 1, 0, 1) DG_CASE(1, 8, 4, 1, 1, 1) DG_CASE(2, 8, 4, 1, 1, 1)
 #undef DG_CASE
     default: return -1;
   }
@@ -375,5 +407,73 @@ __global__ void rows_to_tiled_kernel(const bf16_t* __restrict__ x, bf16_t* __res
 int gvl_launch_rows_to_tiled(const bf16_t* x, bf16_t* xt, int batch, int cols, int stride, hipStream_t st) {
   if (cols % 32 || batch < 1 || batch > GVL_MAX_DECODE_BATCH) return -1;
   hipLaunchKernelGGL(rows_to_tiled_kernel, dim3((unsigned)(((long)batch * cols + 255) / 256)), dim3(256), 0, st, x, xt, batch, cols, stride);
+  return CHECK_LAUNCH();
+}
+
+// ---- FP8 (OCP e4m3) weight variant of the decode copies ---------------------------------------------------------------
+// Per LOGICAL row n (rotate_half pair order when Dr > 0): scale = 2^ceil(log2(max|w| / 448)) -- a power of two, so w_q = fp8(w / scale)
+// * scale is exactly representable in bf16 and the row-major bf16 weight is REPLACED by it: prefill (bf16 GEMM) and decode (FP8 stream)
+// then evaluate the same model, and every invariant of the bf16 path (decode == prefill, batch invariance) carries over.
+__device__ __forceinline__ int decode_row_perm(int n, int N, int Dr, int n_qk_heads) {
+  if (Dr > 0) { const int halfd = Dr >> 1, j = n >> 1; if (j < n_qk_heads * halfd) { const int hd = j / halfd, d = j - hd * halfd; return hd * Dr + d + (n & 1) * halfd; } }
+  return n;
+}
+__global__ __launch_bounds__(64) void fp8_row_scale_kernel(const bf16_t* __restrict__ W, float* __restrict__ scale, int N, int K, int Dr, int n_qk_heads) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const bf16_t* row = W + (size_t)decode_row_perm(n, N, Dr, n_qk_heads) * K;
+  float m = 0.f;
+  for (int c = lane; c < (K >> 3); c += 64) {
+    const u32x4_t v = *(const u32x4_t*)(row + c * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(lo_bf(v[e])), fabsf(hi_bf(v[e]))));
+  }
+  m = wave_max(m);
+  if (lane == 0) {
+    float s = 1.f;
+    if (m > 0.f) { int ex; const float fr = frexpf(m / 448.f, &ex); s = ldexpf(1.f, fr == 0.5f ? ex - 1 : ex); }   // smallest power of two >= m / 448
+    scale[n] = s;
+  }
+}
+// one thread per 16-byte piece of the FP8 tile copy [row block][k step pair][64 lanes][16]: bytes 0..7 = k chunk (l >> 4) of step 2p,
+// bytes 8..15 = the same chunk of step 2p + 1; the source elements are overwritten with their de-quantised values
+__global__ void fp8_requant_retile_kernel(bf16_t* __restrict__ W, unsigned char* __restrict__ Wt8, const float* __restrict__ scale, int N, int K, int Dr, int n_qk_heads) {
+  const long total = (long)((N + 15) / 16) * (K / 64) * 64;
+  typedef float f32x2v_t __attribute__((ext_vector_type(2)));
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int l = (int)(idx & 63);
+    const long tile = idx >> 6;
+    const int p = (int)(tile % (K / 64)), rbk = (int)(tile / (K / 64));
+    const int n = rbk * 16 + (l & 15);
+    u32x4_t out = {0u, 0u, 0u, 0u};
+    if (n < N) {
+      const float sc = scale[n], inv = 1.f / sc;                       // powers of two: both exact
+      bf16_t* row = W + (size_t)decode_row_perm(n, N, Dr, n_qk_heads) * K;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bf16_t* src = row + (2 * p + h) * 32 + (l >> 4) * 8;
+        const u32x4_t v = *(const u32x4_t*)src;
+        unsigned q[2]; u32x4_t back;
+#pragma unroll
+        for (int d2 = 0; d2 < 2; ++d2) {                                // dword d2 of the 8-byte piece = elements 4 d2 .. 4 d2 + 3
+          int pk = __builtin_amdgcn_cvt_pk_fp8_f32(lo_bf(v[2 * d2]) * inv, hi_bf(v[2 * d2]) * inv, 0, false);
+          pk = __builtin_amdgcn_cvt_pk_fp8_f32(lo_bf(v[2 * d2 + 1]) * inv, hi_bf(v[2 * d2 + 1]) * inv, pk, true);
+          q[d2] = (unsigned)pk;
+          const f32x2v_t a0 = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8(pk, true);
+          back[2 * d2] = pack2bf(a0[0] * sc, a0[1] * sc);               // exact: 4 significant bits times a power of two
+          back[2 * d2 + 1] = pack2bf(a1[0] * sc, a1[1] * sc);
+        }
+        out[2 * h] = q[0]; out[2 * h + 1] = q[1];
+        *(u32x4_t*)src = back;
+      }
+    }
+    *(u32x4_t*)(Wt8 + (size_t)idx * 16) = out;
+  }
+}
+int gvl_fp8_quantise_decode_weight(bf16_t* W, unsigned char* Wt8, float* scale, int N, int K, int Dr, int n_qk_heads, hipStream_t st) {
+  if (K % 512 || N <= 0) return -1;
+  hipLaunchKernelGGL(fp8_row_scale_kernel, dim3(N), dim3(64), 0, st, W, scale, N, K, Dr, n_qk_heads);
+  const long total = (long)((N + 15) / 16) * (K / 64) * 64;
+  long blocks = (total + 255) / 256; if (blocks > 65535 * 8) blocks = 65535 * 8;
+  hipLaunchKernelGGL(fp8_requant_retile_kernel, dim3((unsigned)blocks), dim3(256), 0, st, W, Wt8, scale, N, K, Dr, n_qk_heads);
   return CHECK_LAUNCH();
 }

@@ -207,12 +207,15 @@ struct GemvArgs {
   const int* pos_ptrs[GVL_MAX_DECODE_BATCH]; const int* tables[GVL_MAX_DECODE_BATCH];   // per sequence of the batch
   bf16_t *Q, *Kt, *Vt; int H, KV, Dr, D; int q_stride;
   int variant;                    // skinny-GEMM path: kernel variant (0 = default; tools/decode_bench.py)
+  int w_fp8; const float* wscale; // skinny-GEMM path: W is the FP8 tile copy, wscale[N] its per-row power-of-two scales
   int out_tiled;                  // skinny-GEMM path: the SwiGLU epilogue writes out_bf16 in B-operand tile order (it feeds down_proj)
 };
 // B-operand tile order of the decode activations: element (sequence j < 16, column k) of a [16][cols] matrix lives at
 // [k / 32][lane = 16 * ((k / 8) % 4) + j][k % 8] -- one k step of the MFMA is 1 KiB of consecutive addresses
 __host__ __device__ __forceinline__ size_t gvl_xt_index(int j, int k) { return ((size_t)(k >> 5) * 64 + (size_t)(((k >> 3) & 3) * 16 + j)) * 8 + (k & 7); }
 int gvl_retile_decode_weight(const bf16_t* W, bf16_t* Wt, int N, int K, int Dr, int n_qk_heads, hipStream_t st);
+// FP8 variant: scale[n] (per logical row, power of two), Wt8 = e4m3 tile copy, and W (row-major bf16) REPLACED by its de-quantised values
+int gvl_fp8_quantise_decode_weight(bf16_t* W, unsigned char* Wt8, float* scale, int N, int K, int Dr, int n_qk_heads, hipStream_t st);
 int gvl_launch_rows_to_tiled(const bf16_t* x, bf16_t* xt, int batch, int cols, int stride, hipStream_t st);
 int gvl_launch_gemv(const GemvArgs& a, hipStream_t st);
 // the same projection as ONE MFMA skinny GEMM for 1..16 sequences (gvl_decode.hip); -1 when the geometry needs the VALU kernel

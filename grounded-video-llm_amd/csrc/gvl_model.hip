@@ -34,7 +34,8 @@ struct Tensor { void* p = nullptr; int dtype = 0; int64_t numel = 0; std::vector
 struct ClipLayerW { const float *ln1w, *ln1b, *ln2w, *ln2b, *qkvb, *outb, *fc1b, *fc2b; const bf16_t *qkvw, *outw, *fc1w, *fc2w; };
 struct Iv2BlockW { const bf16_t *n1, *n2, *qkvw, *qn, *kn, *projw, *fc1w, *fc2w; const float *projb, *ls1, *ls2, *fc1b, *fc2b; };
 struct LlmLayerW { const bf16_t *ln1, *ln2, *qkvw, *ow, *guw, *downw;
-                   const bf16_t *qkvd, *od, *gud, *downd; };   // decode copies in MFMA tile order (gvl_decode.hip); null on the VALU fallback
+                   const bf16_t *qkvd, *od, *gud, *downd;      // decode copies in MFMA tile order (gvl_decode.hip; bf16, or FP8 e4m3 when cfg.decode_fp8); null on the VALU fallback
+                   const float *qkvs, *os, *gus, *downs; };    // FP8 variant: per-row power-of-two scales
 
 struct Seq {
   bool used = false; int max_tokens = 0, n_pages = 0; std::vector<int> pages;
@@ -82,6 +83,8 @@ struct gvl_ctx {
   int* d_seq_ngen = nullptr;         // [kMaxSeqs]
   bool decode_mfma = false;          // geometry allows the skinny MFMA GEMM decode path (K % 256 == 0 for every projection)
   const bf16_t* l_headd = nullptr;   // lm_head in tile order
+  const float* l_heads = nullptr;    // its FP8 row scales
+  bool fp8 = false;                  // the decode copies are FP8 (cfg.decode_fp8 and the geometry allows it)
   std::vector<void*> dw_allocs;      // tile-order weight copies owned by the ctx
   // (all decode work buffers hold GVL_MAX_DECODE_BATCH rows: one per sequence of a batched decode step)
   float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_seq_tok = nullptr, *d_seq_out = nullptr;
@@ -441,7 +444,11 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
   if (fused_norm) RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_tok_rows(ctx->l_embed, tp, ctx->d_x, Hd, st));
   else RUN(GVL_PROF_OTHER, 0, gvl_launch_embed_norm(ctx->l_embed, tp, ctx->d_x, ctx->d_xn, ctx->ll[0].ln1, Hd, f.rms_eps, st));
   double ctx_tokens = 0; for (int b = 0; b < B; ++b) ctx_tokens += sqs[b]->pos + 1;
-  auto proj = [&](const GemvArgs& g) { return mfma ? gvl_launch_dgemm(g, st) : gvl_launch_gemv(g, st); };
+  auto proj = [&](GemvArgs& g, const float* wscale) {
+    if (!mfma) return gvl_launch_gemv(g, st);
+    if (ctx->fp8) { g.w_fp8 = 1; g.wscale = wscale; }
+    return gvl_launch_dgemm(g, st);
+  };
   auto normed_input = [&](GemvArgs& g, const bf16_t* w) {       // the projection reads rmsnorm(d_x) * w
     if (fused_norm) { g.x = ctx->d_x; g.norm_w = w; g.eps = f.rms_eps; } else g.x = ctx->d_xn;
   };
@@ -455,7 +462,7 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
       g.rope_switch = ctx->cos_l ? f.rope_orig_max_pos : 0;
       for (int b = 0; b < B; ++b) { g.pos_ptrs[b] = sqs[b]->d_pos; g.tables[b] = sqs[b]->d_block_table; }
       g.Q = ctx->d_q; g.q_stride = H * D; g.Kt = Kt; g.Vt = Vt; g.H = H; g.KV = KV; g.Dr = Dr; g.D = D;
-      RUN(GVL_PROF_GEMV, 2.0 * qkvw * Hd, proj(g)); }
+      RUN(GVL_PROF_GEMV, 2.0 * qkvw * Hd, proj(g, w.qkvs)); }
     { DecodeAttnArgs a; memset(&a, 0, sizeof(a)); a.q = ctx->d_q; a.q_stride = H * D; a.Kt = Kt; a.Vt = Vt;
       for (int b = 0; b < B; ++b) { a.tables[b] = sqs[b]->d_block_table; a.pos_ptrs[b] = sqs[b]->d_pos; }
       a.part = ctx->d_part; a.counters = ctx->d_counters; a.batch = B;
@@ -463,22 +470,22 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
       RUN(GVL_PROF_DECODE_ATTN, 4.0 * ctx_tokens * (double)KV * D, gvl_launch_decode_attention(a, st)); }
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? w.od : w.ow; g.N = Hd; g.K = H * Dr; g.x = ctx->d_attn; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
       g.batch = B; g.x_stride = H * Dr; g.out_stride = Hd;
-      RUN(GVL_PROF_GEMV, 2.0 * Hd * H * Dr, proj(g)); }
+      RUN(GVL_PROF_GEMV, 2.0 * Hd * H * Dr, proj(g, w.os)); }
     if (!fused_norm) RUN(GVL_PROF_OTHER, 0, gvl_launch_norm_tiled(ctx->d_x, ctx->d_xn, w.ln2, B, Hd, f.rms_eps, st));     // post_attention_layernorm
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? w.gud : w.guw; g.N = 2 * I; g.K = Hd; g.act = GVL_ACT_SILU_MUL; g.out_bf16 = ctx->d_act;
       g.batch = B; g.x_stride = Hd; g.out_stride = I; g.out_tiled = mfma ? 1 : 0;
       normed_input(g, w.ln2);
-      RUN(GVL_PROF_GEMV, 4.0 * I * Hd, proj(g)); }
+      RUN(GVL_PROF_GEMV, 4.0 * I * Hd, proj(g, w.gus)); }
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? w.downd : w.downw; g.N = Hd; g.K = I; g.x = ctx->d_act; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
       g.batch = B; g.x_stride = I; g.out_stride = Hd;
-      RUN(GVL_PROF_GEMV, 2.0 * Hd * I, proj(g)); }
+      RUN(GVL_PROF_GEMV, 2.0 * Hd * I, proj(g, w.downs)); }
     if (!fused_norm)   // the next layer's input_layernorm, or the final norm in front of lm_head
       RUN(GVL_PROF_OTHER, 0, gvl_launch_norm_tiled(ctx->d_x, ctx->d_xn, l + 1 < f.layers ? ctx->ll[l + 1].ln1 : ctx->l_norm, B, Hd, f.rms_eps, st));
   }
   { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? ctx->l_headd : ctx->l_headw; g.N = f.vocab; g.K = Hd; g.bias = ctx->l_headb;
     g.batch = B; g.x_stride = Hd; g.out_stride = f.vocab;
     normed_input(g, ctx->l_norm);
-    g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, proj(g)); }
+    g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, proj(g, ctx->l_heads)); }
   { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = f.vocab; am.batch = B;   // token, output list, n_gen++ and pos++ on the device
     for (int b = 0; b < B; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.ngen_ptrs[b] = sqs[b]->d_ngen; am.pos_ptrs[b] = sqs[b]->d_pos; }
     RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(am, st)); }
@@ -750,25 +757,41 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
     // is baked in): 288 GB of HBM pay for the second copy of the LLM -- the prefill GEMM keeps the row-major one
     for (void* p : ctx->dw_allocs) if (p) hipFree(p);
     ctx->dw_allocs.clear();
+    ctx->fp8 = false;
+    if (f.decode_fp8) {
+      if (!ctx->decode_mfma || Hd % 512 || I % 512 || (f.heads * Dr) % 512)
+        return fail(ctx, GVL_ERR_ARG, "cfg.decode_fp8 needs hidden, inter and heads*head_dim to be multiples of 512 (skinny-GEMM decode path)");
+      ctx->fp8 = true;
+    }
     if (ctx->decode_mfma) {
-      auto tiled = [&](const bf16_t* W, int N, int K, int dr, int nqk, const bf16_t** out) -> int {
+      // bf16: a re-tiled copy.  FP8: per-row scales + the e4m3 tile copy, and the row-major weight is replaced by its de-quantised values
+      auto tiled = [&](const bf16_t* W, int N, int K, int dr, int nqk, const bf16_t** out, const float** sc_out) -> int {
         void* p = nullptr;
-        const size_t bytes = (size_t)((N + 15) / 16) * 16 * K * 2;
+        const size_t bytes = (size_t)((N + 15) / 16) * 16 * K * (ctx->fp8 ? 1 : 2);
         if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, GVL_ERR_OOM, "hipMalloc(decode weight copy) failed"); }
         ctx->dw_allocs.push_back(p);
-        if (gvl_retile_decode_weight(W, (bf16_t*)p, N, K, dr, nqk, nullptr)) return fail(ctx, GVL_ERR_HIP, "retile launch failed");
         *out = (const bf16_t*)p;
+        if (ctx->fp8) {
+          void* sc = nullptr;
+          if (hipMalloc(&sc, (size_t)N * 4) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, GVL_ERR_OOM, "hipMalloc(fp8 scales) failed"); }
+          ctx->dw_allocs.push_back(sc);
+          *sc_out = (const float*)sc;
+          if (gvl_fp8_quantise_decode_weight(const_cast<bf16_t*>(W), (unsigned char*)p, (float*)sc, N, K, dr, nqk, nullptr)) return fail(ctx, GVL_ERR_HIP, "fp8 quantise launch failed");
+        } else {
+          *sc_out = nullptr;
+          if (gvl_retile_decode_weight(W, (bf16_t*)p, N, K, dr, nqk, nullptr)) return fail(ctx, GVL_ERR_HIP, "retile launch failed");
+        }
         return 0;
       };
       for (int l = 0; l < f.layers; ++l) {
         LlmLayerW& w = ctx->ll[l];
-        int rc = tiled(w.qkvw, qkvw, Hd, Dr, f.heads + f.kv_heads, &w.qkvd);
-        if (!rc) rc = tiled(w.ow, Hd, f.heads * Dr, 0, 0, &w.od);
-        if (!rc) rc = tiled(w.guw, 2 * I, Hd, 0, 0, &w.gud);
-        if (!rc) rc = tiled(w.downw, Hd, I, 0, 0, &w.downd);
+        int rc = tiled(w.qkvw, qkvw, Hd, Dr, f.heads + f.kv_heads, &w.qkvd, &w.qkvs);
+        if (!rc) rc = tiled(w.ow, Hd, f.heads * Dr, 0, 0, &w.od, &w.os);
+        if (!rc) rc = tiled(w.guw, 2 * I, Hd, 0, 0, &w.gud, &w.gus);
+        if (!rc) rc = tiled(w.downw, Hd, I, 0, 0, &w.downd, &w.downs);
         if (rc) return rc;
       }
-      { const int rc = tiled(ctx->l_headw, f.vocab, Hd, 0, 0, &ctx->l_headd); if (rc) return rc; }
+      { const int rc = tiled(ctx->l_headw, f.vocab, Hd, 0, 0, &ctx->l_headd, &ctx->l_heads); if (rc) return rc; }
       HIPCHK(ctx, hipDeviceSynchronize());
     }
   }

@@ -29,7 +29,7 @@ class GvlConfig(C.Structure):
         ("vocab", C.c_int32),
         ("rms_eps", C.c_float),
         ("lm_head_bias", C.c_int32), ("rope_orig_max_pos", C.c_int32), ("max_seq", C.c_int32),
-        ("max_segs", C.c_int32), ("kv_pages", C.c_int32), ("max_prefill", C.c_int32),
+        ("max_segs", C.c_int32), ("kv_pages", C.c_int32), ("max_prefill", C.c_int32), ("decode_fp8", C.c_int32),
     ]
 
 

@@ -777,3 +777,32 @@ def synthetic_frame(name: str, h: int, w: int) -> np.ndarray:
     yy, xx = np.mgrid[0:h, 0:w]
     base = np.stack([127 + 120 * np.sin(xx / 7.0 + c) * np.cos(yy / 11.0 - c) for c in range(3)], -1)
     return np.clip(base + rs.randint(-90, 91, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------------------
+# f3 -- FP8 weight variant (no reference counterpart: SURVEY §8 f3 lists it as a tooling option).  The library quantises every
+# decoder projection and lm_head to OCP e4m3 with a per-row POWER-OF-TWO scale and evaluates the model whose weights are the
+# de-quantised values; this restates that quantiser so the tests can run the ordinary oracle forward on W_q.
+# --------------------------------------------------------------------------------------
+_FP8_PROJ = ("qkv_proj", "o_proj", "gate_up_proj", "down_proj", "q_proj", "k_proj", "v_proj", "gate_proj", "up_proj")
+
+
+def fp8_pow2_dequant(w: torch.Tensor) -> torch.Tensor:
+    """w [N, K] (bf16 values) -> fp8_e4m3(w / s) * s with s = smallest power of two >= max|row| / 448 (exact in bf16)."""
+    w = w.to(torch.bfloat16).float()
+    amax = w.abs().amax(dim=1, keepdim=True)
+    m, e = torch.frexp(amax / 448.0)                        # amax / 448 = m * 2^e, m in [0.5, 1)
+    e = torch.where(m == 0.5, e - 1, e)
+    s = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), e), torch.ones_like(amax))
+    return (w / s).to(torch.float8_e4m3fn).float() * s
+
+
+def fp8_weight_model(W: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """State dict of the FP8-variant model: decoder projections and lm_head.weight de-quantised, everything else untouched."""
+    out = {}
+    for k, v in W.items():
+        if k == "lm_head.weight" or (k.endswith(".weight") and any(k.endswith(p + ".weight") for p in _FP8_PROJ)):
+            out[k] = fp8_pow2_dequant(v)
+        else:
+            out[k] = v
+    return out

@@ -452,3 +452,60 @@ def test_decode_groups_up_to_16_are_bit_identical_to_single_at_full_width():
         assert torch.equal(eng.decode_step_logits(s, 7), lg)
         eng.seq_free(s)
     eng.close()
+
+
+def test_fp8_weight_variant_matches_the_dequantised_model():
+    """SURVEY §8 f3 'FP8 weight variants' (opt-in, cfg.decode_fp8): every decoder projection and lm_head is quantised on the device to
+    OCP e4m3 with a per-row power-of-two scale; decode streams the FP8 tile copy (half the bytes), prefill uses the de-quantised
+    bf16 values -- ONE model.  Checked against the ordinary oracle forward on W_q = oracle.fp8_weight_model(W): prefill logits,
+    teacher-forced decode steps through the FP8 stream, and greedy ids; and the quantisation must actually change the logits."""
+    c = dict(hidden=512, inter=1024, layers=2, heads=8, kv_heads=8, vocab=640)
+    geo = _phi_geo(c, max_seq=256, max_prefill=128, kv_pages=8)
+    geo.decode_fp8 = True
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.fp8")
+    eng = llm_engine(geo, W)
+    Wq = O.fp8_weight_model(W)
+    ocfg = _ocfg(geo)
+    x = synth.det_tensor("t.fp8.x", (40, c["hidden"]), 0.5)
+    seq = eng.seq_alloc(64)
+    got = eng.prefill(seq, x.to(DEV).to(bf), want_logits=True).clone()
+    cache, cache32 = [None] * geo.layers, [None] * geo.layers
+    ref_emu = O.llm_forward(ocfg, Wq, x, True, cache, 0, last_only=True)[0]
+    ref32 = O.llm_forward(ocfg, Wq, x, False, cache32, 0, last_only=True)[0]
+    base32 = O.llm_forward(ocfg, W, x, False, None, 0, last_only=True)[0]
+    scale = float(ref32.abs().max())
+    qerr = float((ref32 - base32).abs().max()) / scale
+    print(f"[parity] FP8 variant: quantisation itself moves the logits by {qerr:.2e} of the scale")
+    assert qerr > 2e-2, "the FP8 quantiser does not change this model: the test would prove nothing"
+    check_bf16_class(got, ref32, ref_emu, 1e-2, "FP8 variant: prefill logits (de-quantised bf16 weights) vs oracle on W_q (fp32)")
+    e = Wq["model.embed_tokens.weight"].to(bf).float()
+    n = x.shape[0]
+    for step, tok in enumerate((5, 77, 300, 12)):
+        lg = eng.decode_step_logits(seq, tok)
+        r_emu = O.llm_forward(ocfg, Wq, e[tok][None], True, cache, n, last_only=True)[0]
+        r32 = O.llm_forward(ocfg, Wq, e[tok][None], False, cache32, n, last_only=True)[0]
+        n += 1
+        check_bf16_class(lg, r32, r_emu, 1e-2, f"FP8 variant: decode step {step} (FP8 weight stream) vs oracle on W_q (fp32)")
+    eng.seq_free(seq)
+    ids = eng.generate_ids(x.to(DEV).to(bf), 8, None)
+    ref_ids, margins = O.greedy_generate(ocfg, Wq, x.to(bf).float(), 8, None, emu=True, return_margins=True)
+    for i, (a, b) in enumerate(zip(ids, ref_ids)):
+        if a != b:
+            assert margins[i] < 2e-2 * scale, f"FP8 variant: greedy id differs at step {i} with margin {margins[i]}"
+            break
+    # groups share the FP8 stream exactly like the bf16 one: bit-identical to single decode
+    embs = [x.to(DEV).to(bf), x[:17].to(DEV).to(bf), x[3:36].to(DEV).to(bf)]
+    single = [eng.generate_ids(em, 6, None) for em in embs]
+    seqs = [eng.seq_alloc(em.shape[0] + 8) for em in embs]
+    for s_, em in zip(seqs, embs):
+        eng.prefill(s_, em)
+    assert eng.decode_greedy_batch(seqs, 6, None) == single
+    for s_ in seqs:
+        eng.seq_free(s_)
+    eng.close()
+    # a geometry the FP8 tile copy cannot serve is refused, not silently run in bf16
+    g2 = _phi_geo(dict(hidden=256, inter=512, layers=1, heads=4, kv_heads=4, vocab=64), max_seq=128, max_prefill=64, kv_pages=4)
+    g2.decode_fp8 = True
+    W2 = synth.llm_weights("phi3", 256, 512, 1, 4, 4, 64, True, seed="t.fp8.b")
+    with pytest.raises(E.L.GvlError, match="multiples of 512"):
+        llm_engine(g2, W2)

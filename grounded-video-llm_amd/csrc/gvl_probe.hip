@@ -1,0 +1,66 @@
+// gvl_probe.hip -- measurement only: how fast can this MI355X issue bf16 MFMAs at all?  A register-only kernel (no LDS, no global
+// traffic inside the loop) keeps every SIMD's matrix pipe 100 % busy with v_mfma_f32_32x32x16_bf16 on ZERO, CONSTANT or RANDOM operands
+// and reports TFLOP/s and the sustained shader clock (s_memtime ticks / wall time).  It separates "the kernel leaves the pipe idle"
+// from "the part cannot clock higher at this switching activity" when a GEMM's fraction of the 2.5 PFLOP/s figure is judged
+// (profiles/r02_mfma_peak_probe.txt; tools/mfma_probe.py).
+#include "gvl_internal.h"
+#include <cstring>
+
+__global__ __launch_bounds__(256) void mfma_probe_kernel(const bf16x8_t* __restrict__ ops, float* __restrict__ sink, unsigned long long* __restrict__ ticks, int iters) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bf16x8_t a = ops[lane], b = ops[64 + lane];
+  f32x16_t acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);   // 4 independent accumulator chains
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += acc[j][e];
+  if (s == 123456.789f) sink[0] = s;                    // keeps the chains alive
+  if (lane == 0) ticks[blockIdx.x * 4 + wave] = t1 - t0;
+}
+
+// mode 0: zero operands, 1: constant 1.0, 2: random bf16 in [-1, 1).  waves_per_simd 1 or 2.
+extern "C" int gvl_probe_mfma(int mode, int waves_per_simd, int iters, double* tflops, double* ghz, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipDeviceProp_t p; int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || hipGetDeviceProperties(&p, d) != hipSuccess) return -3;
+  const int blocks = p.multiProcessorCount * (waves_per_simd == 2 ? 2 : 1);
+  unsigned short h[128 * 8];
+  unsigned x = 12345u;
+  for (int i = 0; i < 128 * 8; ++i) {
+    x = x * 1664525u + 1013904223u;
+    const float f = mode == 0 ? 0.f : (mode == 1 ? 1.f : ((x >> 8) * (1.0f / 8388608.0f) - 1.0f));
+    unsigned u; memcpy(&u, &f, 4);
+    h[i] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  }
+  void *ops = nullptr, *sink = nullptr, *ticks = nullptr;
+  if (hipMalloc(&ops, sizeof(h)) != hipSuccess || hipMalloc(&sink, 64) != hipSuccess || hipMalloc(&ticks, (size_t)blocks * 4 * 8) != hipSuccess) return -3;
+  hipMemcpy(ops, h, sizeof(h), hipMemcpyHostToDevice);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, (const bf16x8_t*)ops, (float*)sink, (unsigned long long*)ticks, iters / 8 + 1);   // warm-up
+  hipEventRecord(e0, st);
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, (const bf16x8_t*)ops, (float*)sink, (unsigned long long*)ticks, iters);
+  hipEventRecord(e1, st);
+  hipStreamSynchronize(st);
+  float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long* ht = new unsigned long long[(size_t)blocks * 4];
+  hipMemcpy(ht, ticks, (size_t)blocks * 4 * 8, hipMemcpyDeviceToHost);
+  double tsum = 0; for (int i = 0; i < blocks * 4; ++i) tsum += (double)ht[i];
+  delete[] ht;
+  hipEventDestroy(e0); hipEventDestroy(e1); hipFree(ops); hipFree(sink); hipFree(ticks);
+  const double flop = (double)blocks * 4 * (double)iters * 4 * 32768.0;
+  if (tflops) *tflops = flop / (ms * 1e-3) / 1e12;
+  // s_memtime runs at a fixed 100 MHz on this part if it does not track the shader clock; report ticks per microsecond of wall time
+  if (ghz) *ghz = tsum / (blocks * 4) / (ms * 1e3) / 1e3;
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}

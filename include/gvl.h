@@ -227,6 +227,11 @@ int gvl_op_dgemm(gvl_ctx* ctx, const uint16_t* W, const uint16_t* x, const float
 int gvl_op_decode_bench(gvl_ctx* ctx, int N, int K, int batch, int mode, int variant, int rounds, int iters, double* us_per_launch,
                         void* stream);
 
+/* measurement only (tools/mfma_probe.py): a register-only kernel that keeps every matrix pipe 100 % busy with
+ * v_mfma_f32_32x32x16_bf16 -- mode 0 zero / 1 constant / 2 random operands -- and reports TFLOP/s and s_memtime ticks per ns of wall
+ * time: the ceiling the power envelope leaves a PERFECT bf16 GEMM at a given switching activity.  Needs no ctx. */
+int gvl_probe_mfma(int mode, int waves_per_simd, int iters, double* tflops, double* ghz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

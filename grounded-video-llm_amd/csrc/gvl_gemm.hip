@@ -340,7 +340,11 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x16_t
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAG, int EPI, int STG = 0>
+// NS = LDS ring slots.  2: k-tile t+1 is requested while t is consumed (compiler-tracked DMA).  3: TWO k-tiles ahead, DMA issued from
+// inline asm with the waits counted by hand (`s_waitcnt vmcnt(NI)` leaves the newest tile in flight): for the planner's remainder /
+// tail launches (a few hundred small tiles, <= 2 blocks per CU) the k loop is bound by the DMA round trip, not by MFMA issue --
+// 96 k-tiles x ~0.95 us on InternVideo2's fc2 tail; the per-element k order, hence every output bit, is unchanged.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAG, int EPI, int STG = 0, int NS = 2>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
   constexpr int NWAVES = WAVES_M * WAVES_N;
   constexpr int NT = NWAVES * 64;
@@ -417,6 +421,40 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
   const int a_row_off = BN * 128 + (wm * TM + l31) * 128;
 
   const int nk = a.K / BK;
+  auto compute = [&](const char* sb, int kk) {
+    const int coff = ((kk * 2 + h) ^ swz) << 4;
+    bf16x8_t wf[NB], af[MB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
+#pragma unroll
+    for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+  };
+  if constexpr (NS == 3) {
+    const unsigned smem_u = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    auto stage3 = [&](int slot, int k0) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) glds16(src[i] + k0, smem_u + slot * STAGE_BYTES + (i * NWAVES + wave) * 1024);
+    };
+    stage3(0, 0);
+    if (nk > 1) stage3(1, BK);
+    int slot = 0;
+    for (int t = 0; t < nk; ++t) {
+      // outstanding DMA groups: tile t and (if it exists) tile t+1 -- vmcnt retires in order, so NI leaves exactly the newer one
+      if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                        // tile t is in LDS for everybody; everybody is done reading tile t-1, whose slot is refilled next
+      int nslot = slot + 2; nslot = nslot >= 3 ? nslot - 3 : nslot;
+      if (t + 2 < nk) stage3(nslot, (t + 2) * BK);
+      const char* sb = smem + slot * STAGE_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) compute(sb, kk);
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+  } else {
   // 2-slot LDS ring: k-tile t+1 is requested while k-tile t is consumed.  STAG = 1: the waves request it at DIFFERENT k-steps
   // (slot = f(wave)), so that on every SIMD some wave always has MFMAs to issue while another pays the ~8 x 60-cycle
   // global_load_lds issue cost; STAG = 0: everybody at the top of the iteration (baseline, cfg 1).
@@ -431,24 +469,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       if constexpr (STAG != 0) { if (kk == dma_slot && more) stage((t + 1) & 1, (t + 1) * BK); }
-      const int coff = ((kk * 2 + h) ^ swz) << 4;
-      bf16x8_t wf[NB], af[MB];
-#pragma unroll
-      for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
-#pragma unroll
-      for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
-#pragma unroll
-      for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+      compute(sb, kk);
     }
+  }
   }
 
   if constexpr (STG != 0 && EPI >= 0) {
     constexpr int STG_BYTES = 32 * ((EPI & 4) ? TN * 4 + 16 : TN * 2 + 16);
-    static_assert(NWAVES * STG_BYTES <= 2 * STAGE_BYTES, "staging does not fit the ring");
+    static_assert(NWAVES * STG_BYTES <= NS * STAGE_BYTES, "staging does not fit the ring");
     __syncthreads();                               // the other waves may still be reading the last k-tile
-    constexpr int BG_OFF = 2 * STAGE_BYTES - NWAVES * TN * 8;   // bias/gamma scratch: TN floats each per wave, top of the ring
+    constexpr int BG_OFF = NS * STAGE_BYTES - NWAVES * TN * 8;   // bias/gamma scratch: TN floats each per wave, top of the ring
     static_assert(NWAVES * STG_BYTES <= BG_OFF, "staging overlaps the bias scratch");
     u32x4_t rv[StgGeom<NB, EPI>::KI];
     gemm_epilogue_staged<MB, NB, EPI>(a, acc, smem + wave * STG_BYTES, smem + BG_OFF + wave * TN * 8, m0 + wm * TM, n0 + wn * TN, lane, rv);
@@ -720,12 +750,12 @@ static int launch_pp(const GemmArgs& a_in, hipStream_t st) {
 //  vmcnt(8) -- was built and measured 10-15 % SLOWER than gemm_pp_kernel on every hot-path shape (64-byte DMA rows fetch
 //  each 128-byte line twice); it was removed.  See DESIGN.md §3.1 and profiles/r01_gemm_microbench_pp.txt.)
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAG, int EPI = -1, int STG = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAG, int EPI = -1, int STG = 0, int NS = 2>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int LDS = 2 * (BM + BN) * 128;
+  constexpr int LDS = NS * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAG, EPI, STG>;
+  auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAG, EPI, STG, NS>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
     attr_set = true;
@@ -846,6 +876,14 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     // ONE 128x128 block (remainder rows / tail columns of the planner: 193-264 tiles on 512 slots).  Same k-order per output
     // element as every other cfg, so the results are bit-identical.
     case 22: {
+      // 3-slot ring (two k-tiles of DMA in flight, 72 KB: still 2 blocks per CU) unless GVL_GEMM_RING=2 (A/B)
+      static const int ring = [] { const char* e = getenv("GVL_GEMM_RING"); return e ? atoi(e) : 3; }();
+      if (stg_ok && ring == 3) switch (epi) {
+#define S_CASE(E) case E: return launch_cfg<64, 128, 2, 2, 1, E, 1, 3>(a, st);
+        S_CASE(0) S_CASE(32) S_CASE(33) S_CASE(34) S_CASE(3) S_CASE(44) S_CASE(56) S_CASE(8) S_CASE(4) S_CASE(36)
+#undef S_CASE
+        default: break;
+      }
       if (stg_ok) switch (epi) {
 #define S_CASE(E) case E: return launch_cfg<64, 128, 2, 2, 1, E, 1>(a, st);
         S_CASE(0) S_CASE(32) S_CASE(33) S_CASE(34) S_CASE(3) S_CASE(44) S_CASE(56) S_CASE(8) S_CASE(4) S_CASE(36)

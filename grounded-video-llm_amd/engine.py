@@ -299,7 +299,7 @@ class Engine:
         self._chk(self.lib.gvl_prefill_varlen(self.ctx, ids, n, ptrs, lens, self.stream), "gvl_prefill_varlen")
 
     def decode_greedy_batch(self, seqs: Sequence[int], max_new: int, eos_id: Optional[int]) -> List[List[int]]:
-        """Greedy decode of several freshly prefilled sequences together (weights streamed once per step per group of 4/2/1)."""
+        """Greedy decode of several freshly prefilled sequences together (weights streamed once per step per group of up to 16 sequences)."""
         n = len(seqs)
         ids = (C.c_int * n)(*[int(s) for s in seqs])
         buf = (C.c_int32 * (n * max_new))()

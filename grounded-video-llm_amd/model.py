@@ -271,7 +271,7 @@ class LLAVA_NEXT_VIDEO:
         # bs > 1 (the reference left-pads the batch, llava_next_video.py:622-647): every sample keeps its own paged KV and its
         # un-padded length -- identical maths to the masked left-padded batch.  Prefill runs over the packed rows of the batch
         # (gvl_prefill_varlen) and the greedy decode of the whole batch runs together (gvl_decode_greedy_batch: one weight stream
-        # per token for groups of 4 / 2 / 1 sequences)
+        # per token for groups of up to 16 sequences)
         # The KV pool bounds how many samples are resident at once: the batch is processed in as many groups as it takes.
         from .lib import GvlError, ERR_OOM
         out: List[List[int]] = []

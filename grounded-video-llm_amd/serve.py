@@ -8,7 +8,7 @@ lets requests join and leave between decode chunks:
   admit    queued requests take a free slot: splice -> KV pages (gvl_seq_alloc) -> ONE ragged prefill for all newcomers
            (gvl_prefill_varlen: packed rows through the decoder GEMMs)
   decode   every active sequence advances `chunk` tokens (gvl_decode_steps: members at different generation steps share
-           one weight stream per step in groups of 4 / 2 / 1)
+           one weight stream per step in groups of up to 16)
   retire   ids are read back (gvl_seq_read), sequences that produced eos / reached max_new free their pages at once
 
 All arithmetic is per sequence and batch-invariant, so the ids equal `Engine.generate_ids` of each request on its own

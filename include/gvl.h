@@ -141,14 +141,15 @@ int gvl_prefill_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, const uint16
                       void* stream);
 /* Batched greedy decode of n_seqs freshly prefilled sequences (the reference batches clips in generate() with
  * left padding, llava_next_video.py:622-647 -- here every sequence keeps its own pages and length, no padding).  Groups of
- * 4 / 2 / 1 sequences advance together: every weight matrix is streamed ONCE per step for the whole group, so the HBM cost per
+ * up to 16 sequences advance together (skinny MFMA GEMM, gvl_decode.hip; 4 / 2 / 1 on the VALU fallback for K % 256 != 0
+ * geometries): every weight matrix is streamed ONCE per step for the whole group, so the HBM cost per
  * sequence falls as 1/group; the per-sequence arithmetic (and therefore the ids) is bit-identical to gvl_decode_greedy.
  * out_ids_host int32 [n_seqs][max_new]; n_out [n_seqs].  A group runs until all of its members hit eos / max_new. */
 int gvl_decode_greedy_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, int max_new, int eos_id,
                             int32_t* out_ids_host, int* n_out, void* stream);
 /* Continuous batching: the two calls a scheduler needs besides prefill / seq_alloc / seq_free.
  * gvl_decode_steps advances every listed sequence by n_steps greedy tokens -- the sequences may be at DIFFERENT generation
- * steps (joined at different times); groups of 4 / 2 / 1 share one weight stream per step; asynchronous on `stream`, no eos
+ * steps (joined at different times); groups of up to 16 share one weight stream per step; asynchronous on `stream`, no eos
  * test (the host inspects the ids between chunks; tokens after an eos are discarded by the caller).
  * gvl_seq_read copies the ids generated so far, from index `first`, to the host (at most cap), reports the total count in
  * *n_gen and synchronises `stream`.  Free a sequence only after a gvl_seq_read / stream synchronise that follows its last step. */

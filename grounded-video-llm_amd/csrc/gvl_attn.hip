@@ -285,7 +285,15 @@ int gvl_launch_attention(const AttnArgs& a, hipStream_t st) {
 // =====================================================================================================
 // decode attention: one new query per head against the paged cache, split over the context
 // =====================================================================================================
-template <int D>
+// One block per (query head, context split, sequence).  Grouped-query attention (Llama-3: 32 query heads on 8 KV heads): the G = H / KV
+// heads of a group read the SAME pages.  Round 1 launched grid (H, nsplit, batch): consecutive query heads are consecutive workgroup
+// ids, which the dispatcher deals round-robin over the 8 XCDs -- the 4 heads of a group landed on 4 different L2s and every page crossed
+// the fabric 4 times (Llama-3-8B, 16 sequences at 3.5 k context: 0.33 of the HBM roofline, profiles/r02_other_configs.txt).
+// PH = 1: XCD-aware grid (8, ceil(units / 8) * G): unit (KV head, split, sequence) = (y / G) * 8 + x, head = KV head * G + y % G -- the G
+// blocks of a unit share x, i.e. ONE XCD's L2, and are dispatched 8 ids apart (their misses merge); the pages are then read with plain
+// (L2-allocating) loads instead of non-temporal ones.  (A variant with ONE block per KV head looping over its G query heads keeps the
+// page in registers but needs 256+ VGPRs at D = 128 -- hipcc spilled 401 of them; dropped.)  G stays 1 in both modes.
+template <int D, int G, int PH = 0>
 __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArgs a) {
   constexpr int CPR = D / 8;       // 16-byte chunks per key row
   constexpr int NIT = D / 8;       // 64*CPR chunks per page / 64 lanes
@@ -293,12 +301,20 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
   static_assert(D == 64 || D == 96 || D == 128, "head dim");
   __shared__ __attribute__((aligned(16))) float part_s[4][64 * (CPR + 1)];   // +1: conflict-free per-key reads
   __shared__ __attribute__((aligned(16))) float p_s[4][64];
-  __shared__ float red_s[4][D + 2];
+  __shared__ float red_s[G][4][D + 2];
   __shared__ int last_s;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int head = blockIdx.x, split = blockIdx.y, bz = blockIdx.z;   // bz: sequence of the decode batch
-  const int hkv = head / (a.H / a.KV);
+  int split = blockIdx.y, bz = blockIdx.z;                            // bz: sequence of the decode batch
+  int hkv = blockIdx.x, head0 = hkv * G;
+  if constexpr (PH == 2) { head0 = blockIdx.x; hkv = head0 / (a.H / a.KV); }
+  if constexpr (PH == 1) {
+    const int Gq = a.H / a.KV, units = a.KV * a.nsplit * a.batch;
+    const int unit = ((int)blockIdx.y / Gq) * 8 + (int)blockIdx.x;
+    if (unit >= units) return;
+    hkv = unit % a.KV; split = (unit / a.KV) % a.nsplit; bz = unit / (a.KV * a.nsplit);
+    head0 = hkv * Gq + (int)blockIdx.y % Gq;
+  }
   const int* __restrict__ block_table = a.tables[bz];
   const bf16_t* qb = a.q + (size_t)bz * a.q_stride;
   float* part_b = a.part + (size_t)bz * a.H * a.nsplit * (D + 2);
@@ -310,15 +326,21 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
   int p_end = p_begin + pps; if (p_end > npages) p_end = npages;
 
   // the lane's q chunks (chunk index (it*64+lane) % CPR): 16-byte L2 hits, no LDS staging / block barrier
-  u32x4_t qv[QP];
+  u32x4_t qv[G][QP];
 #pragma unroll
-  for (int it = 0; it < QP; ++it) qv[it] = *(const u32x4_t*)(qb + head * D + ((it * 64 + lane) % CPR) * 8);
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int it = 0; it < QP; ++it) qv[g][it] = *(const u32x4_t*)(qb + (head0 + g) * D + ((it * 64 + lane) % CPR) * 8);
 
   const float sc = a.scale * 1.4426950408889634f;
-  float m_run = -1e30f, l_run = 0.f;
-  float oacc[NIT];
+  float m_run[G], l_run[G];
+  float oacc[G][NIT];
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) oacc[i] = 0.f;
+  for (int g = 0; g < G; ++g) {
+    m_run[g] = -1e30f; l_run[g] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) oacc[g][i] = 0.f;
+  }
 
   for (int pg = p_begin + wave; pg < p_end; pg += 4) {
     const size_t pb = ((size_t)block_table[pg] * a.KV + hkv) * (size_t)(64 * D);
@@ -327,100 +349,121 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
     // the whole page (K and V^T) is requested up front: 2*NIT fully coalesced 16-byte loads in flight per lane
     u32x4_t kv[NIT], vv[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) kv[it] = __builtin_nontemporal_load((const u32x4_t*)(kp + (it * 64 + lane) * 8));
+    for (int it = 0; it < NIT; ++it) kv[it] = PH == 1 ? *(const u32x4_t*)(kp + (it * 64 + lane) * 8) : __builtin_nontemporal_load((const u32x4_t*)(kp + (it * 64 + lane) * 8));
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) vv[it] = __builtin_nontemporal_load((const u32x4_t*)(vp + (it * 64 + lane) * 8));
+    for (int it = 0; it < NIT; ++it) vv[it] = PH == 1 ? *(const u32x4_t*)(vp + (it * 64 + lane) * 8) : __builtin_nontemporal_load((const u32x4_t*)(vp + (it * 64 + lane) * 8));
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int c = it * 64 + lane;
-      float acc = 0.f;
+    for (int g = 0; g < G; ++g) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc += lo_bf(kv[it][e]) * lo_bf(qv[it % QP][e]) + hi_bf(kv[it][e]) * hi_bf(qv[it % QP][e]);
-      part_s[wave][c + c / CPR] = acc;              // key*(CPR+1) + chunk
+      for (int it = 0; it < NIT; ++it) {
+        const int c = it * 64 + lane;
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += lo_bf(kv[it][e]) * lo_bf(qv[g][it % QP][e]) + hi_bf(kv[it][e]) * hi_bf(qv[g][it % QP][e]);
+        part_s[wave][c + c / CPR] = acc;              // key*(CPR+1) + chunk
+      }
+      __builtin_amdgcn_wave_barrier();
+      float sv = 0.f;
+#pragma unroll
+      for (int i = 0; i < CPR; ++i) sv += part_s[wave][lane * (CPR + 1) + i];
+      sv *= sc;
+      if (pg * 64 + lane >= pos) sv = -1e30f;
+      const float mx = wave_max(sv);
+      const float m_new = fmaxf(m_run[g], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
+      m_run[g] = m_new;
+      const float p = __builtin_amdgcn_exp2f(sv - m_new);
+      l_run[g] = l_run[g] * alpha + wave_sum(p);
+      p_s[wave][lane] = rbf(p);                       // the reference multiplies bf16 probabilities into V
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = it * 64 + lane;                 // chunk of V^T: d = c/8, keys 8*(c%8)..+7
+        const float* pp = p_s[wave] + (c & 7) * 8;
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += lo_bf(vv[it][e]) * pp[2 * e] + hi_bf(vv[it][e]) * pp[2 * e + 1];
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        oacc[g][it] = oacc[g][it] * alpha + acc;      // d = it*8 + lane/8 (same value in the 8 lanes)
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
-    float sv = 0.f;
-#pragma unroll
-    for (int i = 0; i < CPR; ++i) sv += part_s[wave][lane * (CPR + 1) + i];
-    sv *= sc;
-    if (pg * 64 + lane >= pos) sv = -1e30f;
-    const float mx = wave_max(sv);
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    const float p = __builtin_amdgcn_exp2f(sv - m_new);
-    l_run = l_run * alpha + wave_sum(p);
-    p_s[wave][lane] = rbf(p);                       // the reference multiplies bf16 probabilities into V
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int c = it * 64 + lane;                 // chunk of V^T: d = c/8, keys 8*(c%8)..+7
-      const float* pp = p_s[wave] + (c & 7) * 8;
-      float acc = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc += lo_bf(vv[it][e]) * pp[2 * e] + hi_bf(vv[it][e]) * pp[2 * e + 1];
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      acc += __shfl_xor(acc, 4, 64);
-      oacc[it] = oacc[it] * alpha + acc;            // d = it*8 + lane/8 (same value in the 8 lanes)
-    }
-    __builtin_amdgcn_wave_barrier();
   }
   // combine the 4 waves of this block
-  if ((lane & 7) == 0) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) red_s[wave][it * 8 + (lane >> 3)] = oacc[it];
+  for (int g = 0; g < G; ++g) {
+    if ((lane & 7) == 0) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) red_s[g][wave][it * 8 + (lane >> 3)] = oacc[g][it];
+    }
+    if (lane == 0) { red_s[g][wave][D] = m_run[g]; red_s[g][wave][D + 1] = l_run[g]; }
   }
-  if (lane == 0) { red_s[wave][D] = m_run; red_s[wave][D + 1] = l_run; }
   __syncthreads();
-  // ---- publish this block's partial with write-through (sc1) stores, take a ticket; the last block of the head
+  // ---- publish this block's partials with write-through (sc1) stores, take a ticket; the last block of the KV group
   //      merges the partials reading them with sc1 loads (bypass the stale L1): no release/acquire fences needed
   //      (guide G16 recipe R1; placement independent) ---------------------------------------------------------
-  float* outp = part_b + ((size_t)head * a.nsplit + split) * (D + 2);
-  const float mm = fmaxf(fmaxf(red_s[0][D], red_s[1][D]), fmaxf(red_s[2][D], red_s[3][D]));
-  if (tid < D) {
-    float acc = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) acc += red_s[w][tid] * __builtin_amdgcn_exp2f(red_s[w][D] - mm);
-    __hip_atomic_store(outp + tid, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (tid == 0) {
-    float l = 0.f;
+  for (int g = 0; g < G; ++g) {
+    float* outp = part_b + ((size_t)(head0 + g) * a.nsplit + split) * (D + 2);
+    const float mm = fmaxf(fmaxf(red_s[g][0][D], red_s[g][1][D]), fmaxf(red_s[g][2][D], red_s[g][3][D]));
+    if (tid < D) {
+      float acc = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) l += red_s[w][D + 1] * __builtin_amdgcn_exp2f(red_s[w][D] - mm);
-    __hip_atomic_store(outp + D, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(outp + D + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int w = 0; w < 4; ++w) acc += red_s[g][w][tid] * __builtin_amdgcn_exp2f(red_s[g][w][D] - mm);
+      __hip_atomic_store(outp + tid, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+      float l = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) l += red_s[g][w][D + 1] * __builtin_amdgcn_exp2f(red_s[g][w][D] - mm);
+      __hip_atomic_store(outp + D, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(outp + D + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores
   __syncthreads();
   if (tid == 0) {
-    const int t = __hip_atomic_fetch_add(counters_b + head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int t = __hip_atomic_fetch_add(counters_b + head0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_s = (t == a.nsplit - 1);
   }
   __syncthreads();
   if (!last_s) return;
-  // one round trip: every thread fetches its share of the nsplit*(D+2) partial words (sc1 loads, all independent)
+  // one round trip per head: every thread fetches its share of the nsplit*(D+2) partial words (sc1 loads, all independent)
   // into LDS (the score scratch is free by now), then the merge runs out of LDS
-  const float* pp = part_b + (size_t)head * a.nsplit * (D + 2);
   float* mg = &part_s[0][0];
   const int nword = a.nsplit * (D + 2);
-  for (int i = tid; i < nword; i += 256) mg[i] = __hip_atomic_load(pp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  float gm = -1e30f;
-  for (int s2 = 0; s2 < a.nsplit; ++s2) gm = fmaxf(gm, mg[s2 * (D + 2) + D]);
-  float l = 0.f, acc = 0.f;
-  for (int s2 = 0; s2 < a.nsplit; ++s2) {
-    const float w = __builtin_amdgcn_exp2f(mg[s2 * (D + 2) + D] - gm);
-    l += mg[s2 * (D + 2) + D + 1] * w;
-    if (tid < D) acc += mg[s2 * (D + 2) + tid] * w;
+  for (int g = 0; g < G; ++g) {
+    const int head = head0 + g;
+    const float* pp = part_b + (size_t)head * a.nsplit * (D + 2);
+    for (int i = tid; i < nword; i += 256) mg[i] = __hip_atomic_load(pp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    float gm = -1e30f;
+    for (int s2 = 0; s2 < a.nsplit; ++s2) gm = fmaxf(gm, mg[s2 * (D + 2) + D]);
+    float l = 0.f, acc = 0.f;
+    for (int s2 = 0; s2 < a.nsplit; ++s2) {
+      const float w = __builtin_amdgcn_exp2f(mg[s2 * (D + 2) + D] - gm);
+      l += mg[s2 * (D + 2) + D + 1] * w;
+      if (tid < D) acc += mg[s2 * (D + 2) + tid] * w;
+    }
+    if (tid < a.Dout) a.out[a.out_tiled ? gvl_xt_index(bz, head * a.Dout + tid) : (size_t)bz * a.out_stride + head * a.Dout + tid] = f2bf(acc / l);
+    __syncthreads();                                  // mg is refilled for the next head of the group
   }
-  if (tid < a.Dout) a.out[a.out_tiled ? gvl_xt_index(bz, head * a.Dout + tid) : (size_t)bz * a.out_stride + head * a.Dout + tid] = f2bf(acc / l);
-  if (tid == 0) __hip_atomic_store(counters_b + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+  if (tid == 0) __hip_atomic_store(counters_b + head0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
 }
 
 template <int D>
-static int launch_decode(const DecodeAttnArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(decode_attn_kernel<D>, dim3(a.H, a.nsplit, a.batch), dim3(256), 0, st, a);
+static int launch_decode_g(const DecodeAttnArgs& a, hipStream_t st) {
+  static const bool no_gqa = getenv("GVL_DECODE_ATTN_NOGQA") != nullptr;      // A/B: the round-1 grid for GQA models
+  const int G = a.H / a.KV;
+  if (G == 1 || no_gqa) {
+    if (G == 1) hipLaunchKernelGGL((decode_attn_kernel<D, 1, 0>), dim3(a.H, a.nsplit, a.batch), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((decode_attn_kernel<D, 1, 2>), dim3(a.H, a.nsplit, a.batch), dim3(256), 0, st, a);
+  } else {
+    const int units = a.KV * a.nsplit * a.batch;
+    hipLaunchKernelGGL((decode_attn_kernel<D, 1, 1>), dim3(8, (units + 7) / 8 * G), dim3(256), 0, st, a);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -428,10 +471,11 @@ int gvl_launch_decode_attention(const DecodeAttnArgs& a_in, hipStream_t st) {
   DecodeAttnArgs a = a_in;
   if (a.batch <= 0) a.batch = 1;
   if (a.batch > GVL_MAX_DECODE_BATCH) return -1;
+  if (a.H % a.KV) return -1;
   switch (a.D) {
-    case 64: return launch_decode<64>(a, st);
-    case 96: return launch_decode<96>(a, st);
-    case 128: return launch_decode<128>(a, st);
+    case 64: return launch_decode_g<64>(a, st);
+    case 96: return launch_decode_g<96>(a, st);
+    case 128: return launch_decode_g<128>(a, st);
     default: return -1;
   }
 }

@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgvl.so")
-SOURCES = ["gvl_gemm.hip", "gvl_attn.hip", "gvl_elem.hip", "gvl_decode.hip", "gvl_model.hip", "gvl_pre.hip", "gvl_probe.hip"]
-HEADERS = ["gvl_internal.h", os.path.join("..", "..", "include", "gvl.h")]
+SOURCES = ["gvl_gemm.hip", "gvl_attn.hip", "gvl_elem.hip", "gvl_decode.hip", "gvl_model.hip", "gvl_host.hip", "gvl_pre.hip", "gvl_probe.hip"]
+HEADERS = ["gvl_internal.h", "gvl_ctx.h", os.path.join("..", "..", "include", "gvl.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result", "-Wno-cuda-compat",
          # MFMA accumulators in VGPRs (gfx950 has a unified file): no v_accvgpr_read/write copies around the softmax / epilogue VALU
          "-mllvm", "-amdgpu-mfma-vgpr-form"]

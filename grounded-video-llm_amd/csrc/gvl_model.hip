@@ -8,107 +8,13 @@
 //   splice          models/llava_next_video.py:568-596
 //   LLM             models/modeling_phi3.py:1034-1095,1249-1383,1512-1526 / models/modeling_llama.py:699-760
 //   generate()      models/llava_next_video.py:655-661 (greedy; transformers GenerationMixin [ext])
-#include "gvl_internal.h"
-#include "../../include/gvl.h"
+#include "gvl_ctx.h"
 
-#include <dlfcn.h>
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <string>
-#include <unordered_map>
-#include <vector>
+std::string& gvl_create_error() { static std::string e; return e; }
 
 namespace {
 
-std::string g_create_err;
-
-struct Tensor { void* p = nullptr; int dtype = 0; int64_t numel = 0; std::vector<int64_t> shape; };
-
-struct ClipLayerW { const float *ln1w, *ln1b, *ln2w, *ln2b, *qkvb, *outb, *fc1b, *fc2b; const bf16_t *qkvw, *outw, *fc1w, *fc2w; };
-struct Iv2BlockW { const bf16_t *n1, *n2, *qkvw, *qn, *kn, *projw, *fc1w, *fc2w; const float *projb, *ls1, *ls2, *fc1b, *fc2b; };
-struct LlmLayerW { const bf16_t *ln1, *ln2, *qkvw, *ow, *guw, *downw;
-                   const bf16_t *qkvd, *od, *gud, *downd;      // decode copies in MFMA tile order (gvl_decode.hip; bf16, or FP8 e4m3 when cfg.decode_fp8); null on the VALU fallback
-                   const float *qkvs, *os, *gus, *downs; };    // FP8 variant: per-row power-of-two scales
-
-struct Seq {
-  bool used = false; int max_tokens = 0, n_pages = 0; std::vector<int> pages;
-  int* d_block_table = nullptr; int* d_pos = nullptr; int pos = 0; int n_gen = 0;
-  int* d_tok = nullptr;   // the sequence's latest greedy token (input of its next decode step)
-  int* d_out = nullptr;   // [outlist_cap] generated ids, index = generation step
-  int* d_ngen = nullptr;  // device copy of n_gen: where the next generated id goes (a decode step carries no host counters)
-};
-
-struct ProfRec { int cat; hipEvent_t e0, e1; double work; };
-
-}  // namespace
-
-struct gvl_ctx {
-  gvl_config cfg;
-  std::string err;
-  std::unordered_map<std::string, Tensor> w;
-  bool finalized = false;
-  // derived geometry
-  int c_P = 0, c_S = 0, c_Kp = 0, c_Dr = 0, c_D = 0;
-  int v_L = 0, v_TL = 0, v_S = 0, v_Kp = 0, v_Dr = 0, v_D = 0;
-  int l_Dr = 0, l_D = 0, tok_per_seg = 0, img_tok = 0, seg_tok = 0;
-  bool has_clip = false, has_iv2 = false, has_llm = false, has_proj = false;
-  // resolved weights
-  const bf16_t* c_patchw = nullptr; const float *c_cls = nullptr, *c_pos = nullptr, *c_prelnw = nullptr, *c_prelnb = nullptr;
-  std::vector<ClipLayerW> cl;
-  const bf16_t *v_patchw = nullptr, *v_cls = nullptr, *v_pos = nullptr; const float* v_patchb = nullptr;
-  std::vector<Iv2BlockW> vb;
-  const bf16_t *mm0w = nullptr, *mm1w = nullptr, *vp0w = nullptr, *vp1w = nullptr, *glb_gn = nullptr, *newline = nullptr;
-  const float *mm0b = nullptr, *mm1b = nullptr, *vp0b = nullptr, *vp1b = nullptr, *sub_gn = nullptr;
-  const bf16_t *l_embed = nullptr, *l_norm = nullptr, *l_headw = nullptr; const float* l_headb = nullptr;
-  const float *cos_s = nullptr, *sin_s = nullptr, *cos_l = nullptr, *sin_l = nullptr;
-  std::vector<LlmLayerW> ll;
-  // arena
-  char* arena = nullptr; size_t arena_bytes = 0, arena_off = 0;          // vision towers, glue, op-level entries
-  char* arena_l = nullptr; size_t arena_l_bytes = 0, arena_l_off = 0;    // LLM prefill (own arena: may overlap vision on another stream)
-  // KV pool
-  bf16_t *kpool = nullptr, *vpool = nullptr; size_t layer_stride = 0; std::vector<int> free_pages;
-  std::vector<Seq> seqs;
-  static constexpr int kMaxSeqs = 256;   // live sequences (slots of the device-side tables); the KV pool is the real limit
-  int* d_seq_tables = nullptr; int* d_seq_pos = nullptr; int seq_table_cap = 0;   // [kMaxSeqs][seq_table_cap], [kMaxSeqs]
-  // decode buffers
-  bf16_t *d_x = nullptr, *d_qkv = nullptr, *d_q = nullptr, *d_attn = nullptr, *d_act = nullptr;
-  bf16_t* d_xn = nullptr;            // [NB][hidden] RMS-normalised residual rows for the next projection (skinny-GEMM decode path)
-  int* d_seq_ngen = nullptr;         // [kMaxSeqs]
-  bool decode_mfma = false;          // geometry allows the skinny MFMA GEMM decode path (K % 256 == 0 for every projection)
-  const bf16_t* l_headd = nullptr;   // lm_head in tile order
-  const float* l_heads = nullptr;    // its FP8 row scales
-  bool fp8 = false;                  // the decode copies are FP8 (cfg.decode_fp8 and the geometry allows it)
-  std::vector<void*> dw_allocs;      // tile-order weight copies owned by the ctx
-  // (all decode work buffers hold GVL_MAX_DECODE_BATCH rows: one per sequence of a batched decode step)
-  float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_seq_tok = nullptr, *d_seq_out = nullptr;
-  int nsplit = 16, outlist_cap = 8192, ids_cap = 16384;
-  // frame pre-processing scratch (tmp image + tap tables), grown on demand
-  void* pre_scratch = nullptr; size_t pre_scratch_bytes = 0;
-  int kv_total_pages = 0;
-  // RCCL communicator owned by the ctx (gvl_comm_init); the library is dlopen'ed on first use
-  void* comm = nullptr; int comm_rank = 0, comm_world = 1;
-  // profiling
-  bool prof = false; std::vector<ProfRec> recs;
-  double prof_ms[GVL_PROF_NCAT] = {0}, prof_work[GVL_PROF_NCAT] = {0}; int64_t prof_n[GVL_PROF_NCAT] = {0};
-};
-
-namespace {
-
-int fail(gvl_ctx* c, int code, const std::string& msg) {
-  if (c) c->err = msg; else g_create_err = msg;
-  return code;
-}
-int hipfail(gvl_ctx* c, hipError_t e, const char* what) {
-  return fail(c, GVL_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
-}
-#define HIPCHK(c, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return hipfail(c, _e, #expr); } while (0)
+int fail(gvl_ctx* c, int code, const std::string& msg) { return gvl_fail(c, code, msg); }
 
 int pad_head(int dr) { return dr <= 64 ? 64 : (dr <= 96 ? 96 : (dr <= 128 ? 128 : -1)); }
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -564,7 +470,7 @@ int decode_group(gvl_ctx* ctx, Seq* const* sqs, int B, int max_new, int eos_id, 
 // =====================================================================================================
 extern "C" {
 
-const char* gvl_last_error(const gvl_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+const char* gvl_last_error(const gvl_ctx* ctx) { return ctx ? ctx->err.c_str() : gvl_create_error().c_str(); }
 
 int gvl_device_info(char* arch_out, int arch_len, int* num_cus) {
   int n = 0;
@@ -1056,166 +962,6 @@ int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, voi
   int rc = decode_step(ctx, one, 1, st);
   if (rc) return rc;
   if (logits) HIPCHK(ctx, hipMemcpyAsync(logits, ctx->d_logits, (size_t)ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
-  return 0;
-}
-
-int gvl_kv_info(const gvl_ctx* ctx, int* total_pages, int* free_pages, int64_t* pool_bytes, int* max_live_seqs) {
-  if (!ctx) return GVL_ERR_ARG;
-  if (total_pages) *total_pages = ctx->kv_total_pages;
-  if (free_pages) *free_pages = (int)ctx->free_pages.size();
-  if (pool_bytes) *pool_bytes = (int64_t)(ctx->layer_stride * ctx->cfg.layers * 2 * 2);
-  if (max_live_seqs) *max_live_seqs = gvl_ctx::kMaxSeqs;
-  return 0;
-}
-
-// ---- packed weight file (safetensors container): u64 header length, JSON header, raw little-endian tensor bytes ----------------
-namespace {
-struct StEntry { std::string name, dtype; std::vector<int64_t> shape; uint64_t b = 0, e = 0; };
-// Minimal reader for the restricted JSON a safetensors header is: {"name": {"dtype": "...", "shape": [..], "data_offsets": [b, e]}, ...,
-// "__metadata__": {"k": "v", ...}}.  Returns false on anything else.
-struct StParser {
-  const char* p; const char* end; std::string err;
-  void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
-  bool lit(char c) { ws(); if (p < end && *p == c) { ++p; return true; } return false; }
-  bool str(std::string& out) {
-    ws(); if (p >= end || *p != '"') return false; ++p; out.clear();
-    while (p < end && *p != '"') {
-      if (*p == '\\') { if (p + 1 >= end) return false; const char c = p[1]; p += 2;
-        if (c == 'u') { if (p + 4 > end) return false; out += '?'; p += 4; } else out += (c == 'n' ? '\n' : c == 't' ? '\t' : c); }
-      else out += *p++;
-    }
-    if (p >= end) return false; ++p; return true;
-  }
-  bool num(uint64_t& v) { ws(); if (p >= end || *p < '0' || *p > '9') return false; v = 0; while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (uint64_t)(*p++ - '0'); return true; }
-  bool numlist(std::vector<int64_t>& v) {
-    v.clear(); if (!lit('[')) return false; if (lit(']')) return true;
-    for (;;) { uint64_t x; if (!num(x)) return false; v.push_back((int64_t)x); if (lit(']')) return true; if (!lit(',')) return false; }
-  }
-  bool parse(std::vector<StEntry>& out, std::unordered_map<std::string, std::string>& meta) {
-    if (!lit('{')) return false; if (lit('}')) return true;
-    for (;;) {
-      std::string key; if (!str(key) || !lit(':') || !lit('{')) return false;
-      if (key == "__metadata__") {
-        if (!lit('}')) for (;;) { std::string k, v; if (!str(k) || !lit(':') || !str(v)) return false; meta[k] = v; if (lit('}')) break; if (!lit(',')) return false; }
-      } else {
-        StEntry en; en.name = key; bool have_off = false;
-        for (;;) {
-          std::string k; if (!str(k) || !lit(':')) return false;
-          if (k == "dtype") { if (!str(en.dtype)) return false; }
-          else if (k == "shape") { if (!numlist(en.shape)) return false; }
-          else if (k == "data_offsets") { std::vector<int64_t> o; if (!numlist(o) || o.size() != 2) return false; en.b = (uint64_t)o[0]; en.e = (uint64_t)o[1]; have_off = true; }
-          else return false;
-          if (lit('}')) break; if (!lit(',')) return false;
-        }
-        if (!have_off) return false;
-        out.push_back(en);
-      }
-      if (lit('}')) return true; if (!lit(',')) return false;
-    }
-  }
-};
-}  // namespace
-
-int gvl_load_packed(gvl_ctx* ctx, const char* path, int* n_loaded) {
-  if (!ctx || !path) return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: bad argument");
-  const int fd = open(path, O_RDONLY);
-  if (fd < 0) return fail(ctx, GVL_ERR_ARG, std::string("gvl_load_packed: cannot open ") + path);
-  struct stat sb;
-  if (fstat(fd, &sb) != 0 || sb.st_size < 8) { close(fd); return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: file too short"); }
-  const size_t fsize = (size_t)sb.st_size;
-  void* map = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
-  close(fd);
-  if (map == MAP_FAILED) return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: mmap failed");
-  struct Unmap { void* m; size_t n; ~Unmap() { munmap(m, n); } } unmap{map, fsize};
-  const unsigned char* base = (const unsigned char*)map;
-  uint64_t hlen = 0; for (int i = 7; i >= 0; --i) hlen = (hlen << 8) | base[i];
-  if (hlen > fsize - 8) return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: header length exceeds the file");
-  std::vector<StEntry> ents; std::unordered_map<std::string, std::string> meta;
-  StParser ps{(const char*)base + 8, (const char*)base + 8 + hlen, {}};
-  if (!ps.parse(ents, meta)) return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: malformed safetensors header");
-  if (meta["format"] != "gvl-packed-1") return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: not a gvl packed weight file (metadata format != gvl-packed-1)");
-  const unsigned char* data = base + 8 + hlen; const size_t dsize = fsize - 8 - hlen;
-  int n = 0;
-  for (const StEntry& en : ents) {
-    int dt; size_t esz;
-    if (en.dtype == "BF16") { dt = GVL_BF16; esz = 2; } else if (en.dtype == "F32") { dt = GVL_F32; esz = 4; }
-    else return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: tensor " + en.name + " has dtype " + en.dtype + " (want BF16 / F32)");
-    int64_t numel = 1; for (int64_t d : en.shape) numel *= d;
-    if (en.e < en.b || en.e > dsize || (uint64_t)numel * esz != en.e - en.b || en.shape.size() > 8) return fail(ctx, GVL_ERR_ARG, "gvl_load_packed: bad offsets / shape for " + en.name);
-    int64_t one = 1;
-    const int rc = gvl_load_weight(ctx, en.name.c_str(), data + en.b, dt, en.shape.empty() ? &one : en.shape.data(), en.shape.empty() ? 1 : (int)en.shape.size(), 0);
-    if (rc) return rc;
-    ++n;
-  }
-  if (n_loaded) *n_loaded = n;
-  return 0;
-}
-
-// ---- RCCL (dlopen'ed: libgvl.so itself links only the HIP runtime) ------------------------------------------------------------
-namespace {
-struct Rccl {
-  struct UID { char b[128]; };          // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed BY VALUE to ncclCommInitRank
-  void* h = nullptr; bool tried = false; std::string err;
-  int (*GetUniqueId)(void*) = nullptr;
-  int (*CommInitRank)(void**, int, UID, int) = nullptr;
-  int (*CommDestroy)(void*) = nullptr;
-  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
-} g_rccl;
-bool rccl_load() {
-  if (g_rccl.tried) return g_rccl.h != nullptr;
-  g_rccl.tried = true;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) { g_rccl.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rccl.h) break; }
-  if (!g_rccl.h) { g_rccl.err = std::string("dlopen(librccl) failed: ") + (dlerror() ? dlerror() : "?"); return false; }
-  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.h, "ncclGetUniqueId");
-  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.h, "ncclCommInitRank");
-  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.h, "ncclCommDestroy");
-  g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.h, "ncclAllGather");
-  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.h, "ncclGetErrorString");
-  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) { g_rccl.err = "librccl lacks a required symbol"; dlclose(g_rccl.h); g_rccl.h = nullptr; return false; }
-  return true;
-}
-std::string rccl_msg(const char* what, int rc) { return std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error") + " (" + std::to_string(rc) + ")"; }
-constexpr int kNcclBfloat16 = 9;    // ncclDataType_t, rccl.h
-}  // namespace
-
-int gvl_comm_unique_id(char id_out[128]) {
-  if (!id_out) return fail(nullptr, GVL_ERR_ARG, "gvl_comm_unique_id: null");
-  if (!rccl_load()) return fail(nullptr, GVL_ERR_STATE, g_rccl.err);
-  const int rc = g_rccl.GetUniqueId(id_out);
-  if (rc) return fail(nullptr, GVL_ERR_HIP, rccl_msg("ncclGetUniqueId", rc));
-  return 0;
-}
-int gvl_comm_init(gvl_ctx* ctx, const char id[128], int rank, int world) {
-  if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return fail(ctx, GVL_ERR_ARG, "gvl_comm_init: bad arguments");
-  if (ctx->comm) return fail(ctx, GVL_ERR_STATE, "gvl_comm_init: communicator already initialised");
-  if (!rccl_load()) return fail(ctx, GVL_ERR_STATE, g_rccl.err);
-  Rccl::UID uid; memcpy(uid.b, id, 128);
-  void* comm = nullptr;
-  const int rc = g_rccl.CommInitRank(&comm, world, uid, rank);
-  if (rc) return fail(ctx, GVL_ERR_HIP, rccl_msg("ncclCommInitRank", rc));
-  ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_world = world;
-  return 0;
-}
-int gvl_comm_destroy(gvl_ctx* ctx) {
-  if (!ctx) return GVL_ERR_ARG;
-  if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
-  ctx->comm = nullptr; ctx->comm_world = 1; ctx->comm_rank = 0;
-  return 0;
-}
-int gvl_allgather_visual(gvl_ctx* ctx, void* comm, const uint16_t* local, int rows_per_rank, int hidden, uint16_t* all, void* stream) {
-  if (!ctx || !local || !all || rows_per_rank <= 0 || hidden <= 0) return fail(ctx, GVL_ERR_ARG, "gvl_allgather_visual: bad arguments");
-  hipStream_t st = (hipStream_t)stream;
-  void* cm = comm ? comm : ctx->comm;
-  const size_t count = (size_t)rows_per_rank * hidden;
-  if (!cm) {   // no communicator: a single-rank job
-    if (local != all) HIPCHK(ctx, hipMemcpyAsync(all, local, count * 2, hipMemcpyDeviceToDevice, st));
-    return 0;
-  }
-  if (!rccl_load()) return fail(ctx, GVL_ERR_STATE, g_rccl.err);
-  const int rc = g_rccl.AllGather(local, all, count, kNcclBfloat16, cm, st);
-  if (rc) return fail(ctx, GVL_ERR_HIP, rccl_msg("ncclAllGather", rc));
   return 0;
 }
 

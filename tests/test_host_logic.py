@@ -460,3 +460,24 @@ def test_reset_embeddings_grows_a_base_language_model():
     assert G["lm_head.bias"].shape == (402,) and "lm_head.bias" not in W
     packed = Wt.pack_llm(G, "phi3", 1, 4, 4, 64, 10000.0)
     assert packed["llm.embed"].shape == (402, 64) and packed["llm.head.b"].shape == (402,)
+
+
+def test_committed_bench_line_meets_the_driver_contract():
+    """The one JSON line bench.py prints (committed copy of a default run: profiles/r02_bench_1gpu.json) carries every field the driver
+    and the tier's measurement rules ask for, with consistent values."""
+    path = os.path.join(ROOT, "profiles", "r02_bench_1gpu.json")
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "clips/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    cps = d["config"]["clips_per_step"]
+    assert abs(d["value"] - d["n_gpus"] * cps / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]       # value == whole-job clips / measured time
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 2500.0
+    assert r["traffic"] is None or "traffic_source" in r
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["oracle_ids_equal_reference_golden"] is True

@@ -21,6 +21,7 @@
 //   registers: K rows are read in a permuted order so that the 8 scores a lane holds per 16-key step
 //   are exactly the 8 k-slots the MFMA B operand wants -- no cross-lane movement of P at all).
 #include "gvl_internal.h"
+#include <cstdlib>
 
 template <int D> struct KSwz;
 template <> struct KSwz<64> {   // 128-byte rows: phys = chunk ^ ((row>>1)&7)
@@ -43,7 +44,10 @@ __device__ __forceinline__ int kperm(int i) {
   return (b >> 1) * 16 + 8 * hh + 4 * (b & 1) + c;
 }
 
-template <int D, int NWAVES, int NS>
+// ONES: the V^T pad row Dout is all ones (D = 96, Dout = 88: InternVideo2), so O^T[Dout] accumulates the softmax row sum inside the
+// P.V MFMAs the kernel issues anyway -- the 32 VALU adds per key tile of the VALU-bound loop are dropped (the sum then runs over the
+// bf16-rounded probabilities the P.V product uses, in fp32).
+template <int D, int NWAVES, int NS, int ONES = 0>
 __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int NT = NWAVES * 64;
   constexpr int DK = D / 16;          // k-steps of the QK^T contraction
@@ -204,9 +208,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
       for (int r = 0; r < 16; ++r) {
         const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, nm));
         s[kb][r] = p;
-        psum += p;
+        if constexpr (!ONES) psum += p;
       }
-    l_run = l_run * alpha + psum;
+    if constexpr (!ONES) l_run = l_run * alpha + psum;
     // ---- O^T += V^T . P^T ---------------------------------------------------------------------------
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
@@ -224,7 +228,19 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot;
+  if constexpr (ONES) {
+    // row Dout of O^T: block DB-1, local row lr = Dout - 32 (DB-1); MFMA layout row = (reg & 3) + 8 (reg >> 2) + 4 h -> held by the
+    // h = 0 lane of the query in register (lr / 8) * 4 + lr % 4 (the launcher only selects ONES when lr % 8 < 4)
+    const int lr = a.Dout - 32 * (DB - 1);
+    float mine = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mine = (e == (lr >> 3) * 4 + (lr & 3)) ? o[DB - 1][e] : mine;
+    const float other = __shfl_xor(mine, 32, 64);
+    l_tot = h ? other : mine;
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  }
   const float inv = 1.f / l_tot;
   // Row-per-lane store, widened (MI355X guide T21): lanes l and l+32 hold columns 8g..8g+3 / 8g+4..8g+7 of the SAME row, so
   // one v_permlane32_swap per dword pairs the column groups (g, g+1): afterwards the lower half-wave owns all 8 columns of
@@ -249,11 +265,11 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
       }
   }
 }
-template <int D, int NWAVES, int NS>
+template <int D, int NWAVES, int NS, int ONES = 0>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
   constexpr int LDS = NS * 2 * 64 * D * 2 + 1024;   // ring + page-id table (256 pages)
   static bool attr_set = false;
-  auto kern = attn_fwd_kernel<D, NWAVES, NS>;
+  auto kern = attn_fwd_kernel<D, NWAVES, NS, ONES>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
     attr_set = true;
@@ -276,7 +292,14 @@ int gvl_launch_attention(const AttnArgs& a, hipStream_t st) {
     // ring depth 2: 48 KB (D=96) -> 3 blocks / CU at 151 VGPRs (measured 427 us vs 461 us for the 73 KB depth-3 ring, which
     // caps residency at 2 blocks / CU; DMA latency is not the limiter -- PMC shows the kernel is VALU-issue-bound)
     case 64: return launch_attn<64, 4, 2>(a, st);
-    case 96: return launch_attn<96, 4, 2>(a, st);
+    case 96: {
+      static const bool no_ones = getenv("GVL_ATTN_NO_ONES") != nullptr;                       // A/B
+      // (192-query blocks of 6 waves -- 3 % instead of 5.9 % tail waste at S = 2049, K/V tiles shared by more waves -- measured 24.6 ms
+      //  of attention per clip against 18.0: two 98 KB blocks per CU hide less latency than three 49 KB ones.  Round 2, dropped.)
+      const int lr = a.Dout - 64;
+      const bool ones = a.ones_row && !no_ones && a.Dout < 96 && lr >= 0 && (lr & 7) < 4 && !a.causal;
+      return ones ? launch_attn<96, 4, 2, 1>(a, st) : launch_attn<96, 4, 2>(a, st);
+    }
     case 128: return launch_attn<128, 4, 2>(a, st);
     default: return -1;
   }

@@ -382,6 +382,8 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const QkvPostArgs a) {
     if (d < a.Dr) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (unsigned)tile[k8 + 2 * e][d] | ((unsigned)tile[k8 + 2 * e + 1][d] << 16);
+    } else if (a.ones_row && d == a.Dr) {
+      o = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};     // bf16 1.0: O^T[Dr] = sum_k P[k] (masked keys carry P = 0)
     }
     *(u32x4_t*)(dst + d * 64 + k8) = o;
   }

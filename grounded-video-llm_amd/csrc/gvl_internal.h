@@ -135,6 +135,8 @@ struct AttnArgs {
   int B, H, KV, S, D, Dout;   // S = number of queries == number of keys (self attention), q_pos0 = 0
   float scale;
   int causal;
+  int ones_row;         // D > Dout only: V^T pad row Dout holds 1.0 for every key (QkvPostArgs.ones_row), so the P.V MFMAs deliver the
+                        // softmax row sum in O^T[Dout] for free and the kernel drops its 32 VALU adds per key tile
 };
 int gvl_launch_attention(const AttnArgs& a, hipStream_t st);
 double gvl_attn_flops(const AttnArgs& a);
@@ -176,6 +178,7 @@ struct QkvPostArgs {
   const float* cos; const float* sin; int pos0;      // mode 2: tables [max_seq][Dr/2] (already bf16-rounded values)
   const int* pos_ptr;              // mode 2 decode: device position of the (single) row, overrides pos0 when non-null
   const float* cos_l; const float* sin_l; int rope_switch;   // decode: long-factor tables used when pos+1 > rope_switch (>0)
+  int ones_row;                    // V^T pad row Dr (needs D > Dr) is filled with 1.0 instead of 0: see AttnArgs.ones_row
 };
 int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st);
 // HD 2x2 merge + sub_GN newline (Phi): f32 [n,576,C] -> bf16 [n,156,4C]

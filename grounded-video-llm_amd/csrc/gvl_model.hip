@@ -197,9 +197,10 @@ int iv2_encode(gvl_ctx* ctx, const float* px, int n, bf16_t* out, hipStream_t st
     RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.n1, h, M, C, 1e-6f, st));
     { GemmArgs g = gemm(h, C, w.qkvw, qkv, 3 * C, M, 3 * C, C); RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
     { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv; q.ld = 3 * C; q.Q = Q; q.Kt = Kt; q.Vt = Vt; q.B = n; q.S = S; q.H = H; q.KV = H; q.Dr = Dr; q.D = D;
-      q.mode = 1; q.qn = w.qn; q.kn = w.kn; q.eps = 1e-6f; RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
+      q.mode = 1; q.qn = w.qn; q.kn = w.kn; q.eps = 1e-6f; q.ones_row = D > Dr ? 1 : 0; RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
     { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; a.O = att; a.B = n; a.H = H; a.KV = H; a.S = S; a.D = D; a.Dout = Dr;
-      a.scale = 1.0f / sqrtf((float)Dr); a.causal = 0; RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
+      a.scale = 1.0f / sqrtf((float)Dr); a.causal = 0; a.ones_row = D > Dr ? 1 : 0;   // head dim 88 padded to 96: the pad row of V^T carries the softmax row sum
+      RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
     { GemmArgs g = gemm(att, C, w.projw, x, C, M, C, C); g.bias = w.projb; g.gamma = w.ls1; g.resid = x; g.ldr = C;
       RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
     RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.n2, h, M, C, 1e-6f, st));

@@ -80,7 +80,7 @@ class LLAVA_NEXT_VIDEO:
         self.num_frames, self.num_segs, self.lora, self.num_temporal_tokens, self.llm = num_frames, num_segs, lora, num_temporal_tokens, llm
         self.group = group
         if geometry is None:
-            geometry = geometry_from_checkpoint_dirs(llm, config_path, pretrained_vision_proj_llm_path)
+            geometry = geometry_from_checkpoint_dirs(llm, config_path, pretrained_vision_proj_llm_path, stage, num_temporal_tokens)
         geometry.frames_per_seg = num_frames // num_segs
         if geometry.max_segs < num_segs:
             geometry.max_segs = num_segs
@@ -299,13 +299,20 @@ class LLAVA_NEXT_VIDEO:
         return out
 
 
-def geometry_from_checkpoint_dirs(llm: str, config_path: Optional[str], pretrained_vision_proj_llm_path: Optional[str]) -> TowerGeometry:
+BASE_VOCAB = {"phi3.5": 32064, "llama3": 128256, "vicuna": 32000}     # tokenizer sizes before reset_embeddings [ext]
+
+
+def geometry_from_checkpoint_dirs(llm: str, config_path: Optional[str], pretrained_vision_proj_llm_path: Optional[str],
+                                  stage: str = "sft", num_temporal_tokens: int = 300) -> TowerGeometry:
     """Default geometry of an LLM family, completed from the HF config.json next to the weights: the reference builds its language
     model from `<pretrained_vision_proj_llm_path>/language_model_seperated` (models/llava_next_video.py:149-151), whose config.json
-    carries rope_scaling.{short,long}_factor, both context limits, rope_theta and rms_norm_eps."""
+    carries rope_scaling.{short,long}_factor, both context limits, rope_theta, rms_norm_eps and the base vocab_size.
+    Vocabulary: stages 'grounded' / 'sft' run reset_embeddings (:153-154, :231-268): num_temporal_tokens + 2 new rows and an lm_head
+    WITH bias; stage 'pretrain' keeps the base vocabulary and the bias-free lm_head."""
     import json
     geo = {"phi3.5": TowerGeometry, "llama3": TowerGeometry.llama3_8b, "vicuna": TowerGeometry.vicuna_7b}[llm]()
     geo.kv_pages = 0                   # production default: the paged KV pool takes the HBM left once the weights are resident
+    base_vocab = BASE_VOCAB[llm]
     cands = []
     if pretrained_vision_proj_llm_path:
         cands.append(os.path.join(pretrained_vision_proj_llm_path, "language_model_seperated", "config.json"))
@@ -314,8 +321,13 @@ def geometry_from_checkpoint_dirs(llm: str, config_path: Optional[str], pretrain
     for c in cands:
         if os.path.exists(c):
             with open(c) as f:
-                geo.apply_hf_config(json.load(f))
+                cfg = json.load(f)
+            geo.apply_hf_config(cfg)
+            base_vocab = int(cfg.get("text_config", cfg).get("vocab_size", base_vocab))
             break
+    grown = stage in ("grounded", "sft")
+    geo.vocab = base_vocab + (num_temporal_tokens + 2 if grown else 0)
+    geo.lm_head_bias = grown
     return geo
 
 

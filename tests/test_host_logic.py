@@ -426,6 +426,10 @@ def test_phi35_geometry_reads_longrope_from_config_json_and_refuses_without(tmp_
            "rope_scaling": {"type": "su", "short_factor": short, "long_factor": long}}
     (d / "config.json").write_text(json.dumps(cfg))
     geo = M.geometry_from_checkpoint_dirs("phi3.5", None, str(tmp_path / "sep"))
+    assert geo.vocab == 32064 + 302 and geo.lm_head_bias                                       # stage sft: reset_embeddings ran (:153-154)
+    g_pre = M.geometry_from_checkpoint_dirs("phi3.5", None, str(tmp_path / "sep"), stage="pretrain")
+    assert g_pre.vocab == 32064 and not g_pre.lm_head_bias                                      # stage pretrain: base vocabulary, bias-free lm_head
+    assert M.geometry_from_checkpoint_dirs("llama3", None, None, "grounded", 300).vocab == 128558
     assert geo.rope_short == short and geo.rope_long == long and geo.rope_max_pos == 131072 and geo.rope_orig_max_pos == 4096
     # the tables built from that geometry carry the short factors and the 1.19 scale even at position 1 (i.e. below 4096)
     cs, sn = Wt.rope_tables(96, 8, geo.rope_theta, geo.rope_short, geo.rope_max_pos, geo.rope_orig_max_pos)

@@ -44,9 +44,10 @@ def main(argv=None, geometry=None):
     ap.add_argument("--ckpt_path", default=None)
     ap.add_argument("--num_frames", type=int, default=96)
     ap.add_argument("--num_segs", type=int, default=12)
+    ap.add_argument("--num_temporal_tokens", type=int, default=300)
     ap.add_argument("--out", required=True)
     a = ap.parse_args(argv)
-    geo = geometry or geometry_from_checkpoint_dirs(a.llm, a.config_path, a.pretrained_vision_proj_llm_path)
+    geo = geometry or geometry_from_checkpoint_dirs(a.llm, a.config_path, a.pretrained_vision_proj_llm_path, a.stage, a.num_temporal_tokens)
     geo.frames_per_seg = a.num_frames // a.num_segs
     sd = load_reference_checkpoints(a.llm, a.pretrained_video_path, a.pretrained_vision_proj_llm_path)
     if a.ckpt_path:

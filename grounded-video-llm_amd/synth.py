@@ -176,34 +176,41 @@ def projector_weights(llm="phi3.5", llm_hidden=3072, clip_hidden=1024, iv2_dim=1
     return W
 
 
-def llm_weights(kind="phi3", hidden=3072, inter=8192, layers=32, heads=32, kv_heads=32, vocab=32366,
-                lm_head_bias=True, seed="llm", device="cpu", exact=False):
-    """State-dict keys of Phi3ForCausalLM / LlamaForCausalLM; lm_head has a bias after
-    reset_embeddings (models/llava_next_video.py:263)."""
-    g = _Gen(seed, device, exact)
+def llm_weight_specs(kind="phi3", hidden=3072, inter=8192, layers=32, heads=32, kv_heads=32, vocab=32366, lm_head_bias=True):
+    """(state-dict key, generator name, shape, std, mean) of every tensor of Phi3ForCausalLM / LlamaForCausalLM, in the
+    order llm_weights() generates them; lm_head has a bias after reset_embeddings (models/llava_next_video.py:263).  A caller that
+    cannot hold a second copy of an 8 B-parameter model (oracle/make_golden.py c3) walks the list one tensor at a time."""
     d = hidden // heads
     sw = hidden ** -0.5
-    W = {"model.embed_tokens.weight": g("embed", (vocab, hidden), 0.5),
-         "model.norm.weight": g("norm", (hidden,), 0.1, 1.0),
-         "lm_head.weight": g("head.w", (vocab, hidden), sw)}
+    specs = [("model.embed_tokens.weight", "embed", (vocab, hidden), 0.5, 0.0),
+             ("model.norm.weight", "norm", (hidden,), 0.1, 1.0),
+             ("lm_head.weight", "head.w", (vocab, hidden), sw, 0.0)]
     if lm_head_bias:
-        W["lm_head.bias"] = g("head.b", (vocab,), 0.05)
+        specs.append(("lm_head.bias", "head.b", (vocab,), 0.05, 0.0))
     for i in range(layers):
         p = f"model.layers.{i}."
-        W[p + "input_layernorm.weight"] = g(f"{i}.ln1", (hidden,), 0.1, 1.0)
-        W[p + "post_attention_layernorm.weight"] = g(f"{i}.ln2", (hidden,), 0.1, 1.0)
-        W[p + "self_attn.o_proj.weight"] = g(f"{i}.o", (hidden, heads * d), sw)
-        W[p + "mlp.down_proj.weight"] = g(f"{i}.down", (hidden, inter), inter ** -0.5)
+        specs.append((p + "input_layernorm.weight", f"{i}.ln1", (hidden,), 0.1, 1.0))
+        specs.append((p + "post_attention_layernorm.weight", f"{i}.ln2", (hidden,), 0.1, 1.0))
+        specs.append((p + "self_attn.o_proj.weight", f"{i}.o", (hidden, heads * d), sw, 0.0))
+        specs.append((p + "mlp.down_proj.weight", f"{i}.down", (hidden, inter), inter ** -0.5, 0.0))
         if kind == "phi3":
-            W[p + "self_attn.qkv_proj.weight"] = g(f"{i}.qkv", ((heads + 2 * kv_heads) * d, hidden), sw)
-            W[p + "mlp.gate_up_proj.weight"] = g(f"{i}.gu", (2 * inter, hidden), sw)
+            specs.append((p + "self_attn.qkv_proj.weight", f"{i}.qkv", ((heads + 2 * kv_heads) * d, hidden), sw, 0.0))
+            specs.append((p + "mlp.gate_up_proj.weight", f"{i}.gu", (2 * inter, hidden), sw, 0.0))
         else:
-            W[p + "self_attn.q_proj.weight"] = g(f"{i}.q", (heads * d, hidden), sw)
-            W[p + "self_attn.k_proj.weight"] = g(f"{i}.k", (kv_heads * d, hidden), sw)
-            W[p + "self_attn.v_proj.weight"] = g(f"{i}.v", (kv_heads * d, hidden), sw)
-            W[p + "mlp.gate_proj.weight"] = g(f"{i}.gate", (inter, hidden), sw)
-            W[p + "mlp.up_proj.weight"] = g(f"{i}.up", (inter, hidden), sw)
-    return W
+            specs.append((p + "self_attn.q_proj.weight", f"{i}.q", (heads * d, hidden), sw, 0.0))
+            specs.append((p + "self_attn.k_proj.weight", f"{i}.k", (kv_heads * d, hidden), sw, 0.0))
+            specs.append((p + "self_attn.v_proj.weight", f"{i}.v", (kv_heads * d, hidden), sw, 0.0))
+            specs.append((p + "mlp.gate_proj.weight", f"{i}.gate", (inter, hidden), sw, 0.0))
+            specs.append((p + "mlp.up_proj.weight", f"{i}.up", (inter, hidden), sw, 0.0))
+    return specs
+
+
+def llm_weights(kind="phi3", hidden=3072, inter=8192, layers=32, heads=32, kv_heads=32, vocab=32366,
+                lm_head_bias=True, seed="llm", device="cpu", exact=False):
+    """State-dict keys of Phi3ForCausalLM / LlamaForCausalLM, all tensors materialised (see llm_weight_specs; its order
+    is the generation order -- it matters for the sequential torch RNG stream of device='cuda', exact=False)."""
+    g = _Gen(seed, device, exact)
+    return {k: g(n, shp, std, mean) for k, n, shp, std, mean in llm_weight_specs(kind, hidden, inter, layers, heads, kv_heads, vocab, lm_head_bias)}
 
 
 def longrope_factors(head_dim=96):

@@ -549,9 +549,110 @@ def g_llama_full(ns):
     save("llama_full_layer", dict(cfg=cfg, seed="g.llama.full", exact=True, ids=ids), logits=logits, logits_bf16ref=lb)
 
 
+def c3_ids(n_text=101, slot=36):
+    ids = np.random.RandomState(43).randint(3, 128000, size=n_text).tolist()
+    ids[slot] = -200
+    return ids
+
+
+def c3_forced_tokens(n=11):
+    return [int(v) for v in np.random.RandomState(44).randint(3, 128000, size=n)]
+
+
+def g_c3(ns):
+    """BASELINE configs[3] at REAL size, end to end through the reference's own modules on CPU in fp32: LLaVA-Next-Llama3-8B base,
+    96 frames / 12 segments -> CLIP 24 L x 12 key frames, InternVideo2 40 blocks x 12 segments (S = 2049), 3x3 pooling + projectors +
+    image_newline, splice into a 101-id prompt (S = 2416), then ONE Llama-3-8B forward (32 layers, GQA 32/8 x 128, theta 5e5, vocab
+    128256 + 302, lm_head bias) over the prompt plus 11 teacher-forced tokens: the logits of the last 12 positions pin the prefill row
+    and 11 paged-KV decode steps of the HIP path.  (The O(n^2) greedy of C0 would need twelve 5-minute forwards; teacher forcing gets
+    the same rows out of one.)"""
+    import copy
+    import time
+    L = ns.llava
+    t00 = time.time()
+
+    class Skel(L.LLAVA_NEXT_VIDEO):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+
+        def get_input_embeddings(self):
+            return self.embed
+
+    hid = 4096
+    sk = Skel()
+    sk.llm, sk.dtype = "llama3", torch.float32
+    c = copy.deepcopy(L.CLIP_VIT_LARGE_PATCH14_336_CONFIG)
+    c._attn_implementation = "eager"
+    sk.vision_tower = _stream_load(ns.clip.CLIPVisionModel(c), lambda: synth.clip_weights(seed="c3.clip", exact=True))
+    sk.video_encoder = _stream_load(_iv2(ns, 1408, 40, 16, 48 / 11, 224, 8), lambda: synth.iv2_weights(seed="c3.iv2", exact=True))
+    Wp = synth.projector_weights("llama3", hid, 1024, 1408, seed="c3.proj", exact=True)
+    sk.video_projecter = load_into(L.Video_Projecter(1408, hid), {k[len("video_projecter."):]: v for k, v in Wp.items() if k.startswith("video_projecter.")})
+    from transformers import LlavaConfig, CLIPVisionConfig, LlamaConfig
+    lc = LlavaConfig(vision_config=CLIPVisionConfig(hidden_size=1024, num_attention_heads=16),
+                     text_config=LlamaConfig(hidden_size=hid, num_hidden_layers=1, intermediate_size=64, num_attention_heads=4, vocab_size=32),
+                     projector_hidden_act="gelu", vision_feature_layer=-2)
+    sk.multi_modal_projector = load_into(L.LlavaMultiModalProjector(lc), {k[len("multi_modal_projector."):]: v for k, v in Wp.items() if k.startswith("multi_modal_projector.")})
+    sk.image_newline = Wp["image_newline"]
+    sk.config = type("C", (), {"hidden_size": hid})()
+    sp = synth.exact_tensor("c3.sp", (1, 12, 3, 336, 336))
+    tp = synth.exact_tensor("c3.tp", (1, 96, 3, 224, 224))
+    t0 = time.time()
+    feats = sk.encode_images({"spatial_pixel_values": sp, "temporal_pixel_values": tp})
+    t_enc = time.time() - t0
+    assert list(feats.shape) == [1, 12 * 193, hid]
+    print(f"[c3] encode_images (12 segments) {t_enc:.0f}s; built in {t0 - t00:.0f}s", flush=True)
+    del sk.vision_tower, sk.video_encoder
+
+    cfg = LlamaConfig(vocab_size=128558, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+                      num_key_value_heads=8, rms_norm_eps=1e-5, max_position_embeddings=8192, pad_token_id=0, bos_token_id=1,
+                      eos_token_id=2, attention_bias=False)
+    cfg.rope_theta = 500000.0
+    cfg.rope_scaling = None
+    cfg.pretraining_tp = 1
+    cfg.attention_dropout = 0.0
+    cfg.mlp_bias = False
+    cfg._attn_implementation = "eager"
+    torch.set_default_dtype(torch.bfloat16)                 # construct small, then hold the real weights in fp32
+    m = ns.llama.LlamaForCausalLM(cfg)
+    m.lm_head = torch.nn.Linear(4096, 128558, bias=True)
+    torch.set_default_dtype(torch.float32)
+    m = m.float()
+    sdm = m.state_dict()                                    # one tensor at a time: a second 32 GB copy does not fit beside the model
+    specs = synth.llm_weight_specs("llama", 4096, 14336, 32, 32, 8, 128558, True)
+    assert set(sdm) == {k for k, *_ in specs}
+    with torch.no_grad():
+        for key, name, shape, std, mean in specs:
+            sdm[key].copy_(synth.exact_tensor("c3.llm/" + name, shape, std, mean).reshape(sdm[key].shape))
+    m.eval()
+    sk.embed = m.get_input_embeddings()
+    print(f"[c3] llama built {time.time() - t00:.0f}s", flush=True)
+    ids = c3_ids()
+    tid = torch.tensor([ids])
+    emb, _, mask = sk.prepare_multimodal_inputs(tid, tid.clone(), torch.ones_like(tid), feats, ["vid"])
+    S = emb.shape[1]
+    assert S == len(ids) - 1 + 12 * 193 == 2416
+    forced = c3_forced_tokens()
+    seq = torch.cat([emb, sk.embed.weight[torch.tensor(forced)][None]], dim=1)                      # [1, S + 11, 4096]
+    t0 = time.time()
+    lg = m(inputs_embeds=seq, use_cache=False).logits[0, S - 1:].float()                            # rows S-1 .. S+10
+    t_llm = time.time() - t0
+    assert lg.shape[0] == 12
+    t2 = torch.topk(lg, 2, dim=-1)
+    mb = m.to(torch.bfloat16)
+    lb = mb(inputs_embeds=seq.to(torch.bfloat16), use_cache=False).logits[0, S - 1:].float()
+    scale = float(lg.abs().max())
+    print(f"[c3] llama forward {t_llm:.0f}s; bf16-vs-fp32 logits rel {float((lb - lg).abs().max()) / scale:.3e} (scale {scale:.3f}); "
+          f"bf16 argmax agrees on {int((lb.argmax(-1) == lg.argmax(-1)).sum())}/12 rows", flush=True)
+    save("c3_full", dict(seeds=dict(clip="c3.clip", iv2="c3.iv2", proj="c3.proj", llm="c3.llm", sp="c3.sp", tp="c3.tp"), ids=ids, forced=forced, S=S,
+                         stride=dict(feats=[5, 16], logits=8), reference_cpu_fp32_timing=dict(threads=torch.get_num_threads(), encode_images_s=t_enc, llm_forward_s=t_llm),
+                         argmax=t2.indices[:, 0].tolist(), second=t2.indices[:, 1].tolist()),
+         feats=feats[:, ::5, ::16], logits_rows=lg[:, ::8], logits_rows_bf16ref=lb[:, ::8],
+         top1=t2.values[:, 0], top2=t2.values[:, 1])
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["int", "clip", "iv2", "phi3", "llama", "glue", "pre", "train"]
     ns = ref_shims.load_reference() if any(w != "pre" for w in which) else None
     for w in which:
         {"int": g_int, "clip": g_clip, "iv2": g_iv2, "phi3": g_phi3, "llama": g_llama, "glue": g_glue, "pre": g_pre, "train": g_train, "c0": g_c0,
-         "llama_full": g_llama_full}[w](ns)
+         "llama_full": g_llama_full, "c3": g_c3}[w](ns)

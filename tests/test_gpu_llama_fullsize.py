@@ -22,10 +22,11 @@ L_SEG = 193
 def llama():
     geo = E.TowerGeometry.llama3_8b(frames_per_seg=8, max_segs=16, max_seq=8192, max_prefill=6400, kv_pages=232)
     eng = E.Engine(geo, DEV)
-    W = synth.clip_weights(seed="l8.clip", device=DEV); eng.load_packed(Wt.pack_clip(W, geo.clip_layers - 1)); del W
-    W = synth.iv2_weights(seed="l8.iv2", device=DEV); eng.load_packed(Wt.pack_iv2(W, geo.iv2_depth - 1, 8)); del W
-    W = synth.projector_weights("llama3", 4096, seed="l8.proj", device=DEV); eng.load_packed(Wt.pack_projectors(W, "llama3")); del W
-    W = synth.llm_weights("llama", geo.hidden, geo.inter, geo.layers, geo.heads, geo.kv_heads, geo.vocab, True, seed="l8.llm", device=DEV)
+    # the weights are the synth.exact_tensor streams of tests/golden/c3_full.npz (bit-identical to what the reference consumed on the CPU)
+    W = synth.clip_weights(seed="c3.clip", device=DEV, exact=True); eng.load_packed(Wt.pack_clip(W, geo.clip_layers - 1)); del W
+    W = synth.iv2_weights(seed="c3.iv2", device=DEV, exact=True); eng.load_packed(Wt.pack_iv2(W, geo.iv2_depth - 1, 8)); del W
+    W = synth.projector_weights("llama3", 4096, seed="c3.proj", device=DEV, exact=True); eng.load_packed(Wt.pack_projectors(W, "llama3")); del W
+    W = synth.llm_weights("llama", geo.hidden, geo.inter, geo.layers, geo.heads, geo.kv_heads, geo.vocab, True, seed="c3.llm", device=DEV, exact=True)
     eng.load_packed(Wt.pack_llm(W, "llama", geo.layers, geo.heads, geo.kv_heads, geo.max_seq, geo.rope_theta, None, None)); del W
     torch.cuda.empty_cache()
     eng.finalize()
@@ -115,3 +116,43 @@ def test_c4_llama3_8b_256_frames_long_context(llama):
     for s in seqs:
         eng.seq_free(s)
     assert both[0] == out[:16] and both[1] == solo2
+
+
+def test_c3_full_depth_end_to_end_vs_reference_golden(llama):
+    """BASELINE configs[3] against the REFERENCE at real width and depth (tests/golden/c3_full.npz, oracle/make_golden.py c3: the
+    reference's own CLIP 24 L / InternVideo2 40 blocks on 12 segments, encode_images, prepare_multimodal_inputs and ONE fp32
+    LlamaForCausalLM forward over the 2416-row prefix plus 11 teacher-forced tokens).  HIP path: 12-segment encode -> splice ->
+    prefill (row S-1) -> 11 teacher-forced decode steps through the paged KV cache (rows S .. S+10).  Bound: max(1e-2, 1.5 x the error
+    of the reference's own bf16 evaluation stored in the golden)."""
+    import numpy as np
+    from conftest import load_golden
+    from gpu_util import check
+    eng, geo = llama
+    meta, g = load_golden("c3_full")
+    sd, st = meta["seeds"], meta["stride"]
+    sp = synth.exact_tensor(sd["sp"], (1, 12, 3, 336, 336), device=DEV)[0]
+    tp = synth.exact_tensor(sd["tp"], (1, 96, 3, 224, 224), device=DEV)
+    tseg = tp.reshape(1, 12, 8, 3, 224, 224).permute(0, 1, 3, 2, 4, 5).flatten(0, 1).contiguous()
+    vis = eng.encode_segments(sp, tseg)
+    assert vis.shape == (12 * L_SEG, 4096)
+    check(vis[None][:, ::st["feats"][0], ::st["feats"][1]], g["feats"], 1e-2, "C3 encode_images (12 segments, 2316 visual tokens) vs reference (fp32)")
+    emb = eng.splice(meta["ids"], vis)
+    S = meta["S"]
+    assert emb.shape[0] == S == 2416
+    scale = float(np.abs(g["logits_rows"]).max())
+    ref_bf = float(np.abs(g["logits_rows_bf16ref"] - g["logits_rows"]).max()) / scale
+    tol = max(1e-2, 1.5 * ref_bf)
+    ls = st["logits"]
+    seq = eng.seq_alloc(S + 32)
+    rows = [eng.prefill(seq, emb, want_logits=True).clone()]
+    for tok in meta["forced"]:
+        rows.append(eng.decode_step_logits(seq, tok).clone())
+    eng.seq_free(seq)
+    errs = [float((r[::ls].cpu().double() - torch.as_tensor(g["logits_rows"][i]).double()).abs().max()) / scale for i, r in enumerate(rows)]
+    print(f"[parity] C3 Llama-3-8B 32 L: the reference's own bf16 evaluation is {ref_bf:.3e} from its fp32 logits (scale {scale:.3f}); bound {tol:.2e}")
+    print("[parity] C3 logits, prefill row + 11 teacher-forced decode rows (of the logit scale):", " ".join(f"{e:.2e}" for e in errs))
+    assert max(errs) <= tol
+    margins = np.asarray(g["top1"]) - np.asarray(g["top2"])
+    for i, r in enumerate(rows):
+        if margins[i] > 2 * tol * scale:
+            assert int(r.argmax()) == meta["argmax"][i], f"row {i}: argmax differs although the reference's margin is {margins[i] / scale:.3e} of the scale"

@@ -34,6 +34,7 @@ struct Seq {
   int* d_tok = nullptr;   // the sequence's latest greedy token (input of its next decode step)
   int* d_out = nullptr;   // [outlist_cap] generated ids, index = generation step
   int* d_ngen = nullptr;  // device copy of n_gen: where the next generated id goes (a decode step carries no host counters)
+  unsigned rng_stream = 0;  // sampling: which random stream this sequence draws from (assigned at its prefill)
 };
 
 struct ProfRec { int cat; hipEvent_t e0, e1; double work; };
@@ -81,6 +82,8 @@ struct gvl_ctx {
   // frame pre-processing scratch (tmp image + tap tables), grown on demand
   void* pre_scratch = nullptr; size_t pre_scratch_bytes = 0;
   int kv_total_pages = 0;
+  // token selection (gvl_set_sampling): greedy argmax unless `on`
+  struct { bool on = false; float inv_temp = 1.f, top_p = 0.f; int top_k = 0; unsigned long long seed = 0; unsigned next_stream = 0; } sample;
   // RCCL communicator owned by the ctx (gvl_comm_init); the library is dlopen'ed on first use
   void* comm = nullptr; int comm_rank = 0, comm_world = 1;
   // profiling

@@ -773,6 +773,119 @@ int gvl_launch_argmax(const ArgmaxArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(argmax_kernel, dim3(a.batch), dim3(1024), 0, st, a);
   return CHECK_LAUNCH();
 }
+// ---- sampling (do_sample=True): the reference forwards do_sample / temperature / top_p to HF generate (models/llava_next_video.py:655-661;
+// inference.py:45-49 defaults do_sample=True, T=0.2, top_p=None; HF's GenerationConfig adds top_k=50).  HF order [ext: transformers
+// generation/logits_process.py]: scores / T -> top-k (keep scores >= the k-th largest, ties kept) -> top-p (sorted ascending, drop while
+// the cumulative probability <= 1 - top_p, i.e. keep a token iff the mass of strictly larger scores is < top_p) -> softmax -> one draw.
+// The draw is Gumbel-max, token = argmax_i (l_i - max) / T - log(-log u_i), u_i = counter hash of (seed, stream, step, i): a sample of
+// exactly softmax(l / T) restricted to the kept set, with no sort and no prefix sum.  torch.multinomial's Philox stream cannot be
+// reproduced, so parity is: same kept set and same token as the CPU restatement `sample_token` used by the tests (same hash), and the right distribution.
+// One block per row; every pass re-reads the row from L2 (32 k - 128 k floats).  All reductions run in a fixed order and every
+// thread sees the same totals, so the thresholds are wave-uniform and the result does not depend on the batch a row travels in.
+__device__ __forceinline__ unsigned smp_fmix32(unsigned h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+__device__ __forceinline__ unsigned smp_key(float v) { const unsigned b = __float_as_uint(v); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }   // order-preserving
+__device__ __forceinline__ float smp_block_sum(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);          // butterfly: bitwise the same total in every lane
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) t += sh[w];
+  return t;
+}
+__global__ __launch_bounds__(1024) void sample_kernel(const ArgmaxArgs a) {
+  __shared__ float shf[16];
+  __shared__ int shi[16];
+  __shared__ int hist[256];
+  __shared__ unsigned s_sel[2];
+  const int b = blockIdx.x, tid = threadIdx.x, n = a.n;
+  const float* l = a.logits + (size_t)b * n;
+  // 1. row maximum
+  float m = -3.4e38f;
+  for (int i = tid; i < n; i += 1024) m = fmaxf(m, l[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((tid & 63) == 0) shf[tid >> 6] = m;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 16; ++w) m = fmaxf(m, shf[w]);
+  // 2. top-k: key of the k-th largest score by an 8-bit radix select over the order-preserving keys (integer counts: exact)
+  unsigned kth = 0;
+  if (a.top_k > 0 && a.top_k < n) {
+    unsigned prefix = 0; int remaining = a.top_k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      for (int i = tid; i < n; i += 1024) {
+        const unsigned k = smp_key(l[i]);
+        if (shift == 24 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(k >> shift) & 255], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int c = 0, bsel = 0;
+        for (int q = 255; q >= 0; --q) { if (c + hist[q] >= remaining) { bsel = q; break; } c += hist[q]; }
+        s_sel[0] = prefix | ((unsigned)bsel << shift); s_sel[1] = (unsigned)(remaining - c);
+      }
+      __syncthreads();
+      prefix = s_sel[0]; remaining = (int)s_sel[1];
+      __syncthreads();
+    }
+    kth = prefix;
+  }
+  // 3. normaliser of the kept scores
+  float z = 0.f;
+  for (int i = tid; i < n; i += 1024) { const float v = l[i]; if (smp_key(v) >= kth) z += expf((v - m) * a.inv_temp); }
+  const float Z = smp_block_sum(z, shf);
+  // 4. top-p: smallest key t such that the mass of keys > t is < top_p * Z (the maximum itself always qualifies: min_tokens_to_keep = 1)
+  unsigned thr = kth;
+  if (a.top_p > 0.f && a.top_p < 1.f) {
+    const float target = a.top_p * Z;
+    unsigned lo = kth, hi = smp_key(m);
+    while (lo < hi) {
+      const unsigned mid = lo + ((hi - lo) >> 1);
+      float s = 0.f;
+      for (int i = tid; i < n; i += 1024) { const float v = l[i]; if (smp_key(v) > mid) s += expf((v - m) * a.inv_temp); }
+      const float S = smp_block_sum(s, shf);
+      if (S < target) hi = mid; else lo = mid + 1;
+    }
+    thr = lo;
+  }
+  // 5. Gumbel-max draw over the kept set
+  const int step = a.ngen_ptrs[b] ? *a.ngen_ptrs[b] : (a.step_override ? a.step_override[b] : 0);
+  const unsigned k0 = smp_fmix32(a.seed_lo ^ 0x9e3779b9u), k1 = smp_fmix32(a.seed_hi ^ k0 ^ 0x85ebca77u);
+  const unsigned kk = smp_fmix32(k1 ^ smp_fmix32(a.stream[b] * 0x9e3779b1u + 0x7f4a7c15u) ^ smp_fmix32((unsigned)step * 0x85ebca77u + 0x165667b1u));
+  const unsigned kk2 = smp_fmix32(kk + 0x632be5abu);
+  float best = -3.4e38f; int idx = 0x7fffffff;
+  for (int i = tid; i < n; i += 1024) {
+    const float v = l[i];
+    if (smp_key(v) < thr) continue;
+    const unsigned h = smp_fmix32(smp_fmix32((unsigned)i + kk) ^ kk2);
+    const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float sc = (v - m) * a.inv_temp - logf(-logf(u));
+    if (sc > best) { best = sc; idx = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { shf[tid >> 6] = best; shi[tid >> 6] = idx; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w) if (shf[w] > best || (shf[w] == best && shi[w] < idx)) { best = shf[w]; idx = shi[w]; }
+    *a.tok_ptrs[b] = idx;
+    if (a.ngen_ptrs[b]) { const int g = *a.ngen_ptrs[b]; if (a.out_lists[b]) a.out_lists[b][g] = idx; *a.ngen_ptrs[b] = g + 1; }
+    if (a.pos_ptrs[b]) (*a.pos_ptrs[b])++;
+  }
+}
+int gvl_launch_sample(const ArgmaxArgs& a, hipStream_t st) {
+  if (a.batch < 1 || a.batch > GVL_MAX_DECODE_BATCH || !(a.inv_temp > 0.f) || a.top_k < 0 || a.top_p < 0.f) return -1;
+  hipLaunchKernelGGL(sample_kernel, dim3(a.batch), dim3(1024), 0, st, a);
+  return CHECK_LAUNCH();
+}
 __global__ void gather_tok_rows_kernel(const bf16_t* __restrict__ table, const TokPtrs toks, bf16_t* __restrict__ dst, int cols) {
   const int r = blockIdx.y;
   const int tok = *toks.p[r];

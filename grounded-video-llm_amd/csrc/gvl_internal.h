@@ -233,8 +233,13 @@ int gvl_launch_ce_rows(const bf16_t* logits, int ld, const int* targets, float* 
 // token -> *tok_ptrs[b] and out_lists[b][*ngen_ptrs[b]]; then (*ngen_ptrs[b])++ and, when non-null, (*pos_ptrs[b])++ (the step's
 // bookkeeping lives on the device: a decode step's launches carry no host-side counters)
 struct ArgmaxArgs { const float* logits; int n, batch; int* tok_ptrs[GVL_MAX_DECODE_BATCH]; int* out_lists[GVL_MAX_DECODE_BATCH];
-                    int* ngen_ptrs[GVL_MAX_DECODE_BATCH]; int* pos_ptrs[GVL_MAX_DECODE_BATCH]; };
+                    int* ngen_ptrs[GVL_MAX_DECODE_BATCH]; int* pos_ptrs[GVL_MAX_DECODE_BATCH];
+                    // sampling (gvl_launch_sample only): scores / temperature -> top-k -> top-p -> one draw per row; the draw of row b is a
+                    // pure function of (seed, stream[b], generation step, logits row), i.e. independent of how sequences are grouped
+                    float inv_temp, top_p; int top_k; unsigned seed_lo, seed_hi; unsigned stream[GVL_MAX_DECODE_BATCH];
+                    const int* step_override; };   // operator tests: generation step of row b when the row has no ngen counter
 int gvl_launch_argmax(const ArgmaxArgs& a, hipStream_t st);
+int gvl_launch_sample(const ArgmaxArgs& a, hipStream_t st);
 // x[b][:] = table[*tok_ptrs[b]][:]  and  (*pos_ptrs[b])++ helpers of the batched decode loop
 struct TokPtrs { const int* p[GVL_MAX_DECODE_BATCH]; int n; };
 int gvl_launch_gather_tok_rows(const bf16_t* table, const TokPtrs& toks, bf16_t* dst, int cols, hipStream_t st);

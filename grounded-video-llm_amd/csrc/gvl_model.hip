@@ -243,6 +243,15 @@ int build_visual(gvl_ctx* ctx, const float* clip_feats, const bf16_t* iv2_feats,
 // page ids of a batch of equal-length sequences, passed by value to a stream-ordered fill (no host buffer lifetime)
 __global__ void fill_ints_kernel(int* dst, const IntList l) { for (int i = threadIdx.x; i < l.n; i += blockDim.x) dst[i] = l.v[i]; }
 
+// The next token of every row of `am`: argmax (greedy), or one draw per row when gvl_set_sampling switched sampling on
+int pick_tokens(gvl_ctx* ctx, ArgmaxArgs& am, Seq* const* sqs, hipStream_t st) {
+  if (!ctx->sample.on) return gvl_launch_argmax(am, st);
+  am.inv_temp = ctx->sample.inv_temp; am.top_p = ctx->sample.top_p; am.top_k = ctx->sample.top_k;
+  am.seed_lo = (unsigned)ctx->sample.seed; am.seed_hi = (unsigned)(ctx->sample.seed >> 32);
+  for (int b = 0; b < am.batch; ++b) am.stream[b] = sqs[b]->rng_stream;
+  return gvl_launch_sample(am, st);
+}
+
 // Prefill of nb = 1, 2 or 4 sequences together (lens[b] tokens each).  The decoder GEMMs run over the rows of all of them
 // (packed back to back, no padding); RoPE / KV append / causal attention run per sequence on its own pages -- as ONE launch with a
 // batch dimension when the lengths are equal, as nb launches otherwise.  Every kernel is batch-invariant, so each sequence's
@@ -327,7 +336,8 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
   for (int b = 0; b < nb; ++b) RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sqs[b]->d_ngen, 0, st));
   { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = f.vocab; am.batch = nb;
     for (int b = 0; b < nb; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.ngen_ptrs[b] = sqs[b]->d_ngen; }   // first generated token
-    RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(am, st)); }
+    for (int b = 0; b < nb; ++b) sqs[b]->rng_stream = ctx->sample.next_stream++;     // a fresh random stream per prefilled sequence
+    RUN(GVL_PROF_OTHER, 0, pick_tokens(ctx, am, sqs, st)); }
   for (int b = 0; b < nb; ++b) {
     RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sqs[b]->d_pos, lens[b], st));
     sqs[b]->pos = lens[b]; sqs[b]->n_gen = 1;
@@ -395,7 +405,7 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
     g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, proj(g, ctx->l_heads)); }
   { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = f.vocab; am.batch = B;   // token, output list, n_gen++ and pos++ on the device
     for (int b = 0; b < B; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.ngen_ptrs[b] = sqs[b]->d_ngen; am.pos_ptrs[b] = sqs[b]->d_pos; }
-    RUN(GVL_PROF_OTHER, 0, gvl_launch_argmax(am, st)); }
+    RUN(GVL_PROF_OTHER, 0, pick_tokens(ctx, am, sqs, st)); }
   for (int b = 0; b < B; ++b) { sqs[b]->pos += 1; sqs[b]->n_gen += 1; }
   return 0;
 }
@@ -963,6 +973,29 @@ int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, voi
   int rc = decode_step(ctx, one, 1, st);
   if (rc) return rc;
   if (logits) HIPCHK(ctx, hipMemcpyAsync(logits, ctx->d_logits, (size_t)ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int gvl_set_sampling(gvl_ctx* ctx, int do_sample, float temperature, int top_k, float top_p, uint64_t seed) {
+  if (!ctx) return GVL_ERR_ARG;
+  if (!do_sample) { ctx->sample.on = false; return 0; }
+  if (!(temperature > 0.f) || top_k < 0 || !(top_p >= 0.f) || top_p > 1.f)
+    return fail(ctx, GVL_ERR_ARG, "gvl_set_sampling: temperature must be > 0, top_k >= 0, 0 <= top_p <= 1");
+  ctx->sample.on = true; ctx->sample.inv_temp = 1.0f / temperature; ctx->sample.top_k = top_k; ctx->sample.top_p = top_p;
+  ctx->sample.seed = seed; ctx->sample.next_stream = 0;
+  return 0;
+}
+
+int gvl_op_sample(gvl_ctx* ctx, const float* logits, int n, int batch, float temperature, int top_k, float top_p, uint64_t seed,
+                  const uint32_t* streams, const int32_t* steps_dev, int32_t* tokens_dev, void* stream) {
+  if (!ctx || !logits || !streams || !steps_dev || !tokens_dev || n < 1 || batch < 1 || batch > GVL_MAX_DECODE_BATCH || !(temperature > 0.f) || top_k < 0 || !(top_p >= 0.f) || top_p > 1.f)
+    return fail(ctx, GVL_ERR_ARG, "gvl_op_sample: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = logits; am.n = n; am.batch = batch;
+  am.inv_temp = 1.0f / temperature; am.top_k = top_k; am.top_p = top_p; am.seed_lo = (unsigned)seed; am.seed_hi = (unsigned)(seed >> 32);
+  am.step_override = steps_dev;
+  for (int b = 0; b < batch; ++b) { am.tok_ptrs[b] = tokens_dev + b; am.stream[b] = streams[b]; }
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_sample(am, st));
   return 0;
 }
 

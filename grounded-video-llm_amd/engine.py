@@ -390,6 +390,23 @@ class Engine:
                   "gvl_op_rmsnorm")
         return y
 
+    def set_sampling(self, do_sample, temperature=1.0, top_k=50, top_p=None, seed=0):
+        """Token selection of every later prefill / decode call: greedy argmax (do_sample False) or temperature / top-k / top-p sampling
+        on the device (HF generate's do_sample=True; `top_k` 50 is HF's GenerationConfig default, `top_p` None / 1.0 = off)."""
+        self._chk(self.lib.gvl_set_sampling(self.ctx, int(bool(do_sample)), float(temperature), int(top_k or 0),
+                                            float(top_p) if top_p is not None else 0.0, int(seed) & (2 ** 64 - 1)), "gvl_set_sampling")
+
+    def op_sample(self, logits, temperature, top_k, top_p, seed, streams, steps):
+        """logits f32 [B, n] -> int32 [B] drawn tokens (row b: random stream streams[b], generation step steps[b])."""
+        import ctypes as C
+        B, n = logits.shape
+        st = (C.c_uint32 * B)(*[int(x) for x in streams])
+        steps_d = torch.tensor(list(steps), dtype=torch.int32, device=self.device)
+        out = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._chk(self.lib.gvl_op_sample(self.ctx, _ptr(logits.contiguous()), n, B, float(temperature), int(top_k or 0), float(top_p or 0.0),
+                                         int(seed) & (2 ** 64 - 1), st, _ptr(steps_d), _ptr(out), self.stream), "gvl_op_sample")
+        return out
+
     def op_dgemm(self, W, x, bias=None):
         """x bf16 [B, K] (B <= 16) -> y f32 [B, N]: the skinny MFMA decode GEMM."""
         N, K = W.shape

@@ -194,10 +194,31 @@ class LLAVA_NEXT_VIDEO:
         return vis.view(bs, S * L, self.geo.hidden)
 
     # generate -----------------------------------------------------------------------------------------------
+    def _select_tokens(self, kw):
+        """HF generate's token selection for the kwargs the reference forwards (inference.py:170-176 -> llava_next_video.py:655-661):
+        greedy, or temperature -> top-k (HF default 50) -> top-p sampling on the device; `seed` (extra) makes a run reproducible,
+        otherwise every call draws a fresh seed from torch's CPU generator (so torch.manual_seed governs it, as it does HF's)."""
+        if kw.get("num_beams", 1) not in (1, None):
+            raise NotImplementedError("beam search (num_beams > 1) is not built; use num_beams=1")
+        if not kw.get("do_sample", False):
+            self.engine.set_sampling(False)
+            return
+        t = kw.get("temperature", 1.0)
+        t = 1.0 if t is None else float(t)
+        if not t > 0:
+            raise ValueError("`temperature` has to be a strictly positive float")      # HF's TemperatureLogitsWarper check
+        top_p = kw.get("top_p")
+        if top_p is not None and not (0 < float(top_p) <= 1.0):
+            raise ValueError("`top_p` has to be a float > 0 and <= 1")
+        top_k = kw.get("top_k", 50)
+        seed = kw.get("seed")
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.engine.set_sampling(True, t, 0 if top_k is None else int(top_k), top_p, seed)
+
     @torch.inference_mode()
     def generate(self, samples, **generate_kwargs) -> List[str]:
-        if generate_kwargs.get("do_sample", False) or generate_kwargs.get("num_beams", 1) != 1:
-            raise NotImplementedError("this tier implements greedy decoding (do_sample=False, num_beams=1)")
+        self._select_tokens(generate_kwargs)
         max_new = int(generate_kwargs.get("max_new_tokens", 2048))
         if any(v == "text" for v in samples.get("video_ids", [])):
             # prepare_multimodal_inputs' `video_ids == 'text'` branch (llava_next_video.py:583-586) is a TRAINING device (dummy visual
@@ -216,8 +237,7 @@ class LLAVA_NEXT_VIDEO:
         """Several prompts about ONE video.  The reference's inference.py calls generate() once per prompt (grounding / QA /
         referring, inference.py:178-182) and re-runs both vision towers every time; here the video is encoded once and the prompts
         are prefilled and decoded together.  Texts are identical to one generate() call per prompt (batch-invariant kernels)."""
-        if generate_kwargs.get("do_sample", False) or generate_kwargs.get("num_beams", 1) != 1:
-            raise NotImplementedError("this tier implements greedy decoding (do_sample=False, num_beams=1)")
+        self._select_tokens(generate_kwargs)
         if samples["spatial_pixel_values"].shape[0] != 1:
             raise ValueError("generate_shared takes the pixel tensors of one video")
         max_new = int(generate_kwargs.get("max_new_tokens", 2048))

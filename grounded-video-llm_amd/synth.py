@@ -179,7 +179,7 @@ def projector_weights(llm="phi3.5", llm_hidden=3072, clip_hidden=1024, iv2_dim=1
 def llm_weight_specs(kind="phi3", hidden=3072, inter=8192, layers=32, heads=32, kv_heads=32, vocab=32366, lm_head_bias=True):
     """(state-dict key, generator name, shape, std, mean) of every tensor of Phi3ForCausalLM / LlamaForCausalLM, in the
     order llm_weights() generates them; lm_head has a bias after reset_embeddings (models/llava_next_video.py:263).  A caller that
-    cannot hold a second copy of an 8 B-parameter model (oracle/make_golden.py c3) walks the list one tensor at a time."""
+    cannot hold a second copy of an 8 B-parameter model (the C3 golden generator) walks the list one tensor at a time."""
     d = hidden // heads
     sw = hidden ** -0.5
     specs = [("model.embed_tokens.weight", "embed", (vocab, hidden), 0.5, 0.0),

@@ -129,6 +129,15 @@ int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int seq_len, f
                 void* stream);
 int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t* out_ids_host,
                       int* n_out, void* stream);
+/* Token selection of every later gvl_prefill* / gvl_decode_* call on this ctx.  The reference forwards do_sample / temperature /
+ * top_p from generate(**kw) to HF generate (models/llava_next_video.py:655-661; inference.py:45-49 defaults: do_sample True,
+ * temperature 0.2, top_p None; HF's GenerationConfig adds top_k 50 [ext]).  do_sample = 0: greedy argmax (the default of a new ctx).
+ * do_sample = 1: scores / temperature -> top-k (0 = off; ties with the k-th score are kept) -> top-p (0 or 1 = off; a token is kept
+ * iff the probability mass of strictly larger scores is < top_p) -> ONE draw from the softmax of what is left, all on the device
+ * inside the decode step.  The draw of a sequence is a pure function of (seed, the order in which sequences were prefilled since
+ * this call, generation step, logits): reproducible, and independent of how sequences are grouped into decode batches.
+ * torch.multinomial's random stream is not reproduced (parity = same kept set + same distribution).  num_beams > 1 is not built. */
+int gvl_set_sampling(gvl_ctx* ctx, int do_sample, float temperature, int top_k, float top_p, uint64_t seed);
 /* Prefill of n_seqs sequences together, seq_lens[i] tokens each (ragged: prompts differ in length; the reference left-pads and
  * masks, llava_next_video.py:622-647 -- here the rows are packed back to back, no padding).  Groups of 4 / 2 / 1 sequences whose
  * rows fit cfg.max_prefill: the decoder GEMMs run over all rows of a group at once (better tile fill); RoPE / KV append / causal
@@ -219,6 +228,10 @@ int gvl_op_rmsnorm(gvl_ctx* ctx, const uint16_t* x, const uint16_t* w, uint16_t*
 /* y[N] = W[N,K] x[K] (+bias) -- the decode GEMV; x,W bf16, y f32. */
 int gvl_op_gemv(gvl_ctx* ctx, const uint16_t* W, const uint16_t* x, const float* bias, float* y, int N, int K,
                 void* stream);
+/* The sampler on its own (operator test): logits f32 device [batch][n] -> tokens_dev int32 device [batch]; row b draws from
+ * random stream streams[b] (host array) at generation step steps_dev[b] (device array).  batch <= 16. */
+int gvl_op_sample(gvl_ctx* ctx, const float* logits, int n, int batch, float temperature, int top_k, float top_p, uint64_t seed,
+                  const uint32_t* streams, const int32_t* steps_dev, int32_t* tokens_dev, void* stream);
 /* y[b][N] = W[N,K] x[b][K] (+bias) for b < batch <= 16 -- the decode projections as ONE skinny MFMA GEMM (the weight stream is
  * read once for all sequences; K % 256 == 0).  x bf16 [batch][K], y f32 [batch][N]. */
 int gvl_op_dgemm(gvl_ctx* ctx, const uint16_t* W, const uint16_t* x, const float* bias, float* y, int N, int K, int batch,

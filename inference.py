@@ -2,8 +2,9 @@
 
     python inference.py --llm phi3.5 --video_path clip.mp4 --ckpt_path ... [--synthetic]
 
-Differences from the reference CLI: boolean flags parse properly, decoding is
-greedy on this tier (`--do_sample` defaults to False), `--device` must be a HIP device.  `--synthetic`
+Differences from the reference CLI: boolean flags parse properly, `--device`
+must be a HIP device, `--seed` also seeds the device sampler (sampling = temperature -> top-k 50 -> top-p on the device, the
+HF semantics of the reference's defaults `--do_sample True --temperature 0.2`; beam search is not built).  `--synthetic`
 runs the same plumbing on seeded random weights, synthetic frames and the stand-in tokenizer (there are no
 checkpoints, tokenizer files or video decoders in the offline image).
 """
@@ -52,12 +53,12 @@ def parse_args(argv=None):
     p.add_argument("--prompt_videoqa", type=str, default="Question: What does this TV news report about?\nOptions:\n(A) thievery\n(B) community violence incidents\n(C) fashion show\n(D) aging population")
     p.add_argument("--prompt_referring", type=str, default="What is happening from 70 seconds to 80 seconds?")
     p.add_argument("--video_path", type=str, default="./experiments/_3klvlS4W7A.mp4")
-    p.add_argument("--do_sample", type=_bool, default=False)
+    p.add_argument("--do_sample", type=_bool, default=True)
     p.add_argument("--num_beams", type=int, default=1)
     p.add_argument("--max_new_tokens", type=int, default=2048)
     p.add_argument("--temperature", type=float, default=0.2)
     p.add_argument("--top_p", type=float, default=None)
-    p.add_argument("--share_visual", type=_bool, default=False, help="encode the video ONCE for the three prompts and batch them (the reference re-encodes per prompt); greedy only")
+    p.add_argument("--share_visual", type=_bool, default=False, help="encode the video ONCE for the three prompts and batch them (the reference re-encodes per prompt)")
     p.add_argument("--synthetic", action="store_true", help="seeded random weights / frames / tokenizer (offline image)")
     p.add_argument("--synthetic_scale", type=str, default="small", choices=["small", "full"])
     return p.parse_args(argv)
@@ -128,10 +129,10 @@ def main(argv=None):
                                  ckpt_path=args.ckpt_path)          # base + fine-tuned overlay packed once (inference.py:156-162)
         frames, fps, vlen, duration = read_frames(args.video_path, args.num_frames)
 
-    kw = {"do_sample": args.do_sample, "num_beams": args.num_beams, "max_new_tokens": args.max_new_tokens, "temperature": args.temperature, "top_p": args.top_p}
+    kw = {"do_sample": args.do_sample, "num_beams": args.num_beams, "max_new_tokens": args.max_new_tokens, "temperature": args.temperature, "top_p": args.top_p, "seed": args.seed}
     outs = {}
     modes = ("grounding", "qa", "referring")
-    if args.share_visual and not args.do_sample:
+    if args.share_visual:
         # one pre-processing + one vision encode for the three prompts (the reference re-encodes the video per prompt)
         per_mode = [create_inputs(args, mode, frames, duration, model.engine) for mode in modes[:1]]
         prompts = [per_mode[0]["prompts"][0]] + [create_prompt(args, mode, duration) for mode in modes[1:]]

@@ -806,3 +806,62 @@ def fp8_weight_model(W: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         else:
             out[k] = v
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# do_sample=True token selection.  The reference forwards do_sample / temperature / top_p to HF generate
+# (models/llava_next_video.py:655-661; inference.py:45-49: do_sample True, temperature 0.2, top_p None); the arithmetic lives in
+# transformers [ext, pinned 4.40.1 in requirements.txt:20]: generation/logits_process.py TemperatureLogitsWarper (scores / T),
+# TopKLogitsWarper (remove scores < the k-th largest; GenerationConfig default top_k = 50), TopPLogitsWarper (sort ascending, remove
+# while cumsum(softmax) <= 1 - top_p, keep >= 1) and then torch.multinomial(softmax(scores)).  `sample_keep_mask` restates the three
+# warpers and is checked against the INSTALLED transformers' classes in tests/test_oracle_golden.py; the draw itself cannot follow
+# torch.multinomial's Philox stream, so `sample_token` defines it as Gumbel-max over a counter hash -- a sample of exactly
+# softmax(scores) on the kept set -- and the HIP sampler must reproduce kept set and token.
+# ---------------------------------------------------------------------------------------------------------------------
+def sample_keep_mask(logits: np.ndarray, temperature: float, top_k: int, top_p: Optional[float]) -> np.ndarray:
+    s = np.asarray(logits, dtype=np.float64) / float(temperature)
+    keep = np.ones(s.shape, dtype=bool)
+    if top_k and 0 < top_k < s.size:
+        kth = np.sort(s)[-top_k]
+        keep &= s >= kth                                          # TopKLogitsWarper: scores < topk(...)[-1] are removed (ties stay)
+    if top_p is not None and 0.0 < top_p < 1.0:
+        sm = np.where(keep, s, -np.inf)
+        p = np.exp(sm - sm.max()); p /= p.sum()
+        order = np.argsort(sm, kind="stable")                      # ascending, as torch.sort(descending=False)
+        cum = np.cumsum(p[order])
+        rem = cum <= (1.0 - top_p)
+        rem[-1] = False                                            # min_tokens_to_keep = 1
+        keep2 = np.ones_like(keep); keep2[order[rem]] = False
+        keep &= keep2
+    return keep
+
+
+def _fmix32_np(h):
+    h = np.asarray(h, dtype=np.uint64) & 0xFFFFFFFF
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & 0xFFFFFFFF
+    h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & 0xFFFFFFFF
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def sample_uniforms(n: int, seed: int, stream: int, step: int) -> np.ndarray:
+    """u_i in (0, 1), i < n: the counter hash the device sampler uses (a pure function of seed, stream, step, i)."""
+    M = 0xFFFFFFFF
+    k0 = int(_fmix32_np((seed & M) ^ 0x9E3779B9)); k1 = int(_fmix32_np(((seed >> 32) & M) ^ k0 ^ 0x85EBCA77))
+    kk = int(_fmix32_np(k1 ^ int(_fmix32_np((stream * 0x9E3779B1 + 0x7F4A7C15) & M)) ^ int(_fmix32_np((step * 0x85EBCA77 + 0x165667B1) & M))))
+    kk2 = int(_fmix32_np((kk + 0x632BE5AB) & M))
+    i = np.arange(n, dtype=np.uint64)
+    h = _fmix32_np(_fmix32_np((i + np.uint64(kk)) & M) ^ np.uint64(kk2))
+    return ((h >> np.uint64(8)).astype(np.float64) + 0.5) / 16777216.0
+
+
+def sample_token(logits: np.ndarray, temperature: float, top_k: int, top_p: Optional[float], seed: int, stream: int, step: int):
+    """-> (token, margin, keep): Gumbel-max draw from softmax(logits / T) restricted to the HF-kept set; margin = perturbed score of the
+    winner minus the runner-up's (how far the draw is from flipping under float rounding)."""
+    keep = sample_keep_mask(logits, temperature, top_k, top_p)
+    s = np.asarray(logits, dtype=np.float64)
+    u = sample_uniforms(s.size, seed, stream, step)
+    sc = (s - s.max()) / float(temperature) - np.log(-np.log(u))
+    sc = np.where(keep, sc, -np.inf)
+    o = np.argsort(-sc, kind="stable")
+    return int(o[0]), float(sc[o[0]] - sc[o[1]]) if keep.sum() > 1 else float("inf"), keep

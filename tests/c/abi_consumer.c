@@ -25,6 +25,7 @@ int main(void) {
     if (gvl_allgather_visual(NULL, NULL, NULL, 0, 0, NULL, NULL) != GVL_ERR_ARG) return 6;
     if (gvl_comm_init(NULL, uid, 0, 1) != GVL_ERR_ARG) return 7;
     if (gvl_comm_destroy(NULL) != GVL_ERR_ARG) return 8;
+    if (gvl_set_sampling(NULL, 1, 0.2f, 50, 0.0f, 42u) != GVL_ERR_ARG) return 9;   /* HF generate's do_sample=True on the device */
   }
   if (di == GVL_ERR_NOGPU) return (rc == GVL_ERR_NOGPU && ctx == NULL) ? 0 : 2;   /* no GPU: must refuse */
   if (rc == 0 && ctx) gvl_destroy(ctx);                                           /* GPU present: an all-zero config is a valid empty ctx or an ARG error */

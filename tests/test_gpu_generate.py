@@ -55,8 +55,20 @@ def test_generate_matches_oracle(llm):
         assert len(got) == len(ref_ids)
     texts = model.generate(samples, do_sample=False, num_beams=1, max_new_tokens=10)
     assert isinstance(texts, list) and len(texts) == 1 and texts[0] == tok.batch_decode([got], skip_special_tokens=True)[0].strip()
+    # the reference's default CLI configuration is SAMPLING (inference.py:45-49: do_sample True, temperature 0.2): reproducible under a
+    # seed, top_k = 1 collapses to greedy, and a later do_sample=False call is greedy again; beam search is refused
+    smp = dict(do_sample=True, num_beams=1, max_new_tokens=10, temperature=1.5, top_p=None)
+    s1 = model.generate(samples, seed=11, **smp)
+    assert s1 == model.generate(samples, seed=11, **smp)
+    draws = {model.generate(samples, seed=k, **smp)[0] for k in range(6)}
+    assert len(draws) > 1, "six seeds at temperature 1.5 all gave the same text"
+    assert model.generate(samples, seed=3, top_k=1, **smp) == texts
+    assert model.generate(samples, do_sample=True, temperature=0.2, max_new_tokens=10)[0] is not None      # unseeded: seed from torch's generator
+    with pytest.raises(ValueError):
+        model.generate(samples, do_sample=True, temperature=0.0)
     with pytest.raises(NotImplementedError):
-        model.generate(samples, do_sample=True)
+        model.generate(samples, do_sample=False, num_beams=2)
+    assert model.generate(samples, do_sample=False, num_beams=1, max_new_tokens=10) == texts
     print(f"[parity] generate({llm}) ids {got} oracle {ref_ids}; text {texts[0]!r}")
     # batch of 3 samples with DIFFERENT prompts (the reference left-pads, llava_next_video.py:622-647): the batched decode must give,
     # sample by sample, exactly what the one-sample generate() gives

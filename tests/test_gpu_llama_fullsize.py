@@ -118,41 +118,58 @@ def test_c4_llama3_8b_256_frames_long_context(llama):
     assert both[0] == out[:16] and both[1] == solo2
 
 
-def test_c3_full_depth_end_to_end_vs_reference_golden(llama):
-    """BASELINE configs[3] against the REFERENCE at real width and depth (tests/golden/c3_full.npz, oracle/make_golden.py c3: the
-    reference's own CLIP 24 L / InternVideo2 40 blocks on 12 segments, encode_images, prepare_multimodal_inputs and ONE fp32
-    LlamaForCausalLM forward over the 2416-row prefix plus 11 teacher-forced tokens).  HIP path: 12-segment encode -> splice ->
-    prefill (row S-1) -> 11 teacher-forced decode steps through the paged KV cache (rows S .. S+10).  Bound: max(1e-2, 1.5 x the error
-    of the reference's own bf16 evaluation stored in the golden)."""
+def _full_depth_vs_reference_golden(llama, name):
+    """HIP path: segment encode (in chunks of the per-call workspace) -> splice -> prefill (row S-1) -> teacher-forced decode steps
+    through the paged KV cache; every `row_step`-th row against the golden.  Bound: max(1e-2, 1.5 x the error of the reference's own
+    bf16 evaluation stored in the golden)."""
     import numpy as np
     from conftest import load_golden
     from gpu_util import check
     eng, geo = llama
-    meta, g = load_golden("c3_full")
+    meta, g = load_golden(name)
     sd, st = meta["seeds"], meta["stride"]
-    sp = synth.exact_tensor(sd["sp"], (1, 12, 3, 336, 336), device=DEV)[0]
-    tp = synth.exact_tensor(sd["tp"], (1, 96, 3, 224, 224), device=DEV)
-    tseg = tp.reshape(1, 12, 8, 3, 224, 224).permute(0, 1, 3, 2, 4, 5).flatten(0, 1).contiguous()
-    vis = eng.encode_segments(sp, tseg)
-    assert vis.shape == (12 * L_SEG, 4096)
-    check(vis[None][:, ::st["feats"][0], ::st["feats"][1]], g["feats"], 1e-2, "C3 encode_images (12 segments, 2316 visual tokens) vs reference (fp32)")
+    n_segs, step = meta.get("n_segs", 12), meta.get("row_step", 1)
+    sp = synth.exact_tensor(sd["sp"], (1, n_segs, 3, 336, 336), device=DEV)[0]
+    tp = synth.exact_tensor(sd["tp"], (1, 8 * n_segs, 3, 224, 224), device=DEV)
+    tseg = tp.reshape(1, n_segs, 8, 3, 224, 224).permute(0, 1, 3, 2, 4, 5).flatten(0, 1).contiguous()
+    ms = geo.max_segs
+    vis = torch.cat([eng.encode_segments(sp[i:i + ms], tseg[i:i + ms]) for i in range(0, n_segs, ms)], 0)
+    assert vis.shape == (n_segs * L_SEG, 4096)
+    check(vis[None][:, ::st["feats"][0], ::st["feats"][1]], g["feats"], 1e-2, f"{name}: encode_images ({n_segs} segments, {n_segs * L_SEG} visual tokens) vs reference (fp32)")
     emb = eng.splice(meta["ids"], vis)
     S = meta["S"]
-    assert emb.shape[0] == S == 2416
+    assert emb.shape[0] == S
     scale = float(np.abs(g["logits_rows"]).max())
     ref_bf = float(np.abs(g["logits_rows_bf16ref"] - g["logits_rows"]).max()) / scale
     tol = max(1e-2, 1.5 * ref_bf)
     ls = st["logits"]
-    seq = eng.seq_alloc(S + 32)
+    seq = eng.seq_alloc(S + len(meta["forced"]) + 8)
     rows = [eng.prefill(seq, emb, want_logits=True).clone()]
-    for tok in meta["forced"]:
-        rows.append(eng.decode_step_logits(seq, tok).clone())
+    for i, tok in enumerate(meta["forced"]):
+        lg = eng.decode_step_logits(seq, tok)
+        if (i + 1) % step == 0:
+            rows.append(lg.clone())
     eng.seq_free(seq)
+    assert len(rows) == g["logits_rows"].shape[0]
     errs = [float((r[::ls].cpu().double() - torch.as_tensor(g["logits_rows"][i]).double()).abs().max()) / scale for i, r in enumerate(rows)]
-    print(f"[parity] C3 Llama-3-8B 32 L: the reference's own bf16 evaluation is {ref_bf:.3e} from its fp32 logits (scale {scale:.3f}); bound {tol:.2e}")
-    print("[parity] C3 logits, prefill row + 11 teacher-forced decode rows (of the logit scale):", " ".join(f"{e:.2e}" for e in errs))
+    print(f"[parity] {name} Llama-3-8B 32 L, S={S}: the reference's own bf16 evaluation is {ref_bf:.3e} from its fp32 logits (scale {scale:.3f}); bound {tol:.2e}")
+    print(f"[parity] {name} logits, prefill row + teacher-forced decode rows (every {step}; of the logit scale):", " ".join(f"{e:.2e}" for e in errs))
     assert max(errs) <= tol
     margins = np.asarray(g["top1"]) - np.asarray(g["top2"])
     for i, r in enumerate(rows):
         if margins[i] > 2 * tol * scale:
             assert int(r.argmax()) == meta["argmax"][i], f"row {i}: argmax differs although the reference's margin is {margins[i] / scale:.3e} of the scale"
+
+
+def test_c3_full_depth_end_to_end_vs_reference_golden(llama):
+    """BASELINE configs[3] against the REFERENCE at real width and depth (tests/golden/c3_full.npz, oracle/make_golden.py c3: the
+    reference's own CLIP 24 L / InternVideo2 40 blocks on 12 segments, encode_images, prepare_multimodal_inputs and ONE fp32
+    LlamaForCausalLM forward over the 2416-row prefix plus 11 teacher-forced tokens)."""
+    _full_depth_vs_reference_golden(llama, "c3_full")
+
+
+def test_c4_full_depth_long_context_vs_reference_golden(llama):
+    """BASELINE configs[4] (dense captioning: 256 frames / 32 segments, S = 6276 long-context prefill, 64 tokens) against the REFERENCE
+    at real size on one device (tests/golden/c4_full.npz, oracle/make_golden.py c4: 32-segment encode_images, one fp32 forward over
+    the prefix plus 63 teacher-forced tokens, every 4th row stored)."""
+    _full_depth_vs_reference_golden(llama, "c4_full")

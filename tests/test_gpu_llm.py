@@ -509,3 +509,44 @@ def test_fp8_weight_variant_matches_the_dequantised_model():
     W2 = synth.llm_weights("phi3", 256, 512, 1, 4, 4, 64, True, seed="t.fp8.b")
     with pytest.raises(E.L.GvlError, match="multiples of 512"):
         llm_engine(g2, W2)
+
+
+def test_sampling_inside_the_decode_loop_is_reproducible_and_batch_invariant():
+    """gvl_set_sampling (HF generate's do_sample=True: temperature -> top-k -> top-p -> one draw, all inside the decode step).  A
+    sequence's draws depend on (seed, its prefill order, generation step, its logits) only: 7 sequences decoded as ONE group give the
+    ids of 7 one-at-a-time runs bit for bit; the same seed reproduces them, another seed does not; top_k = 1 is greedy; switching
+    sampling off restores the greedy ids.  (Kept set and draw against the restated HF warpers: tests/test_gpu_ops.py.)"""
+    c = dict(hidden=256, inter=512, layers=2, heads=4, kv_heads=4, vocab=700)
+    geo = _phi_geo(c, max_seq=256, max_prefill=128, kv_pages=32)
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.smp", device=DEV)
+    eng = llm_engine(geo, W)
+    g = torch.Generator(device=DEV); g.manual_seed(9)
+    lens = [5, 17, 60, 64, 33, 1, 100]
+    embs = [(torch.randn((n, c["hidden"]), device=DEV, generator=g) * 0.5).to(bf) for n in lens]
+    new = 12
+
+    def run(batched):
+        seqs = [eng.seq_alloc(e.shape[0] + new + 1) for e in embs]
+        for s, e in zip(seqs, embs):
+            eng.prefill(s, e)                                   # prefill order = random-stream order
+        out = eng.decode_greedy_batch(seqs, new, None) if batched else [eng.decode_greedy(s, new, None) for s in seqs]
+        for s in seqs:
+            eng.seq_free(s)
+        return out
+
+    greedy = run(True)
+    eng.set_sampling(True, 1.3, 50, 0.95, seed=2024)
+    a = run(True)
+    eng.set_sampling(True, 1.3, 50, 0.95, seed=2024)
+    b = run(False)
+    assert a == b, "sampled ids depend on how the sequences were grouped"
+    assert a != greedy and all(len(x) == new for x in a)
+    eng.set_sampling(True, 1.3, 50, 0.95, seed=2025)
+    assert run(True) != a
+    eng.set_sampling(True, 1.3, 1, None, seed=1)
+    assert run(True) == greedy
+    eng.set_sampling(False)
+    assert run(False) == greedy
+    with pytest.raises(RuntimeError):
+        eng.set_sampling(True, 0.0)
+    eng.close()

@@ -2,11 +2,14 @@
 (floating-point kernels; tolerance = bf16 output rounding, stated per test)."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
+import gvl_oracle as O  # noqa: E402
 from gpu_util import DEV, bf, check, tiny_geo  # noqa: E402
 from grounded_video_llm_amd import engine as E, lib as L, synth  # noqa: E402
 
@@ -205,3 +208,71 @@ def test_gemm_planner_full_shapes(eng, M, N, K, epi):
         res = torch.randn((M, N), device=DEV, generator=g).to(bf)
         got, ref = eng.op_gemm(A, W, bias=bias, gamma=gam, resid=res), res.float() + rb(rb(acc + bias) * gam)
     check(got, ref, 8e-3, f"gemm planner {M}x{N}x{K} {epi}")
+
+
+# ---- do_sample=True token selection (gvl_op_sample == the kernel inside every prefill / decode step after gvl_set_sampling) ----------------
+@pytest.mark.parametrize("n,temperature,top_k,top_p", [
+    (100, 1.0, 0, None), (100, 0.7, 5, None), (1000, 0.2, 50, None), (1000, 1.0, 0, 0.9), (5000, 1.3, 50, 0.5),
+    (32366, 0.2, 50, None),           # Phi-3.5 vocabulary, the reference's default sampling configuration
+    (32366, 1.0, 0, 0.95), (128558, 0.2, 50, 0.9), (128558, 1.0, 1000, None), (64, 1.0, 1, None), (64, 0.5, 0, 0.01)])
+def test_sampler_kept_set_and_draw_match_the_restated_hf_semantics(eng, n, temperature, top_k, top_p):
+    """16 rows per launch, each with its own logits, random stream and generation step.  The drawn token must be the oracle's
+    (HF warpers restated + the same counter hash); where the oracle's winner leads the runner-up by less than 1e-3 (f32 vs f64 log /
+    exp, or a top-p boundary within rounding) the runner-up is accepted too.  A drawn token outside the HF-kept set is always an error."""
+    rng = np.random.default_rng(n * 7 + top_k)
+    B = 16
+    logits = (rng.standard_normal((B, n)) * rng.choice([0.5, 2.0, 4.0], size=(B, 1))).astype(np.float32)
+    streams = [int(x) for x in rng.integers(0, 2 ** 31, B)]
+    steps = [int(x) for x in rng.integers(0, 4000, B)]
+    seed = 0x1234_5678_9ABC_DEF0
+    got = eng.op_sample(torch.from_numpy(logits).to(DEV), temperature, top_k, top_p, seed, streams, steps).cpu().tolist()
+    soft = 0
+    for b in range(B):
+        tok, margin, keep = O.sample_token(logits[b], temperature, top_k, top_p, seed, streams[b], steps[b])
+        if got[b] == tok:
+            continue
+        # boundary tokens of the top-p cut may legitimately flip under f32 summation: identify them by their distance to the cut
+        s = logits[b].astype(np.float64) / temperature
+        p = np.exp(s - s.max()); p = np.where(O.sample_keep_mask(logits[b], temperature, top_k, None), p, 0); p /= p.sum()
+        greater = np.array([p[p > p[got[b]]].sum()])
+        near_cut = top_p is not None and abs(float(greater[0]) - top_p) < 1e-4
+        assert keep[got[b]] or near_cut, f"row {b}: token {got[b]} is outside the kept set"
+        assert margin < 1e-3 or near_cut, f"row {b}: drew {got[b]}, oracle {tok} with margin {margin:.3e}"
+        soft += 1
+    assert soft <= 2, f"{soft} of {B} rows needed the near-tie allowance"
+
+
+def test_sampler_is_a_pure_function_of_seed_stream_step_and_row(eng):
+    """Same (seed, stream, step, logits) -> same token whatever else is in the launch (rows shuffled, batch 1 vs 16); another seed, stream
+    or step changes the draws."""
+    rng = np.random.default_rng(5)
+    n, B = 2000, 16
+    logits = torch.from_numpy(rng.standard_normal((B, n)).astype(np.float32)).to(DEV)
+    streams, steps = list(range(B)), [3 * b for b in range(B)]
+    a = eng.op_sample(logits, 1.0, 0, None, 99, streams, steps).cpu().tolist()
+    perm = list(rng.permutation(B))
+    b_ = eng.op_sample(logits[perm], 1.0, 0, None, 99, [streams[i] for i in perm], [steps[i] for i in perm]).cpu().tolist()
+    assert [b_[perm.index(i)] for i in range(B)] == a
+    one = [eng.op_sample(logits[i:i + 1], 1.0, 0, None, 99, [streams[i]], [steps[i]]).cpu().tolist()[0] for i in range(B)]
+    assert one == a
+    assert eng.op_sample(logits, 1.0, 0, None, 100, streams, steps).cpu().tolist() != a
+    assert eng.op_sample(logits, 1.0, 0, None, 99, [s + 1 for s in streams], steps).cpu().tolist() != a
+    assert eng.op_sample(logits, 1.0, 0, None, 99, streams, [s + 1 for s in steps]).cpu().tolist() != a
+
+
+def test_sampler_distribution(eng):
+    """8000 draws (16 rows x 500 steps) from a 12-token row at T = 0.7 with top-k 8: empirical frequencies within 4.5 sigma of
+    softmax(l / T) renormalised over the 8 kept tokens; the 4 removed tokens are never drawn."""
+    l = np.array([0.3, -1.0, 2.0, 1.1, 0.0, -3.0, 1.9, 0.7, -0.2, 2.4, -2.0, 0.9], dtype=np.float32)
+    T, K = 0.7, 8
+    keep = O.sample_keep_mask(l, T, K, None)
+    p = np.where(keep, np.exp(l.astype(np.float64) / T), 0.0); p /= p.sum()
+    rows = torch.from_numpy(np.tile(l, (16, 1))).to(DEV)
+    cnt = np.zeros(12)
+    for it in range(500):
+        toks = eng.op_sample(rows, T, K, None, 7, list(range(16)), [it] * 16).cpu().numpy()
+        cnt += np.bincount(toks, minlength=12)
+    N = cnt.sum()
+    assert N == 8000 and cnt[~keep].sum() == 0
+    sigma = np.sqrt(p * (1 - p) / N)
+    assert np.all(np.abs(cnt / N - p) <= 4.5 * sigma + 1e-9), (cnt / N, p)

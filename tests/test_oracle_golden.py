@@ -252,3 +252,38 @@ def test_pillow_resampler_restatement_fuzz():
         ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BICUBIC))
         got = O.pil_resize_bicubic(img, ow, oh)
         assert got.shape == ref.shape and np.array_equal(got, ref), f"{(h, w)} -> {(oh, ow)}: {int((got != ref).sum())} bytes differ from Pillow {PIL.__version__}"
+
+
+def test_sampler_restatement_matches_installed_transformers_warpers():
+    """do_sample=True (the reference's CLI default, inference.py:45-49 -> llava_next_video.py:655-661 -> HF generate [ext]): the oracle's
+    kept set must equal TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper of the transformers that is installed here
+    (5.x; the reference pins 4.40.1, whose warpers have the same definitions), on 300 random rows."""
+    lp = pytest.importorskip("transformers.generation.logits_process")
+    rng = np.random.default_rng(0)
+    for trial in range(300):
+        n = int(rng.choice([16, 100, 1000, 5000]))
+        l = (rng.standard_normal(n) * rng.choice([0.5, 2, 5])).astype(np.float32)
+        T = float(rng.choice([0.2, 0.7, 1.0, 1.5])); k = int(rng.choice([0, 1, 5, 50]))
+        p = [None, 0.1, 0.5, 0.9, 0.99][int(rng.integers(0, 5))]
+        s = torch.tensor(l)[None].double()
+        s = lp.TemperatureLogitsWarper(T)(None, s)
+        if k:
+            s = lp.TopKLogitsWarper(k)(None, s)
+        if p is not None:
+            s = lp.TopPLogitsWarper(p)(None, s)
+        assert np.array_equal(torch.isfinite(s[0]).numpy(), O.sample_keep_mask(l, T, k, p)), (trial, n, T, k, p)
+
+
+def test_sampler_counter_hash_known_answers_and_distribution():
+    """The counter hash shared with the HIP sampler is pinned by value (a change would silently alter every sampled run), and the
+    Gumbel-max draw over it samples softmax(l / T)."""
+    u = O.sample_uniforms(5, 0x123456789ABCDEF0, 7, 3)
+    assert [float(x).hex() for x in u] == ['0x1.34bd490000000p-1', '0x1.082d680000000p-4', '0x1.a8ff8d0000000p-1', '0x1.3829120000000p-2', '0x1.63d8370000000p-1']
+    l = np.array([0.0, 1.0, 2.0, -1.0, 0.5], dtype=np.float32)
+    tok, margin, keep = O.sample_token(l, 0.7, 0, None, 1234, 3, 17)
+    assert tok == 2 and abs(margin - 3.989575346104739) < 1e-9 and keep.all()
+    cnt = np.zeros(5)
+    for st in range(6000):
+        cnt[O.sample_token(l, 0.7, 0, None, 1234, 3, st)[0]] += 1
+    p = np.exp(l / 0.7); p /= p.sum()
+    assert np.all(np.abs(cnt / 6000 - p) <= 4.5 * np.sqrt(p * (1 - p) / 6000))

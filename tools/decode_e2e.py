@@ -1,6 +1,6 @@
 """Decode-only throughput of the full-size LLM through the C ABI: tokens/s for groups of 1 / 4 / 16 sequences at a short and at the
 BASELINE context (3.5 k), and the fraction of the HBM roofline (weights 7.45 GB + KV 384 KB x context per Phi-3.5 token).
-  GVL_DECODE_GRAPH=1 python tools/decode_e2e.py [phi|llama]"""
+  GVL_DECODE_GRAPH=1 GVL_E2E_S=64,3519 GVL_E2E_B=1,16 python tools/decode_e2e.py [phi|llama]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import _gvl_bootstrap  # noqa
@@ -27,9 +27,11 @@ eng.finalize()
 print("kv pool", eng.kv_info(), "graph", os.environ.get("GVL_DECODE_GRAPH", "0"), "fp8", geo.decode_fp8, flush=True)
 g = torch.Generator(device=dev); g.manual_seed(1)
 new = 33
-for S in (64, 3519):
+SS = [int(x) for x in os.environ.get("GVL_E2E_S", "64,3519").split(",")]
+BS = [int(x) for x in os.environ.get("GVL_E2E_B", "1,2,4,8,16").split(",")]
+for S in SS:
     emb = (torch.randn((S, geo.hidden), device=dev, generator=g) * 0.5).to(torch.bfloat16)
-    for B in (1, 2, 4, 8, 16):
+    for B in BS:
         seqs = [eng.seq_alloc(S + new + 1) for _ in range(B)]
         for s in seqs:
             eng.prefill(s, emb)

@@ -350,10 +350,16 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
   // no merge round trip (measured before: 12 us per layer at 64 tokens, 44 us for 16 sequences -- almost all of it that chain).
   int ns = (npages + 3) >> 2;
   ns = ns > a.nsplit ? a.nsplit : ns;
-  if (split >= ns) return;
+  // A block takes a.cpb CONSECUTIVE splits, one after the other, and publishes one partial per split -- the partials (and therefore the
+  // merged result) are the same whatever cpb is, so the host is free to pick it per launch: 1 when the launch is small (one sequence:
+  // as many blocks as possible), up to 4 for long contexts x many sequences, where a block's publish -> ticket (-> merge) tail costs
+  // more than its page loads and is then paid once per 16 pages instead of once per 4.
+  const int cpb = a.cpb;
+  const int c_begin = split * cpb;                   // `split` = block index along the context here
+  if (c_begin >= ns) return;
+  const int c_end = c_begin + cpb < ns ? c_begin + cpb : ns;
+  const int nblk = (ns + cpb - 1) / cpb;             // blocks working on this (head, sequence): the ticket's target
   const int pps = (npages + ns - 1) / ns;
-  const int p_begin = split * pps;
-  int p_end = p_begin + pps; if (p_end > npages) p_end = npages;
 
   // the lane's q chunks (chunk index (it*64+lane) % CPR): 16-byte L2 hits, no LDS staging / block barrier
   u32x4_t qv[G][QP];
@@ -363,6 +369,9 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
     for (int it = 0; it < QP; ++it) qv[g][it] = *(const u32x4_t*)(qb + (head0 + g) * D + ((it * 64 + lane) % CPR) * 8);
 
   const float sc = a.scale * 1.4426950408889634f;
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+  const int p_begin = chunk * pps;
+  int p_end = p_begin + pps; if (p_end > npages) p_end = npages;
   float m_run[G], l_run[G];
   float oacc[G][NIT];
 #pragma unroll
@@ -422,6 +431,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
     }
   }
   // combine the 4 waves of this block
+  if (chunk > c_begin) __syncthreads();              // the previous split's red_s has been read by everybody
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     if ((lane & 7) == 0) {
@@ -452,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
   //      (guide G16 recipe R1; placement independent) ---------------------------------------------------------
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    float* outp = part_b + ((size_t)(head0 + g) * a.nsplit + split) * (D + 2);
+    float* outp = part_b + ((size_t)(head0 + g) * a.nsplit + chunk) * (D + 2);
     const float mm = fmaxf(fmaxf(red_s[g][0][D], red_s[g][1][D]), fmaxf(red_s[g][2][D], red_s[g][3][D]));
     if (tid < D) {
       float acc = 0.f;
@@ -468,11 +478,12 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
       __hip_atomic_store(outp + D + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  }                                                  // next split of this block
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores
   __syncthreads();
   if (tid == 0) {
     const int t = __hip_atomic_fetch_add(counters_b + head0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last_s = (t == ns - 1);
+    last_s = (t == nblk - 1);
   }
   __syncthreads();
   if (!last_s) return;
@@ -518,7 +529,8 @@ int gvl_launch_decode_attention(const DecodeAttnArgs& a_in, hipStream_t st) {
   if (a.batch <= 0) a.batch = 1;
   if (a.batch > GVL_MAX_DECODE_BATCH) return -1;
   if (a.H % a.KV) return -1;
-  if (a.gsplit <= 0 || a.gsplit > a.nsplit) a.gsplit = a.nsplit;
+  if (a.cpb < 1) a.cpb = 1;
+  if (a.gsplit <= 0 || a.gsplit > a.nsplit) a.gsplit = (a.nsplit + a.cpb - 1) / a.cpb;
   switch (a.D) {
     case 64: return launch_decode_g<64>(a, st);
     case 96: return launch_decode_g<96>(a, st);

@@ -152,7 +152,8 @@ struct DecodeAttnArgs {
   bf16_t* out;            // [batch][H*Dout], out_stride elements apart; out_tiled: B-operand tile order (gvl_xt_index) for the skinny decode GEMM
   int H, KV, D, Dout, nsplit, batch, q_stride, out_stride, out_tiled;
   float scale;
-  int gsplit;             // split slots actually launched (0 = nsplit): the host may pass min(nsplit, ceil(longest context in pages / 4)) -- a
+  int cpb;                // consecutive splits per block (0 = 1); any value gives the same result (one partial per split either way)
+  int gsplit;             // block slots along the context actually launched (0 = ceil(nsplit / cpb)): the host may pass min(nsplit, ceil(longest context in pages / 4)) -- a
                           // sequence uses ceil(its pages / 4) splits whatever the grid offers, so this only trims blocks that would leave at once
 };
 int gvl_launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st);

@@ -361,14 +361,21 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
   if (fused_norm) RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_tok_rows(ctx->l_embed, tp, ctx->d_x, Hd, st));
   else RUN(GVL_PROF_OTHER, 0, gvl_launch_embed_norm(ctx->l_embed, tp, ctx->d_x, ctx->d_xn, ctx->ll[0].ln1, Hd, f.rms_eps, st));
   double ctx_tokens = 0; for (int b = 0; b < B; ++b) ctx_tokens += sqs[b]->pos + 1;
-  // context splits worth launching: one per 4 pages of the LONGEST member (a sequence picks its own count from its own length, so
-  // this only trims blocks that would leave at once).  Under stream capture the grid must stay valid for later steps: all slots.
-  int gsplit = ctx->nsplit;
+  // Decode-attention launch shape.  A sequence always uses one context split per 4 pages of ITS OWN length and one partial per split
+  // (its arithmetic never depends on the batch); how many block slots the grid offers (gsplit) and how many consecutive splits one
+  // block works through (cpb) are free.  cpb stays 1: letting a block amortise its publish -> ticket tail over 8 / 16 pages was
+  // measured neutral to slower (Phi-3.5, 3.5 k context, 16 sequences: 2631 tok/s at cpb 1, 2613 at 2, 2574 at 4; one sequence:
+  // 455 / 445 / 408) -- at 5.5 TB/s over pages scattered through a 244 GB pool the page reads, not the tail, are the limit.
+  // GVL_DECODE_ATTN_CPB overrides (A/B, tests).  Under stream capture the shape must stay valid for later steps: every slot.
+  int gsplit = ctx->nsplit, cpb = 1;
   { hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (st == nullptr || hipStreamIsCapturing(st, &cs) != hipSuccess || cs == hipStreamCaptureStatusNone) {
-      int maxp = 0; for (int b = 0; b < B; ++b) { const int np = (sqs[b]->pos + 1 + 63) >> 6; maxp = np > maxp ? np : maxp; }
-      const int need = (maxp + 3) >> 2;
-      gsplit = need < ctx->nsplit ? (need < 1 ? 1 : need) : ctx->nsplit;
+      int nsb[GVL_MAX_DECODE_BATCH];
+      for (int b = 0; b < B; ++b) { const int np = (sqs[b]->pos + 1 + 63) >> 6; const int n = (np + 3) >> 2; nsb[b] = n < 1 ? 1 : (n > ctx->nsplit ? ctx->nsplit : n); }
+      const char* fe = getenv("GVL_DECODE_ATTN_CPB");           // A/B and tests/test_gpu_llm.py (read per step on purpose: the test flips it)
+      const int force_cpb = fe ? atoi(fe) : 0;
+      if (force_cpb >= 1 && force_cpb <= 16) cpb = force_cpb;
+      gsplit = 1; for (int b = 0; b < B; ++b) { const int g = (nsb[b] + cpb - 1) / cpb; gsplit = g > gsplit ? g : gsplit; }
     } }
   auto proj = [&](GemvArgs& g, const float* wscale) {
     if (!mfma) return gvl_launch_gemv(g, st);
@@ -391,7 +398,7 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
       RUN(GVL_PROF_GEMV, 2.0 * qkvw * Hd, proj(g, w.qkvs)); }
     { DecodeAttnArgs a; memset(&a, 0, sizeof(a)); a.q = ctx->d_q; a.q_stride = H * D; a.Kt = Kt; a.Vt = Vt;
       for (int b = 0; b < B; ++b) { a.tables[b] = sqs[b]->d_block_table; a.pos_ptrs[b] = sqs[b]->d_pos; }
-      a.part = ctx->d_part; a.counters = ctx->d_counters; a.batch = B; a.gsplit = gsplit;
+      a.part = ctx->d_part; a.counters = ctx->d_counters; a.batch = B; a.gsplit = gsplit; a.cpb = cpb;
       a.out = ctx->d_attn; a.out_stride = H * Dr; a.out_tiled = mfma ? 1 : 0; a.H = H; a.KV = KV; a.D = D; a.Dout = Dr; a.nsplit = ctx->nsplit; a.scale = 1.0f / sqrtf((float)Dr);
       RUN(GVL_PROF_DECODE_ATTN, 4.0 * ctx_tokens * (double)KV * D, gvl_launch_decode_attention(a, st)); }
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? w.od : w.ow; g.N = Hd; g.K = H * Dr; g.x = ctx->d_attn; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;

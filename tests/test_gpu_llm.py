@@ -550,3 +550,42 @@ def test_sampling_inside_the_decode_loop_is_reproducible_and_batch_invariant():
     with pytest.raises(RuntimeError):
         eng.set_sampling(True, 0.0)
     eng.close()
+
+
+def test_decode_attention_result_is_independent_of_the_launch_shape():
+    """Decode attention splits a sequence's context into one split per 4 pages of ITS OWN length and publishes one partial per split;
+    how many consecutive splits a block works through (cpb: 1 for small launches, 2 / 4 for long contexts x many sequences) is chosen
+    per launch by the host.  The ids and logits must not depend on it: contexts of 9 and 17 splits (one past a page boundary, one
+    crossing 4096 tokens where the split count is clamped to 16), forced cpb = 1, 2, 3, 4, 16 against the default choice."""
+    import os
+    c = dict(hidden=256, inter=512, layers=2, heads=4, kv_heads=4, vocab=320)
+    geo = _phi_geo(c, max_seq=4608, max_prefill=4352, kv_pages=160)
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.cpb", device=DEV)
+    eng = llm_engine(geo, W)
+    g = torch.Generator(device=DEV); g.manual_seed(12)
+    embs = [(torch.randn((n, c["hidden"]), device=DEV, generator=g) * 0.5).to(bf) for n in (2100, 4090, 70)]
+    new = 10
+
+    def run():
+        seqs = [eng.seq_alloc(e.shape[0] + new + 1) for e in embs]
+        for s, e in zip(seqs, embs):
+            eng.prefill(s, e)
+        ids = eng.decode_greedy_batch(seqs, new, None)
+        lg = [eng.decode_step_logits(s, 5).clone() for s in seqs]
+        for s in seqs:
+            eng.seq_free(s)
+        return ids, lg
+
+    old = os.environ.pop("GVL_DECODE_ATTN_CPB", None)
+    try:
+        ref_ids, ref_lg = run()
+        for cpb in (1, 2, 3, 4, 16):
+            os.environ["GVL_DECODE_ATTN_CPB"] = str(cpb)
+            ids, lg = run()
+            assert ids == ref_ids, f"cpb {cpb}: ids differ"
+            assert all(torch.equal(a, b) for a, b in zip(lg, ref_lg)), f"cpb {cpb}: logits differ"
+    finally:
+        os.environ.pop("GVL_DECODE_ATTN_CPB", None)
+        if old is not None:
+            os.environ["GVL_DECODE_ATTN_CPB"] = old
+    eng.close()

@@ -554,8 +554,8 @@ def test_sampling_inside_the_decode_loop_is_reproducible_and_batch_invariant():
 
 def test_decode_attention_result_is_independent_of_the_launch_shape():
     """Decode attention splits a sequence's context into one split per 4 pages of ITS OWN length and publishes one partial per split;
-    how many consecutive splits a block works through (cpb: 1 for small launches, 2 / 4 for long contexts x many sequences) is chosen
-    per launch by the host.  The ids and logits must not depend on it: contexts of 9 and 17 splits (one past a page boundary, one
+    how many consecutive splits a block works through (cpb, a launch parameter; default 1, GVL_DECODE_ATTN_CPB overrides) and how many
+    block slots the grid offers are free choices of the host.  The ids and logits must not depend on them: contexts of 9 and 17 splits (one past a page boundary, one
     crossing 4096 tokens where the split count is clamped to 16), forced cpb = 1, 2, 3, 4, 16 against the default choice."""
     import os
     c = dict(hidden=256, inter=512, layers=2, heads=4, kv_heads=4, vocab=320)

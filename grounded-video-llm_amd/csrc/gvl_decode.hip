@@ -110,7 +110,7 @@ int gvl_launch_norm_tiled(bf16_t* x, bf16_t* xn, const bf16_t* w, int batch, int
 // widened to bf16 in registers (exact) and the row scale multiplies the fp32 sum (exact): same arithmetic as bf16 weights holding
 // the de-quantised values, at half the HBM bytes
 template <int RB, int NW, int U, int NT, int XN, int W8>
-__global__ __launch_bounds__(NW * 64, 4) void dgemm_kernel(const GemvArgs a) {   // 4 waves / SIMD (<= 128 VGPRs)
+__global__ __launch_bounds__(NW * 64, U >= 8 ? 2 : 4) void dgemm_kernel(const GemvArgs a) {   // U = 4: 4 waves / SIMD (<= 128 VGPRs); U = 8 (few-block launches): 2
   __shared__ __attribute__((aligned(16))) float red[NW][RB][64][4];
   extern __shared__ __attribute__((aligned(16))) char xs_raw[];                  // XN: [k step][k chunk][batch][8] bf16
   const int tid = threadIdx.x, lane = tid & 63;
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(NW * 64, 4) void dgemm_kernel(const GemvArgs a) {  
   };
   const int groups = steps / U;
   if (groups > 0) request_w(0, 0);               // the first weight tiles do not depend on the activations: in flight during the norm
+                                                 // (requesting the second buffer's tiles here as well: measured +-0)
   if constexpr (XN) {
     // every wave normalises ITS k slice of the (<= 4) residual rows into LDS, B-operand order [step][chunk][batch][8]: element (b, k)
     // at (((k >> 5) * 4 + ((k >> 3) & 3)) * batch + b) * 8 + (k & 7).  Only the 8 slice sums cross waves (one barrier); a wave
@@ -349,7 +350,12 @@ int gvl_launch_dgemm(const GemvArgs& a_in, hipStream_t st) {
   // variant (experiments: GVL_DGEMM_VARIANT = rb*1000 + nw*100 + u*10 + nt; 0 = the measured default)
   static const int env_variant = [] { const char* e = getenv("GVL_DGEMM_VARIANT"); return e ? atoi(e) : 0; }();
   int variant = a.variant ? a.variant : env_variant;
-  if (variant == 0) variant = (a.N >= 16384 ? 2000 : 1000) + 800 + 40 + 1;   // measured (tools/decode_bench.py, profiles/r02_decode_microbench.txt)
+  if (variant == 0) {                              // measured (tools/decode_bench.py, profiles/r02_decode_microbench.txt)
+    variant = (a.N >= 16384 ? 2000 : 1000) + 800 + 40 + 1;
+    // few blocks x long k (Phi down_proj: 192 blocks of 32 k steps per wave): 8-step load groups at 2 waves / SIMD keep twice the bytes
+    // in flight per wave, 12.3 -> 11.3 us; every other shape is slower with them (more blocks than slots already).  Same MFMA order.
+    if (!a.w_fp8 && !a.norm_w && a.N <= 3072 && a.K >= 8192 && a.K % 2048 == 0) variant = 1881;
+  }
   const int RB = variant / 1000, NW = (variant / 100) % 10;
   if (a.K % (NW * 32)) return -1;
   const int blocks = (a.N + 16 * RB - 1) / (16 * RB);
@@ -360,7 +366,7 @@ int gvl_launch_dgemm(const GemvArgs& a_in, hipStream_t st) {
 #define DG_CASE(rb, nw, u, nt, xn, w8) case (rb * 1000 + nw * 100 + u * 10 + nt) * 100 + xn * 10 + w8: \
       hipLaunchKernelGGL((dgemm_kernel<rb, nw, u, nt, xn, w8>), dim3(blocks), dim3(nw * 64), lds, st, a); break;
     DG_CASE(1, 8, 4, 1, 0, 0) DG_CASE(2, 8, 4, 1, 0, 0) DG_CASE(1, 4, 4, 1, 0, 0) DG_CASE(2, 4, 4, 1, 0, 0) DG_CASE(1, 8, 2, 1, 0, 0) DG_CASE(2, 8, 2, 1, 0, 0)
-    DG_CASE(1, 8, 4, 1, 1, 0) DG_CASE(2, 8, 4, 1, 1, 0)
+    DG_CASE(1, 8, 4, 1, 1, 0) DG_CASE(2, 8, 4, 1, 1, 0) DG_CASE(1, 8, 8, 1, 0, 0)
     DG_CASE(1, 8, 4, 1, 0, 1) DG_CASE(2, 8, 4, 1, 0, 1) DG_CASE(1, 8, 4, 1, 1, 1) DG_CASE(2, 8, 4, 1, 1, 1)
 #undef DG_CASE
     default: return -1;

@@ -74,7 +74,7 @@ struct gvl_ctx {
   bool decode_mfma = false;          // geometry allows the skinny MFMA GEMM decode path (K % 256 == 0 for every projection)
   const bf16_t* l_headd = nullptr;   // lm_head in tile order
   const float* l_heads = nullptr;    // its FP8 row scales
-  bool fp8 = false;                  // the decode copies are FP8 (cfg.decode_fp8 and the geometry allows it)
+  int fp8 = 0;                       // format of the decode copies: 0 bf16, 1 FP8 e4m3 + row scales, 2 MXFP4 (cfg.decode_fp8 and the geometry allows it)
   std::vector<void*> dw_allocs;      // tile-order weight copies owned by the ctx
   // (all decode work buffers hold GVL_MAX_DECODE_BATCH rows: one per sequence of a batched decode step)
   float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_seq_tok = nullptr, *d_seq_out = nullptr;

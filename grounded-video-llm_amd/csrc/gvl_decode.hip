@@ -108,7 +108,10 @@ int gvl_launch_norm_tiled(bf16_t* x, bf16_t* xn, const bf16_t* w, int batch, int
 // NT: weight loads carry the non-temporal hint; XN: the B operand is RMS-normalised by this block into LDS (batch <= 4, a.x row-major);
 // W8: the weights are the FP8 (OCP e4m3, per-row power-of-two scale) tile copy -- 16 bytes per lane feed TWO k steps; the values are
 // widened to bf16 in registers (exact) and the row scale multiplies the fp32 sum (exact): same arithmetic as bf16 weights holding
-// the de-quantised values, at half the HBM bytes
+// the de-quantised values, at half the HBM bytes.  W8 = 2: the MXFP4 tile copy (OCP Microscaling v1.0: E2M1 elements, one
+// E8M0 scale per 32 consecutive k = one k step of one row) -- 16 bytes per lane feed FOUR k steps plus one 4-byte word of scales;
+// v_cvt_scalef32_pk_bf16_fp4 widens two elements per instruction (exact: <= 2 significant bits times a power of two); a quarter of
+// the HBM bytes.
 template <int RB, int NW, int U, int NT, int XN, int W8>
 __global__ __launch_bounds__(NW * 64, U >= 8 ? 2 : 4) void dgemm_kernel(const GemvArgs a) {   // U = 4: 4 waves / SIMD (<= 128 VGPRs); U = 8 (few-block launches): 2
   __shared__ __attribute__((aligned(16))) float red[NW][RB][64][4];
@@ -124,13 +127,17 @@ __global__ __launch_bounds__(NW * 64, U >= 8 ? 2 : 4) void dgemm_kernel(const Ge
   const int steps = kw >> 5;
   const int nkt = a.K >> 5;                      // k steps per row block
   const bf16_t* wp[RB];
+  const unsigned* sp[RB];                        // MXFP4: this lane's scale words (row i of the row block; one word = 4 consecutive k steps)
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
+    sp[rb] = nullptr;
     int rbk = blockIdx.x * RB + rb;
     const int rbk_max = (a.N + 15) / 16 - 1;
     rbk = rbk < rbk_max ? rbk : rbk_max;         // a block past the end re-reads the last row block; its rows are never stored
-    wp[rb] = W8 ? (const bf16_t*)((const char*)a.W + ((size_t)rbk * nkt + (size_t)wave * steps) * 512 + lane * 16)   // 512 bytes per k step
-                : a.W + ((size_t)rbk * nkt + (size_t)wave * steps) * 512 + lane * 8;
+    wp[rb] = W8 == 2 ? (const bf16_t*)((const char*)a.W + ((size_t)rbk * nkt + (size_t)wave * steps) * 256 + lane * 16)   // 256 bytes per k step
+           : W8 == 1 ? (const bf16_t*)((const char*)a.W + ((size_t)rbk * nkt + (size_t)wave * steps) * 512 + lane * 16)   // 512 bytes per k step
+                     : a.W + ((size_t)rbk * nkt + (size_t)wave * steps) * 512 + lane * 8;
+    if constexpr (W8 == 2) sp[rb] = (const unsigned*)a.wscale + ((size_t)rbk * nkt + (size_t)wave * steps) * 4 + i;   // [row block][4 steps][16 rows] words
   }
   // B columns >= batch re-read the LAST sequence's chunk: a D column depends on its own B column only and those columns
   // are never stored, so no masking is needed in the loop (the duplicate addresses coalesce / broadcast)
@@ -154,8 +161,24 @@ __global__ __launch_bounds__(NW * 64, U >= 8 ? 2 : 4) void dgemm_kernel(const Ge
     return __builtin_bit_cast(bf16x8_t, p);
   };
   u32x4_t w8[2][U / 2][RB];                       // W8: raw 16-byte pieces (two k steps each), widened at consumption
+  u32x4_t w4[2][RB]; unsigned s4[2][RB];          // MXFP4: one 16-byte piece (four k steps) + their four E8M0 scales per load group
+  static_assert(W8 != 2 || U == 4, "MXFP4: a load group is exactly one 16-byte piece");
+  auto widen4 = [](unsigned word, unsigned e8) {  // 8 E2M1 nibbles x 2^(e8 - 127) -> 8 bf16, exact
+    typedef __bf16 bf16x2v_t __attribute__((ext_vector_type(2)));
+    const float sc = __uint_as_float(e8 << 23);
+    const bf16x2v_t p0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(word, sc, 0), p1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(word, sc, 1);
+    const bf16x2v_t p2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(word, sc, 2), p3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(word, sc, 3);
+    const u32x4_t p = {__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1), __builtin_bit_cast(unsigned, p2), __builtin_bit_cast(unsigned, p3)};
+    return __builtin_bit_cast(bf16x8_t, p);
+  };
   auto request_w = [&](int buf, int s) {
-    if constexpr (W8) {
+    if constexpr (W8 == 2) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        w4[buf][rb] = __builtin_nontemporal_load((const u32x4_t*)((const char*)wp[rb] + (size_t)(s / 4) * 1024));
+        s4[buf][rb] = sp[rb][(size_t)(s / 4) * 16];
+      }
+    } else if constexpr (W8 == 1) {
 #pragma unroll
       for (int u = 0; u < U / 2; ++u)
 #pragma unroll
@@ -178,7 +201,8 @@ __global__ __launch_bounds__(NW * 64, U >= 8 ? 2 : 4) void dgemm_kernel(const Ge
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         bf16x8_t wa;
-        if constexpr (W8) wa = (u & 1) ? widen(w8[buf][u / 2][rb][2], w8[buf][u / 2][rb][3]) : widen(w8[buf][u / 2][rb][0], w8[buf][u / 2][rb][1]);
+        if constexpr (W8 == 2) wa = widen4(w4[buf][rb][u], (s4[buf][rb] >> (8 * u)) & 255u);
+        else if constexpr (W8 == 1) wa = (u & 1) ? widen(w8[buf][u / 2][rb][2], w8[buf][u / 2][rb][3]) : widen(w8[buf][u / 2][rb][0], w8[buf][u / 2][rb][1]);
         else wa = wv[buf][u][rb];
         acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xv[buf][u], acc[rb], 0, 0, 0);
       }
@@ -234,7 +258,9 @@ __global__ __launch_bounds__(NW * 64, U >= 8 ? 2 : 4) void dgemm_kernel(const Ge
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       bf16x8_t wa;
-      if constexpr (W8) {                          // (steps is even in W8 mode: K % 512 == 0)
+      if constexpr (W8 == 2) {                     // (never taken: K % 1024 == 0 makes steps a multiple of U = 4)
+        wa = widen4(*(const unsigned*)((const char*)wp[rb] + (size_t)(s0 / 4) * 1024 + (s0 & 3) * 4), (sp[rb][(size_t)(s0 / 4) * 16] >> (8 * (s0 & 3))) & 255u);
+      } else if constexpr (W8 == 1) {              // (steps is even in W8 mode: K % 512 == 0)
         const u32x2_t piece = *(const u32x2_t*)((const char*)wp[rb] + (size_t)(s0 / 2) * 1024 + (s0 & 1) * 8);
         wa = widen(piece[0], piece[1]);
       } else wa = __builtin_nontemporal_load((const bf16x8_t*)(wp[rb] + s0 * 512));
@@ -255,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, U >= 8 ? 2 : 4) void dgemm_kernel(const Ge
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = q[r];
     }
-    if constexpr (W8) {                           // per-row power-of-two scale of the FP8 copy (exact in fp32)
+    if constexpr (W8 == 1) {                      // per-row power-of-two scale of the FP8 copy (exact in fp32)
       const int n4 = n0 + rb * 16 + g * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] *= a.wscale[n4 + r < a.N ? n4 + r : a.N - 1];
@@ -360,14 +386,15 @@ int gvl_launch_dgemm(const GemvArgs& a_in, hipStream_t st) {
   if (a.K % (NW * 32)) return -1;
   const int blocks = (a.N + 16 * RB - 1) / (16 * RB);
   const size_t lds = a.norm_w ? (size_t)a.batch * a.K * 2 : 0;
-  if (a.w_fp8 && (a.K % 512 || !a.wscale)) return -1;
-  const int key = variant * 100 + (a.norm_w ? 10 : 0) + (a.w_fp8 ? 1 : 0);
+  if (a.w_fp8 < 0 || a.w_fp8 > 2 || (a.w_fp8 && (a.K % (a.w_fp8 == 2 ? 1024 : 512) || !a.wscale))) return -1;
+  const int key = variant * 100 + (a.norm_w ? 10 : 0) + a.w_fp8;
   switch (key) {
 #define DG_CASE(rb, nw, u, nt, xn, w8) case (rb * 1000 + nw * 100 + u * 10 + nt) * 100 + xn * 10 + w8: \
       hipLaunchKernelGGL((dgemm_kernel<rb, nw, u, nt, xn, w8>), dim3(blocks), dim3(nw * 64), lds, st, a); break;
     DG_CASE(1, 8, 4, 1, 0, 0) DG_CASE(2, 8, 4, 1, 0, 0) DG_CASE(1, 4, 4, 1, 0, 0) DG_CASE(2, 4, 4, 1, 0, 0) DG_CASE(1, 8, 2, 1, 0, 0) DG_CASE(2, 8, 2, 1, 0, 0)
     DG_CASE(1, 8, 4, 1, 1, 0) DG_CASE(2, 8, 4, 1, 1, 0) DG_CASE(1, 8, 8, 1, 0, 0)
     DG_CASE(1, 8, 4, 1, 0, 1) DG_CASE(2, 8, 4, 1, 0, 1) DG_CASE(1, 8, 4, 1, 1, 1) DG_CASE(2, 8, 4, 1, 1, 1)
+    DG_CASE(1, 8, 4, 1, 0, 2) DG_CASE(2, 8, 4, 1, 0, 2) DG_CASE(1, 8, 4, 1, 1, 2) DG_CASE(2, 8, 4, 1, 1, 2)
 #undef DG_CASE
     default: return -1;
   }
@@ -474,6 +501,86 @@ __global__ void fp8_requant_retile_kernel(bf16_t* __restrict__ W, unsigned char*
     }
     *(u32x4_t*)(Wt8 + (size_t)idx * 16) = out;
   }
+}
+// ---- MXFP4 (OCP Microscaling Formats v1.0 [ext]: E2M1 elements {0, .5, 1, 1.5, 2, 3, 4, 6} x sign, one E8M0 scale 2^(e - 127) per block of
+// 32 consecutive k of one row).  Scale: e = floor(log2(max|w|)) - 2 + 127 (emax of E2M1 is 2), clamped to [0, 254], 0 for an all-zero
+// block; elements: round to nearest, ties to the even code, saturating at 6.  Written out in plain comparisons (the CPU restatement in
+// the tests follows it line by line) rather than through v_cvt_scalef32_pk_fp4_f32.
+// Scale words: [row block][k step / 4][16 rows] u32, byte j = the scale of k step 4 (s / 4) + j.
+__device__ __forceinline__ unsigned mx_e2m1_code(float v, float inv) {
+  const float t = fabsf(v) * inv;                 // exact: inv is a power of two
+  const unsigned c = t <= 0.25f ? 0u : t < 0.75f ? 1u : t <= 1.25f ? 2u : t < 1.75f ? 3u : t <= 2.5f ? 4u : t < 3.5f ? 5u : t <= 5.0f ? 6u : 7u;
+  return c | ((__float_as_uint(v) >> 31) << 3);
+}
+__device__ __forceinline__ float mx_e2m1_value(unsigned code) {
+  const unsigned c = code & 7u;
+  const float m = c < 2u ? 0.5f * (float)c : ldexpf(1.f + 0.5f * (float)(c & 1u), (int)(c >> 1) - 1);   // 0, .5 | 1, 1.5, 2, 3, 4, 6
+  return (code & 8u) ? -m : m;
+}
+__global__ void mxfp4_scale_kernel(const bf16_t* __restrict__ W, unsigned char* __restrict__ scale, int N, int K, int Dr, int n_qk_heads) {
+  const int nkt = K / 32;
+  const long total = (long)((N + 15) / 16) * 16 * nkt;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int s = (int)(idx % nkt); const int n = (int)(idx / nkt);
+    unsigned e = 0;
+    if (n < N) {
+      const bf16_t* src = W + (size_t)decode_row_perm(n, N, Dr, n_qk_heads) * K + s * 32;
+      float m = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const u32x4_t v = *(const u32x4_t*)(src + c * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m = fmaxf(m, fmaxf(fabsf(lo_bf(v[q])), fabsf(hi_bf(v[q]))));
+      }
+      const int ef = (int)((__float_as_uint(m) >> 23) & 255u) - 2;          // exponent field of max|w| minus emax(E2M1)
+      e = m > 0.f ? (unsigned)(ef < 0 ? 0 : (ef > 254 ? 254 : ef)) : 0u;
+    }
+    scale[(((size_t)(n >> 4) * (nkt / 4) + (s >> 2)) * 16 + (n & 15)) * 4 + (s & 3)] = (unsigned char)e;
+  }
+}
+// one thread per 16-byte piece of the tile copy [row block][k step / 4][64 lanes][16]: word j = the lane's 8 elements (k chunk l >> 4) of
+// k step 4 sg + j, element t in nibble t; the source elements are overwritten with their de-quantised values
+__global__ void mxfp4_requant_retile_kernel(bf16_t* __restrict__ W, unsigned char* __restrict__ Wt4, const unsigned* __restrict__ scale, int N, int K, int Dr, int n_qk_heads) {
+  const int nsg = K / 128;
+  const long total = (long)((N + 15) / 16) * nsg * 64;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int l = (int)(idx & 63);
+    const long tile = idx >> 6;
+    const int sg = (int)(tile % nsg), rbk = (int)(tile / nsg);
+    const int n = rbk * 16 + (l & 15);
+    u32x4_t out = {0u, 0u, 0u, 0u};
+    if (n < N) {
+      const unsigned sw = scale[((size_t)rbk * nsg + sg) * 16 + (l & 15)];
+      bf16_t* row = W + (size_t)decode_row_perm(n, N, Dr, n_qk_heads) * K;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned e = (sw >> (8 * j)) & 255u;
+        const float sc = __uint_as_float(e << 23), inv = __uint_as_float((254u - e) << 23);     // 2^(e-127) and its reciprocal (e = 0: block of zeros)
+        bf16_t* src = row + (4 * sg + j) * 32 + (l >> 4) * 8;
+        const u32x4_t v = *(const u32x4_t*)src;
+        unsigned word = 0; u32x4_t back;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned c0 = e ? mx_e2m1_code(lo_bf(v[q]), inv) : 0u, c1 = e ? mx_e2m1_code(hi_bf(v[q]), inv) : 0u;
+          word |= (c0 | (c1 << 4)) << (8 * q);
+          back[q] = pack2bf(mx_e2m1_value(c0) * sc, mx_e2m1_value(c1) * sc);
+        }
+        out[j] = word;
+        *(u32x4_t*)src = back;
+      }
+    }
+    *(u32x4_t*)(Wt4 + (size_t)idx * 16) = out;
+  }
+}
+int gvl_mxfp4_quantise_decode_weight(bf16_t* W, unsigned char* Wt4, unsigned* scale, int N, int K, int Dr, int n_qk_heads, hipStream_t st) {
+  if (K % 1024 || N <= 0) return -1;
+  { const long total = (long)((N + 15) / 16) * 16 * (K / 32);
+    long blocks = (total + 255) / 256; if (blocks > 65535 * 8) blocks = 65535 * 8;
+    hipLaunchKernelGGL(mxfp4_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, st, W, (unsigned char*)scale, N, K, Dr, n_qk_heads); }
+  { const long total = (long)((N + 15) / 16) * (K / 128) * 64;
+    long blocks = (total + 255) / 256; if (blocks > 65535 * 8) blocks = 65535 * 8;
+    hipLaunchKernelGGL(mxfp4_requant_retile_kernel, dim3((unsigned)blocks), dim3(256), 0, st, W, Wt4, scale, N, K, Dr, n_qk_heads); }
+  return CHECK_LAUNCH();
 }
 int gvl_fp8_quantise_decode_weight(bf16_t* W, unsigned char* Wt8, float* scale, int N, int K, int Dr, int n_qk_heads, hipStream_t st) {
   if (K % 512 || N <= 0) return -1;

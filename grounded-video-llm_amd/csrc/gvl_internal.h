@@ -213,7 +213,8 @@ struct GemvArgs {
   const int* pos_ptrs[GVL_MAX_DECODE_BATCH]; const int* tables[GVL_MAX_DECODE_BATCH];   // per sequence of the batch
   bf16_t *Q, *Kt, *Vt; int H, KV, Dr, D; int q_stride;
   int variant;                    // skinny-GEMM path: kernel variant (0 = default; tools/decode_bench.py)
-  int w_fp8; const float* wscale; // skinny-GEMM path: W is the FP8 tile copy, wscale[N] its per-row power-of-two scales
+  int w_fp8; const float* wscale; // skinny-GEMM path: 1 = W is the FP8 tile copy, wscale[N] its per-row power-of-two scales; 2 = the MXFP4 tile
+                                  // copy, wscale = its E8M0 scale words (gvl_mxfp4_quantise_decode_weight)
   int out_tiled;                  // skinny-GEMM path: the SwiGLU epilogue writes out_bf16 in B-operand tile order (it feeds down_proj)
 };
 // B-operand tile order of the decode activations: element (sequence j < 16, column k) of a [16][cols] matrix lives at
@@ -222,6 +223,8 @@ __host__ __device__ __forceinline__ size_t gvl_xt_index(int j, int k) { return (
 int gvl_retile_decode_weight(const bf16_t* W, bf16_t* Wt, int N, int K, int Dr, int n_qk_heads, hipStream_t st);
 // FP8 variant: scale[n] (per logical row, power of two), Wt8 = e4m3 tile copy, and W (row-major bf16) REPLACED by its de-quantised values
 int gvl_fp8_quantise_decode_weight(bf16_t* W, unsigned char* Wt8, float* scale, int N, int K, int Dr, int n_qk_heads, hipStream_t st);
+// MXFP4 twin: Wt4 [ceil(N/16)][K/128][64][16] bytes, scale [ceil(N/16)][K/128][16] words of four E8M0 bytes; W is replaced by the de-quantised values
+int gvl_mxfp4_quantise_decode_weight(bf16_t* W, unsigned char* Wt4, unsigned* scale, int N, int K, int Dr, int n_qk_heads, hipStream_t st);
 int gvl_launch_rows_to_tiled(const bf16_t* x, bf16_t* xt, int batch, int cols, int stride, hipStream_t st);
 int gvl_launch_gemv(const GemvArgs& a, hipStream_t st);
 // the same projection as ONE MFMA skinny GEMM for 1..16 sequences (gvl_decode.hip); -1 when the geometry needs the VALU kernel

@@ -379,7 +379,7 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
     } }
   auto proj = [&](GemvArgs& g, const float* wscale) {
     if (!mfma) return gvl_launch_gemv(g, st);
-    if (ctx->fp8) { g.w_fp8 = 1; g.wscale = wscale; }
+    if (ctx->fp8) { g.w_fp8 = ctx->fp8; g.wscale = wscale; }
     return gvl_launch_dgemm(g, st);
   };
   auto normed_input = [&](GemvArgs& g, const bf16_t* w) {       // the projection reads rmsnorm(d_x) * w
@@ -690,26 +690,33 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
     // is baked in): 288 GB of HBM pay for the second copy of the LLM -- the prefill GEMM keeps the row-major one
     for (void* p : ctx->dw_allocs) if (p) hipFree(p);
     ctx->dw_allocs.clear();
-    ctx->fp8 = false;
+    ctx->fp8 = 0;
     if (f.decode_fp8) {
-      if (!ctx->decode_mfma || Hd % 512 || I % 512 || (f.heads * Dr) % 512)
-        return fail(ctx, GVL_ERR_ARG, "cfg.decode_fp8 needs hidden, inter and heads*head_dim to be multiples of 512 (skinny-GEMM decode path)");
-      ctx->fp8 = true;
+      if (f.decode_fp8 != 1 && f.decode_fp8 != 2) return fail(ctx, GVL_ERR_ARG, "cfg.decode_fp8: 0 = bf16, 1 = FP8 e4m3, 2 = MXFP4");
+      const int mult = f.decode_fp8 == 2 ? 1024 : 512;
+      if (!ctx->decode_mfma || Hd % mult || I % mult || (f.heads * Dr) % mult)
+        return fail(ctx, GVL_ERR_ARG, "cfg.decode_fp8 needs hidden, inter and heads*head_dim to be multiples of 512 (FP8) / 1024 (MXFP4) (skinny-GEMM decode path)");
+      ctx->fp8 = f.decode_fp8;
     }
     if (ctx->decode_mfma) {
-      // bf16: a re-tiled copy.  FP8: per-row scales + the e4m3 tile copy, and the row-major weight is replaced by its de-quantised values
+      // bf16: a re-tiled copy.  FP8: per-row scales + the e4m3 tile copy.  MXFP4: E8M0 block scales + the E2M1 tile copy.  In both
+      // quantised formats the row-major weight is replaced by its de-quantised values (prefill and decode evaluate ONE model).
       auto tiled = [&](const bf16_t* W, int N, int K, int dr, int nqk, const bf16_t** out, const float** sc_out) -> int {
         void* p = nullptr;
-        const size_t bytes = (size_t)((N + 15) / 16) * 16 * K * (ctx->fp8 ? 1 : 2);
+        const size_t n16 = (size_t)((N + 15) / 16) * 16;
+        const size_t bytes = ctx->fp8 == 2 ? n16 * K / 2 : n16 * K * (ctx->fp8 ? 1 : 2);
         if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, GVL_ERR_OOM, "hipMalloc(decode weight copy) failed"); }
         ctx->dw_allocs.push_back(p);
         *out = (const bf16_t*)p;
         if (ctx->fp8) {
           void* sc = nullptr;
-          if (hipMalloc(&sc, (size_t)N * 4) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, GVL_ERR_OOM, "hipMalloc(fp8 scales) failed"); }
+          const size_t sbytes = ctx->fp8 == 2 ? n16 * (K / 32) : (size_t)N * 4;
+          if (hipMalloc(&sc, sbytes) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, GVL_ERR_OOM, "hipMalloc(weight scales) failed"); }
           ctx->dw_allocs.push_back(sc);
           *sc_out = (const float*)sc;
-          if (gvl_fp8_quantise_decode_weight(const_cast<bf16_t*>(W), (unsigned char*)p, (float*)sc, N, K, dr, nqk, nullptr)) return fail(ctx, GVL_ERR_HIP, "fp8 quantise launch failed");
+          const int qrc = ctx->fp8 == 2 ? gvl_mxfp4_quantise_decode_weight(const_cast<bf16_t*>(W), (unsigned char*)p, (unsigned*)sc, N, K, dr, nqk, nullptr)
+                                        : gvl_fp8_quantise_decode_weight(const_cast<bf16_t*>(W), (unsigned char*)p, (float*)sc, N, K, dr, nqk, nullptr);
+          if (qrc) return fail(ctx, GVL_ERR_HIP, "weight quantise launch failed");
         } else {
           *sc_out = nullptr;
           if (gvl_retile_decode_weight(W, (bf16_t*)p, N, K, dr, nqk, nullptr)) return fail(ctx, GVL_ERR_HIP, "retile launch failed");

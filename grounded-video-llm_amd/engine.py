@@ -52,7 +52,8 @@ class TowerGeometry:
     max_segs: int = 12
     kv_pages: int = 128
     max_prefill: int = 4096
-    decode_fp8: bool = False                 # FP8 (e4m3, per-row power-of-two scale) weight variant of the LLM: opt-in, not the reference's numerics
+    decode_fp8: int = 0                      # quantised weight variant of the LLM (opt-in, not the reference's numerics): 1 / True = FP8 e4m3 with per-row
+                                             # power-of-two scales, 2 = MXFP4 (E2M1 elements, E8M0 scale per 32 k); 0 = bf16
 
     @property
     def kind(self) -> str:
@@ -123,7 +124,7 @@ class Engine:
             cfg.rope_orig_max_pos = geo.rope_orig_max_pos if geo.rope_long is not None else 0
             cfg.max_seq = geo.max_seq
             cfg.kv_pages, cfg.max_prefill = geo.kv_pages, geo.max_prefill
-            cfg.decode_fp8 = 1 if geo.decode_fp8 else 0
+            cfg.decode_fp8 = int(geo.decode_fp8)
         cfg.max_segs = geo.max_segs
         self.cfg = cfg
         self.towers = tuple(towers)

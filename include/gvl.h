@@ -58,10 +58,12 @@ typedef struct {
   int32_t max_segs;            /* largest number of segments per encode call on this rank */
   int32_t kv_pages;            /* pages (64 tokens each, all layers) in the paged KV pool */
   int32_t max_prefill;         /* largest prefill length (rows of the activation workspace) */
-  int32_t decode_fp8;          /* 1: FP8 weight variant of the LLM: every decoder projection and lm_head is quantised at
-                                  gvl_finalize_weights to OCP e4m3 with a per-row power-of-two scale; the decode path streams the FP8 copy
-                                  (half the bytes), the prefill path uses the de-quantised bf16 values -- ONE model, not the reference's
-                                  numerics (opt-in; needs hidden / inter / heads*head_dim multiples of 512) */
+  int32_t decode_fp8;          /* quantised weight variants of the LLM, opt-in, NOT the reference's numerics.  0: bf16.
+                                  1: FP8 -- every decoder projection and lm_head is quantised at gvl_finalize_weights to OCP e4m3 with a
+                                  per-row power-of-two scale; the decode path streams the FP8 copy (half the bytes).  2: MXFP4 (OCP
+                                  Microscaling v1.0: E2M1 elements, one E8M0 scale per 32 consecutive k) -- a quarter of the bytes.
+                                  In both the prefill path uses the de-quantised bf16 values: ONE model.  Needs hidden / inter /
+                                  heads*head_dim multiples of 512 (FP8) / 1024 (MXFP4). */
 } gvl_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -797,15 +797,41 @@ def fp8_pow2_dequant(w: torch.Tensor) -> torch.Tensor:
     return (w / s).to(torch.float8_e4m3fn).float() * s
 
 
-def fp8_weight_model(W: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+def fp8_weight_model(W: Dict[str, torch.Tensor], dequant=None) -> Dict[str, torch.Tensor]:
     """State dict of the FP8-variant model: decoder projections and lm_head.weight de-quantised, everything else untouched."""
+    dequant = dequant or fp8_pow2_dequant
     out = {}
     for k, v in W.items():
         if k == "lm_head.weight" or (k.endswith(".weight") and any(k.endswith(p + ".weight") for p in _FP8_PROJ)):
-            out[k] = fp8_pow2_dequant(v)
+            out[k] = dequant(v)
         else:
             out[k] = v
     return out
+
+
+_E2M1 = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0)
+
+
+def mxfp4_dequant(w: torch.Tensor) -> torch.Tensor:
+    """w [N, K] (bf16 values, K % 32 == 0) -> MXFP4 round trip, OCP Microscaling Formats v1.0 [ext]: blocks of 32 consecutive k of one
+    row share an E8M0 scale X = 2^(floor(log2(max|w|)) - 2) (emax of E2M1 = 2; an all-zero block stays zero); elements = w / X rounded
+    to the nearest E2M1 value {0, .5, 1, 1.5, 2, 3, 4, 6}, ties to the even code, saturating at 6.  The result is exact in bf16."""
+    w = w.to(torch.bfloat16).float()
+    N, K = w.shape
+    b = w.view(N, K // 32, 32)
+    amax = b.abs().amax(dim=2, keepdim=True)
+    _, ex = torch.frexp(amax)                                   # amax = m * 2^ex, m in [0.5, 1)  =>  floor(log2 amax) = ex - 1
+    X = torch.ldexp(torch.ones_like(amax), ex - 1 - 2)
+    t = torch.where(amax > 0, b.abs() / X, torch.zeros_like(b))
+    grid = torch.tensor(_E2M1)
+    # ties go to the even CODE (index): 0.25 -> 0, 0.75 -> 1.0, 1.25 -> 1.0, 1.75 -> 2.0, 2.5 -> 2.0, 3.5 -> 4.0, 5.0 -> 4.0
+    code = (t > 0.25).long() + (t >= 0.75).long() + (t > 1.25).long() + (t >= 1.75).long() + (t > 2.5).long() + (t >= 3.5).long() + (t > 5.0).long()
+    q = grid[code] * X * torch.sign(b)
+    return torch.where(amax > 0, q, torch.zeros_like(q)).view(N, K)
+
+
+def mxfp4_weight_model(W: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    return fp8_weight_model(W, mxfp4_dequant)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -454,17 +454,22 @@ def test_decode_groups_up_to_16_are_bit_identical_to_single_at_full_width():
     eng.close()
 
 
-def test_fp8_weight_variant_matches_the_dequantised_model():
-    """SURVEY §8 f3 'FP8 weight variants' (opt-in, cfg.decode_fp8): every decoder projection and lm_head is quantised on the device to
-    OCP e4m3 with a per-row power-of-two scale; decode streams the FP8 tile copy (half the bytes), prefill uses the de-quantised
-    bf16 values -- ONE model.  Checked against the ordinary oracle forward on W_q = oracle.fp8_weight_model(W): prefill logits,
-    teacher-forced decode steps through the FP8 stream, and greedy ids; and the quantisation must actually change the logits."""
-    c = dict(hidden=512, inter=1024, layers=2, heads=8, kv_heads=8, vocab=640)
+@pytest.mark.parametrize("fmt", ["fp8", "mxfp4"])
+def test_fp8_weight_variant_matches_the_dequantised_model(fmt):
+    """SURVEY §8 f3 'FP8 / MXFP4 weight variants' (opt-in, cfg.decode_fp8 = 1 / 2): every decoder projection and lm_head is quantised on
+    the device -- FP8: OCP e4m3 with a per-row power-of-two scale, decode streams half the bytes; MXFP4: OCP Microscaling E2M1 elements
+    with one E8M0 scale per 32 consecutive k, a quarter of the bytes -- and prefill uses the de-quantised bf16 values: ONE model.
+    Checked against the ordinary oracle forward on W_q = oracle.fp8_weight_model(W) / mxfp4_weight_model(W): prefill logits,
+    teacher-forced decode steps through the quantised stream, and greedy ids; and the quantisation must actually change the logits."""
+    if fmt == "fp8":
+        c = dict(hidden=512, inter=1024, layers=2, heads=8, kv_heads=8, vocab=640)
+    else:                       # the MXFP4 tile copy needs every K to be a multiple of 1024
+        c = dict(hidden=1024, inter=2048, layers=2, heads=8, kv_heads=8, vocab=640)
     geo = _phi_geo(c, max_seq=256, max_prefill=128, kv_pages=8)
-    geo.decode_fp8 = True
+    geo.decode_fp8 = 1 if fmt == "fp8" else 2
     W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.fp8")
     eng = llm_engine(geo, W)
-    Wq = O.fp8_weight_model(W)
+    Wq = O.fp8_weight_model(W) if fmt == "fp8" else O.mxfp4_weight_model(W)
     ocfg = _ocfg(geo)
     x = synth.det_tensor("t.fp8.x", (40, c["hidden"]), 0.5)
     seq = eng.seq_alloc(64)
@@ -475,9 +480,9 @@ def test_fp8_weight_variant_matches_the_dequantised_model():
     base32 = O.llm_forward(ocfg, W, x, False, None, 0, last_only=True)[0]
     scale = float(ref32.abs().max())
     qerr = float((ref32 - base32).abs().max()) / scale
-    print(f"[parity] FP8 variant: quantisation itself moves the logits by {qerr:.2e} of the scale")
+    print(f"[parity] {fmt} variant: quantisation itself moves the logits by {qerr:.2e} of the scale")
     assert qerr > 2e-2, "the FP8 quantiser does not change this model: the test would prove nothing"
-    check_bf16_class(got, ref32, ref_emu, 1e-2, "FP8 variant: prefill logits (de-quantised bf16 weights) vs oracle on W_q (fp32)")
+    check_bf16_class(got, ref32, ref_emu, 1e-2, f"{fmt} variant: prefill logits (de-quantised bf16 weights) vs oracle on W_q (fp32)")
     e = Wq["model.embed_tokens.weight"].to(bf).float()
     n = x.shape[0]
     for step, tok in enumerate((5, 77, 300, 12)):
@@ -485,7 +490,7 @@ def test_fp8_weight_variant_matches_the_dequantised_model():
         r_emu = O.llm_forward(ocfg, Wq, e[tok][None], True, cache, n, last_only=True)[0]
         r32 = O.llm_forward(ocfg, Wq, e[tok][None], False, cache32, n, last_only=True)[0]
         n += 1
-        check_bf16_class(lg, r32, r_emu, 1e-2, f"FP8 variant: decode step {step} (FP8 weight stream) vs oracle on W_q (fp32)")
+        check_bf16_class(lg, r32, r_emu, 1e-2, f"{fmt} variant: decode step {step} (quantised weight stream) vs oracle on W_q (fp32)")
     eng.seq_free(seq)
     ids = eng.generate_ids(x.to(DEV).to(bf), 8, None)
     ref_ids, margins = O.greedy_generate(ocfg, Wq, x.to(bf).float(), 8, None, emu=True, return_margins=True)

@@ -16,9 +16,11 @@ if which == "phi":
 else:
     geo = E.TowerGeometry.llama3_8b(max_seq=4096, max_prefill=3712, kv_pages=0, max_segs=1)
     kind, wbytes, kv_per_tok = "llama", 15.0e9, 131072
-geo.decode_fp8 = os.environ.get("GVL_FP8", "0") == "1"          # FP8 weight variant (cfg.decode_fp8): half the weight bytes per step
-if geo.decode_fp8:
+geo.decode_fp8 = int(os.environ.get("GVL_FP8", "0"))           # quantised weight variant (cfg.decode_fp8): 1 = FP8 (half the weight bytes per step), 2 = MXFP4 (a quarter + 1/32 of scales)
+if geo.decode_fp8 == 1:
     wbytes /= 2
+elif geo.decode_fp8 == 2:
+    wbytes *= (0.5 + 1.0 / 32) / 2
 eng = E.Engine(geo, dev, towers=("llm",))
 W = synth.llm_weights(kind, geo.hidden, geo.inter, geo.layers, geo.heads, geo.kv_heads, geo.vocab, True, seed="d2e", device=dev)
 eng.load_packed(Wt.pack_llm(W, kind, geo.layers, geo.heads, geo.kv_heads, geo.max_seq, geo.rope_theta, geo.rope_short, geo.rope_long)); del W

@@ -510,10 +510,246 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const DecodeAttnArg
   if (tid == 0) __hip_atomic_store(counters_b + head0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
 }
 
+// =====================================================================================================
+// decode attention for GROUPED-query models on the matrix pipe (Llama-3: 32 query heads on 8 KV heads, G = 4)
+// =====================================================================================================
+// The per-head kernel above runs the G query heads of a KV head as G blocks: every page is fetched G times (from L2) and the
+// dot products are G x VALU work; with 231 VGPRs at D = 128 only two blocks fit a CU, so 16 sequences at 3.5 k context (7168 blocks)
+// ran 14 rounds of a latency-bound block: 109 us per layer for 231 MB of KV (2.1 TB/s).  Here ONE block per (KV head, split, sequence)
+// serves the whole group, and the page layouts are already MFMA operands:
+//   S = Q K^T : A = Q  [16 heads (rows >= G zero) x 32 d]  lane (l & 15) = head, (l >> 4) = 8-wide d chunk   (16 B of Q)
+//               B = K^T [32 d x 16 keys]                  lane (l & 15) = key,  (l >> 4) = d chunk            (16 B of the K page row)
+//   O += P V  : A = P  [16 heads x 32 keys]  (bf16, through LDS: the C layout has keys on lanes, A wants 8 consecutive keys per lane)
+//               B = V  [32 keys x 16 d]                   lane (l & 15) = d,    (l >> 4) = 8-wide key chunk   (16 B of the V^T page row)
+// C layout of v_mfma_f32_16x16x32_bf16: lane holds column (l & 15) and rows (l >> 4) * 4 + r: a lane owns heads (l >> 4) * 4 + r of its
+// key / d column, so the per-head running max / sum / rescale are per-register scalars replicated over the 16 lanes of a row group.
+// Wave = page (as above); partials, ticket and merge are the per-head ones (same record format, one record per head of the group).
+// all-reduce over the 16 lanes of a DPP row in four VALU instructions (no LDS round trip): xor 1, xor 2 (quad_perm), mirror within 8,
+// mirror within 16.  Partners always hold a + b and b + a, so every lane ends with bitwise the same value (sums included).
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_row_f<0xB1>(v)); v = fmaxf(v, dpp_row_f<0x4E>(v)); v = fmaxf(v, dpp_row_f<0x141>(v)); v = fmaxf(v, dpp_row_f<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_row_f<0xB1>(v); v += dpp_row_f<0x4E>(v); v += dpp_row_f<0x141>(v); v += dpp_row_f<0x140>(v);
+  return v;
+}
+template <int D, int GM>
+__global__ __launch_bounds__(256, 2) void decode_attn_gqa_kernel(const DecodeAttnArgs a) {
+  constexpr int NS = D / 32;       // d steps of the score MFMAs
+  constexpr int NDB = D / 16;      // 16-wide d blocks of the output
+  static_assert(D % 32 == 0 && (GM == 4 || GM == 16), "geometry");
+  __shared__ __attribute__((aligned(16))) bf16_t p_s[4][16][64 + 8];        // per wave: P [head][key] (+8: the A-operand reads of 16 heads hit distinct banks)
+  __shared__ float red_s[GM][4][D + 2];
+  constexpr int MGH = GM == 4 ? 4 : 1;              // heads merged per round trip (LDS: 4 x 16 records of D + 2 words = 33 KB at D = 128)
+  __shared__ __attribute__((aligned(16))) float mg_s[MGH * 16 * (D + 2)];
+  __shared__ int last_s;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, cg = lane >> 4;
+  // a block serves hpb CONSECUTIVE query heads of one KV head (hpb divides H / KV).  The MFMA rows are independent, so a head's result
+  // does not depend on hpb: the host picks it per launch -- the whole group when there are enough (KV head, split, sequence) units to
+  // fill the chip, fewer heads per block (more blocks, the page re-read from L2) for a single sequence.
+  const int G = a.hpb, nhb = a.H / G, units = nhb * a.gsplit * a.batch;
+  const int unit = (int)blockIdx.x;
+  if (unit >= units) return;
+  const int hb = unit % nhb, split = (unit / nhb) % a.gsplit, bz = unit / (nhb * a.gsplit);
+  const int head0 = hb * G, hkv = head0 / (a.H / a.KV);
+  const int* __restrict__ block_table = a.tables[bz];
+  const bf16_t* qb = a.q + (size_t)bz * a.q_stride;
+  float* part_b = a.part + (size_t)bz * a.H * a.nsplit * (D + 2);
+  int* counters_b = a.counters + bz * a.H;
+  const int pos = *a.pos_ptrs[bz] + 1;
+  const int npages = (pos + 63) >> 6;
+  int ns = (npages + 3) >> 2;                       // same split rule as the per-head kernel: a function of this sequence's length only
+  ns = ns > a.nsplit ? a.nsplit : ns;
+  const int cpb = a.cpb;
+  const int c_begin = split * cpb;
+  if (c_begin >= ns) return;
+  const int c_end = c_begin + cpb < ns ? c_begin + cpb : ns;
+  const int nblk = (ns + cpb - 1) / cpb;
+  const int pps = (npages + ns - 1) / ns;
+
+  bf16x8_t qa[NS];                                  // A operand of the score MFMAs: head `col` (zero rows beyond the group)
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (col < G) v = *(const u32x4_t*)(qb + (size_t)(head0 + col) * D + s * 32 + cg * 8);
+    qa[s] = __builtin_bit_cast(bf16x8_t, v);
+  }
+  const float sc = a.scale * 1.4426950408889634f;
+
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const int p_begin = chunk * pps;
+    int p_end = p_begin + pps; if (p_end > npages) p_end = npages;
+    float m_run[4], l_run[4];
+    f32x4_t oacc[NDB];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m_run[r] = -1e30f; l_run[r] = 0.f; }
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int pg = p_begin + wave; pg < p_end; pg += 4) {
+      const size_t pb = ((size_t)block_table[pg] * a.KV + hkv) * (size_t)(64 * D);
+      const bf16_t* kp = a.Kt + pb;
+      const bf16_t* vp = a.Vt + pb;
+      u32x4_t kr[4][NS], vr[NDB][2];                // the whole page, requested up front (read ONCE for the G heads)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) kr[kb][s] = __builtin_nontemporal_load((const u32x4_t*)(kp + (size_t)(kb * 16 + col) * D + s * 32 + cg * 8));
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) vr[db][t] = __builtin_nontemporal_load((const u32x4_t*)(vp + (size_t)(db * 16 + col) * 64 + t * 32 + cg * 8));
+      // scores: sacc[kb][r] = q(head cg*4+r) . k(key kb*16+col)
+      f32x4_t sacc[4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        sacc[kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[s], __builtin_bit_cast(bf16x8_t, kr[kb][s]), sacc[kb], 0, 0, 0);
+      }
+      float alpha[4], mx[4], ls[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        mx[r] = -1e30f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          float v = sacc[kb][r] * sc;
+          if (pg * 64 + kb * 16 + col >= pos) v = -1e30f;
+          sacc[kb][r] = v;
+          mx[r] = fmaxf(mx[r], v);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx[r] = row16_max(mx[r]);                          // the 16 lanes of a row group hold the 64 keys
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float m_new = fmaxf(m_run[r], mx[r]);
+        alpha[r] = __builtin_amdgcn_exp2f(m_run[r] - m_new);
+        m_run[r] = m_new;
+        ls[r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - m_new);
+          ls[r] += pv;
+          p_s[wave][cg * 4 + r][kb * 16 + col] = f2bf(pv);                           // the reference multiplies bf16 probabilities into V
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) l_run[r] = l_run[r] * alpha[r] + row16_sum(ls[r]);
+      __builtin_amdgcn_wave_barrier();
+      bf16x8_t pa[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) pa[t] = *(const bf16x8_t*)(&p_s[wave][col][t * 32 + cg * 8]);
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[db][r] *= alpha[r];
+        oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[0], __builtin_bit_cast(bf16x8_t, vr[db][0]), oacc[db], 0, 0, 0);
+        oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[1], __builtin_bit_cast(bf16x8_t, vr[db][1]), oacc[db], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // combine the 4 waves: red_s[head][wave][d], m, l
+    if (chunk > c_begin) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = cg * 4 + r;
+      if (h < G) {
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) red_s[h][wave][db * 16 + col] = oacc[db][r];
+        if (col == 0) { red_s[h][wave][D] = m_run[r]; red_s[h][wave][D + 1] = l_run[r]; }
+      }
+    }
+    __syncthreads();
+    if (ns == 1) {                                  // the only split of this sequence: finish here, all heads of the group at once
+      for (int idx = tid; idx < G * D; idx += 256) {
+        const int g = idx / D, d = idx - g * D, head = head0 + g;
+        const float mm = fmaxf(fmaxf(red_s[g][0][D], red_s[g][1][D]), fmaxf(red_s[g][2][D], red_s[g][3][D]));
+        float l = 0.f, acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float e = __builtin_amdgcn_exp2f(red_s[g][w][D] - mm);
+          l += red_s[g][w][D + 1] * e;
+          acc += red_s[g][w][d] * e;
+        }
+        if (d < a.Dout) a.out[a.out_tiled ? gvl_xt_index(bz, head * a.Dout + d) : (size_t)bz * a.out_stride + head * a.Dout + d] = f2bf(acc / l);
+      }
+      return;
+    }
+    for (int g = 0; g < G; ++g) {                    // one partial record per head (same format as the per-head kernel)
+      float* outp = part_b + ((size_t)(head0 + g) * a.nsplit + chunk) * (D + 2);
+      const float mm = fmaxf(fmaxf(red_s[g][0][D], red_s[g][1][D]), fmaxf(red_s[g][2][D], red_s[g][3][D]));
+      if (tid < D) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc += red_s[g][w][tid] * __builtin_amdgcn_exp2f(red_s[g][w][D] - mm);
+        __hip_atomic_store(outp + tid, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (tid == 0) {
+        float l = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) l += red_s[g][w][D + 1] * __builtin_amdgcn_exp2f(red_s[g][w][D] - mm);
+        __hip_atomic_store(outp + D, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(outp + D + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const int t = __hip_atomic_fetch_add(counters_b + head0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = (t == nblk - 1);
+  }
+  __syncthreads();
+  if (!last_s) return;
+  // merge: the partial records of up to MGH heads are fetched in ONE round trip (sc1 loads, all independent) and merged by (head, d)
+  // work items -- a group of 4 heads costs one round trip instead of four
+  const int nword = ns * (D + 2);
+  for (int g0 = 0; g0 < G; g0 += MGH) {
+    const int gn = G - g0 < MGH ? G - g0 : MGH;
+    for (int i = tid; i < gn * nword; i += 256) {
+      const int g = i / nword, wd = i - g * nword;
+      mg_s[g * 16 * (D + 2) + wd] = __hip_atomic_load(part_b + (size_t)(head0 + g0 + g) * a.nsplit * (D + 2) + wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < gn * D; idx += 256) {
+      const int g = idx / D, d = idx - g * D, head = head0 + g0 + g;
+      const float* mg = mg_s + g * 16 * (D + 2);
+      float gm = -1e30f;
+      for (int s2 = 0; s2 < ns; ++s2) gm = fmaxf(gm, mg[s2 * (D + 2) + D]);
+      float l = 0.f, acc = 0.f;
+      for (int s2 = 0; s2 < ns; ++s2) {
+        const float w = __builtin_amdgcn_exp2f(mg[s2 * (D + 2) + D] - gm);
+        l += mg[s2 * (D + 2) + D + 1] * w;
+        acc += mg[s2 * (D + 2) + d] * w;
+      }
+      if (d < a.Dout) a.out[a.out_tiled ? gvl_xt_index(bz, head * a.Dout + d) : (size_t)bz * a.out_stride + head * a.Dout + d] = f2bf(acc / l);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) __hip_atomic_store(counters_b + head0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int D>
 static int launch_decode_g(const DecodeAttnArgs& a, hipStream_t st) {
   static const bool no_gqa = getenv("GVL_DECODE_ATTN_NOGQA") != nullptr;      // A/B: the round-1 grid for GQA models
   const int G = a.H / a.KV;
+  static const bool gqa_valu = getenv("GVL_DECODE_ATTN_GQA_VALU") != nullptr;  // A/B: the per-head VALU kernel on the XCD-aware grid
+  if (G > 1 && G <= 16 && !no_gqa && !gqa_valu && D % 32 == 0) {
+    DecodeAttnArgs b = a;
+    if (b.hpb < 1 || b.hpb > G || G % b.hpb) b.hpb = G;
+    const int units = (b.H / b.hpb) * b.gsplit * b.batch;
+    if (b.hpb <= 4) hipLaunchKernelGGL((decode_attn_gqa_kernel<D, 4>), dim3(units), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((decode_attn_gqa_kernel<D, 16>), dim3(units), dim3(256), 0, st, b);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+  }
   if (G == 1 || no_gqa) {
     if (G == 1) hipLaunchKernelGGL((decode_attn_kernel<D, 1, 0>), dim3(a.H, a.gsplit, a.batch), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((decode_attn_kernel<D, 1, 2>), dim3(a.H, a.gsplit, a.batch), dim3(256), 0, st, a);
@@ -530,6 +766,7 @@ int gvl_launch_decode_attention(const DecodeAttnArgs& a_in, hipStream_t st) {
   if (a.batch > GVL_MAX_DECODE_BATCH) return -1;
   if (a.H % a.KV) return -1;
   if (a.cpb < 1) a.cpb = 1;
+  if (a.nsplit < 1 || a.nsplit > 16) return -1;      // the merge buffers hold 16 partial records
   if (a.gsplit <= 0 || a.gsplit > a.nsplit) a.gsplit = (a.nsplit + a.cpb - 1) / a.cpb;
   switch (a.D) {
     case 64: return launch_decode_g<64>(a, st);

@@ -152,6 +152,7 @@ struct DecodeAttnArgs {
   bf16_t* out;            // [batch][H*Dout], out_stride elements apart; out_tiled: B-operand tile order (gvl_xt_index) for the skinny decode GEMM
   int H, KV, D, Dout, nsplit, batch, q_stride, out_stride, out_tiled;
   float scale;
+  int hpb;                // grouped-query kernel: query heads of a KV head served by one block (0 = all H / KV; must divide it); any value gives the same result
   int cpb;                // consecutive splits per block (0 = 1); any value gives the same result (one partial per split either way)
   int gsplit;             // block slots along the context actually launched (0 = ceil(nsplit / cpb)): the host may pass min(nsplit, ceil(longest context in pages / 4)) -- a
                           // sequence uses ceil(its pages / 4) splits whatever the grid offers, so this only trims blocks that would leave at once

@@ -367,7 +367,7 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
   // measured neutral to slower (Phi-3.5, 3.5 k context, 16 sequences: 2631 tok/s at cpb 1, 2613 at 2, 2574 at 4; one sequence:
   // 455 / 445 / 408) -- at 5.5 TB/s over pages scattered through a 244 GB pool the page reads, not the tail, are the limit.
   // GVL_DECODE_ATTN_CPB overrides (A/B, tests).  Under stream capture the shape must stay valid for later steps: every slot.
-  int gsplit = ctx->nsplit, cpb = 1;
+  int gsplit = ctx->nsplit, cpb = 1, hpb = 0;
   { hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (st == nullptr || hipStreamIsCapturing(st, &cs) != hipSuccess || cs == hipStreamCaptureStatusNone) {
       int nsb[GVL_MAX_DECODE_BATCH];
@@ -376,6 +376,15 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
       const int force_cpb = fe ? atoi(fe) : 0;
       if (force_cpb >= 1 && force_cpb <= 16) cpb = force_cpb;
       gsplit = 1; for (int b = 0; b < B; ++b) { const int g = (nsb[b] + cpb - 1) / cpb; gsplit = g > gsplit ? g : gsplit; }
+      // grouped-query models: the whole group per block when that still gives >= ~1.5 blocks per CU, else fewer heads per block
+      const int G = H / KV;
+      if (G > 1) {
+        long splits = 0; for (int b = 0; b < B; ++b) splits += (nsb[b] + cpb - 1) / cpb;
+        hpb = G;
+        while (hpb > 1 && hpb % 2 == 0 && (long)(H / hpb) * splits < 400) hpb >>= 1;
+        const char* he = getenv("GVL_DECODE_ATTN_HPB");          // A/B and tests (read per step on purpose)
+        if (he && atoi(he) >= 1 && G % atoi(he) == 0) hpb = atoi(he);
+      }
     } }
   auto proj = [&](GemvArgs& g, const float* wscale) {
     if (!mfma) return gvl_launch_gemv(g, st);
@@ -398,7 +407,7 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
       RUN(GVL_PROF_GEMV, 2.0 * qkvw * Hd, proj(g, w.qkvs)); }
     { DecodeAttnArgs a; memset(&a, 0, sizeof(a)); a.q = ctx->d_q; a.q_stride = H * D; a.Kt = Kt; a.Vt = Vt;
       for (int b = 0; b < B; ++b) { a.tables[b] = sqs[b]->d_block_table; a.pos_ptrs[b] = sqs[b]->d_pos; }
-      a.part = ctx->d_part; a.counters = ctx->d_counters; a.batch = B; a.gsplit = gsplit; a.cpb = cpb;
+      a.part = ctx->d_part; a.counters = ctx->d_counters; a.batch = B; a.gsplit = gsplit; a.cpb = cpb; a.hpb = hpb;
       a.out = ctx->d_attn; a.out_stride = H * Dr; a.out_tiled = mfma ? 1 : 0; a.H = H; a.KV = KV; a.D = D; a.Dout = Dr; a.nsplit = ctx->nsplit; a.scale = 1.0f / sqrtf((float)Dr);
       RUN(GVL_PROF_DECODE_ATTN, 4.0 * ctx_tokens * (double)KV * D, gvl_launch_decode_attention(a, st)); }
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? w.od : w.ow; g.N = Hd; g.K = H * Dr; g.x = ctx->d_attn; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;

@@ -557,15 +557,25 @@ def test_sampling_inside_the_decode_loop_is_reproducible_and_batch_invariant():
     eng.close()
 
 
-def test_decode_attention_result_is_independent_of_the_launch_shape():
+@pytest.mark.parametrize("kind", ["mha", "gqa"])
+def test_decode_attention_result_is_independent_of_the_launch_shape(kind):
     """Decode attention splits a sequence's context into one split per 4 pages of ITS OWN length and publishes one partial per split;
-    how many consecutive splits a block works through (cpb, a launch parameter; default 1, GVL_DECODE_ATTN_CPB overrides) and how many
-    block slots the grid offers are free choices of the host.  The ids and logits must not depend on them: contexts of 9 and 17 splits (one past a page boundary, one
-    crossing 4096 tokens where the split count is clamped to 16), forced cpb = 1, 2, 3, 4, 16 against the default choice."""
+    how many consecutive splits a block works through (cpb, a launch parameter; default 1, GVL_DECODE_ATTN_CPB overrides), how many
+    block slots the grid offers and -- in the grouped-query kernel (matrix pipe, the page read once for the query heads of a KV
+    head) -- how many of the group's heads share a block (hpb: the host takes the whole group for large launches, fewer heads per
+    block for a single sequence; GVL_DECODE_ATTN_HPB overrides) are free choices of the host.  The ids and logits must not depend on
+    them: contexts of 9 and 17 splits (one past a page boundary, one crossing 4096 tokens where the split count is clamped to 16),
+    forced cpb = 1, 2, 3, 4, 16 (and hpb = 1, 2, 4 for the GQA model: 8 query heads on 2 KV heads) against the default choice."""
     import os
-    c = dict(hidden=256, inter=512, layers=2, heads=4, kv_heads=4, vocab=320)
-    geo = _phi_geo(c, max_seq=4608, max_prefill=4352, kv_pages=160)
-    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.cpb", device=DEV)
+    if kind == "mha":
+        c = dict(hidden=256, inter=512, layers=2, heads=4, kv_heads=4, vocab=320)
+        geo = _phi_geo(c, max_seq=4608, max_prefill=4352, kv_pages=160)
+        W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.cpb", device=DEV)
+    else:
+        c = dict(hidden=256, inter=512, layers=2, heads=8, kv_heads=2, vocab=320)
+        geo = tiny_geo(llm="llama3", hidden=c["hidden"], inter=c["inter"], layers=c["layers"], heads=c["heads"], kv_heads=c["kv_heads"], vocab=c["vocab"],
+                       rope_theta=5e5, rope_orig_max_pos=0, max_seq=4608, max_prefill=4352, kv_pages=160)
+        W = synth.llm_weights("llama", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.hpb", device=DEV)
     eng = llm_engine(geo, W)
     g = torch.Generator(device=DEV); g.manual_seed(12)
     embs = [(torch.randn((n, c["hidden"]), device=DEV, generator=g) * 0.5).to(bf) for n in (2100, 4090, 70)]
@@ -581,16 +591,21 @@ def test_decode_attention_result_is_independent_of_the_launch_shape():
             eng.seq_free(s)
         return ids, lg
 
-    old = os.environ.pop("GVL_DECODE_ATTN_CPB", None)
+    keys = ("GVL_DECODE_ATTN_CPB", "GVL_DECODE_ATTN_HPB")
+    old = {k: os.environ.pop(k, None) for k in keys}
     try:
         ref_ids, ref_lg = run()
-        for cpb in (1, 2, 3, 4, 16):
+        shapes = [(cpb, None) for cpb in (1, 2, 3, 4, 16)] + ([(1, 1), (1, 2), (1, 4), (4, 2)] if kind == "gqa" else [])
+        for cpb, hpb in shapes:
             os.environ["GVL_DECODE_ATTN_CPB"] = str(cpb)
+            if hpb is not None:
+                os.environ["GVL_DECODE_ATTN_HPB"] = str(hpb)
             ids, lg = run()
-            assert ids == ref_ids, f"cpb {cpb}: ids differ"
-            assert all(torch.equal(a, b) for a, b in zip(lg, ref_lg)), f"cpb {cpb}: logits differ"
+            assert ids == ref_ids, f"cpb {cpb} hpb {hpb}: ids differ"
+            assert all(torch.equal(a, b) for a, b in zip(lg, ref_lg)), f"cpb {cpb} hpb {hpb}: logits differ"
     finally:
-        os.environ.pop("GVL_DECODE_ATTN_CPB", None)
-        if old is not None:
-            os.environ["GVL_DECODE_ATTN_CPB"] = old
+        for k in keys:
+            os.environ.pop(k, None)
+            if old[k] is not None:
+                os.environ[k] = old[k]
     eng.close()

@@ -190,8 +190,13 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
       mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
+    // Lazy reference point: m_run is only a reference for the exponentials (any value >= true max - 126 gives the same softmax after the
+    // final division), so it -- and with it the 16 * DB accumulator multiplies, a quarter of the VALU work of a tile -- is moved only
+    // when some row of the wave sees a tile max more than a.lazy (8 = a factor 256) above it: P stays <= 256, exact in bf16's range,
+    // and after the first tile of a row almost never moves again.  (Moving it whenever any row's max grew at all skipped 12 % of the
+    // rescales at S = 2049: with 32 rows per wave some row nearly always grows a little.)
     float alpha = 1.f;
-    if (!__all(mx <= m_run)) {                   // wave-uniform: some row's running max grows -> rescale O (exact)
+    if (!__all((mx - m_run) * sc <= a.lazy)) {   // wave-uniform: some row's tile max is far above its reference -> move it, rescale O
       const float m_new = fmaxf(m_run, mx);
       alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
       m_run = m_new;
@@ -286,7 +291,10 @@ double gvl_attn_flops(const AttnArgs& a) {
   return a.causal ? 0.5 * f : f;
 }
 
-int gvl_launch_attention(const AttnArgs& a, hipStream_t st) {
+int gvl_launch_attention(const AttnArgs& a_in, hipStream_t st) {
+  AttnArgs a = a_in;
+  static const float lazy = [] { const char* e = getenv("GVL_ATTN_LAZY"); return e ? (float)atof(e) : 8.f; }();      // A/B: 0 = move the reference whenever a max grows
+  a.lazy = lazy >= 0.f && lazy <= 64.f ? lazy : 8.f;
   if (a.B <= 0 || a.S <= 0 || a.S > 256 * 64 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 7) || ((uintptr_t)a.O & 15)) return -1;   // 16-byte O stores
   switch (a.D) {
     // ring depth 2: 48 KB (D=96) -> 3 blocks / CU at 151 VGPRs (measured 427 us vs 461 us for the 73 KB depth-3 ring, which

@@ -137,6 +137,8 @@ struct AttnArgs {
   int causal;
   int ones_row;         // D > Dout only: V^T pad row Dout holds 1.0 for every key (QkvPostArgs.ones_row), so the P.V MFMAs deliver the
                         // softmax row sum in O^T[Dout] for free and the kernel drops its 32 VALU adds per key tile
+  float lazy;           // set by the launcher: the running max (and O) of a wave's rows is only moved when some row's tile max exceeds it by
+                        // more than `lazy` (log2 units; 0 = every time it grows)
 };
 int gvl_launch_attention(const AttnArgs& a, hipStream_t st);
 double gvl_attn_flops(const AttnArgs& a);

@@ -609,3 +609,48 @@ def test_decode_attention_result_is_independent_of_the_launch_shape(kind):
             if old[k] is not None:
                 os.environ[k] = old[k]
     eng.close()
+
+
+def test_resource_limits_are_refused_loudly_and_released_cleanly():
+    """The paged KV pool, the live-sequence table and the prefill window are finite: running out must be an error with a message (never a
+    silent truncation or a fallback), and freeing must give everything back -- the pool after the storm equals the pool before it."""
+    c = dict(hidden=64, inter=128, layers=2, heads=4, kv_heads=4, vocab=100)
+    geo = _phi_geo(c, max_seq=512, max_prefill=128, kv_pages=6)
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.lim", device=DEV)
+    eng = llm_engine(geo, W)
+    info0 = eng.kv_info()
+    assert info0["total_pages"] == 6 and info0["free_pages"] == 6
+    a = eng.seq_alloc(200)                                         # 4 pages
+    assert eng.kv_info()["free_pages"] == 2
+    with pytest.raises(E.L.GvlError, match="KV pages exhausted"):
+        eng.seq_alloc(192)                                         # 3 pages, 2 left
+    b = eng.seq_alloc(128)                                         # exactly the 2 left
+    assert eng.kv_info()["free_pages"] == 0
+    with pytest.raises(E.L.GvlError, match="exceeds cfg.max_seq"):
+        eng.seq_alloc(513)
+    x = (torch.randn((130, c["hidden"]), device=DEV) * 0.5).to(bf)
+    with pytest.raises(E.L.GvlError, match="bad length"):
+        eng.prefill(a, x)                                          # 130 rows > max_prefill 128
+    with pytest.raises(E.L.GvlError, match="bad length"):
+        eng.prefill(b, x[:129])                                    # 129 rows > the sequence's 128-token capacity
+    eng.prefill(b, x[:120])
+    with pytest.raises(E.L.GvlError, match="already holds tokens"):
+        eng.prefill(b, x[:8])
+    ids = eng.decode_greedy(b, 64, None)                           # capacity 128: prompt 120 + the prefill's token -> stops when the pages are full
+    assert 1 <= len(ids) <= 9 and all(0 <= t < c["vocab"] for t in ids)
+    with pytest.raises(E.L.GvlError, match="bad seq"):
+        eng.seq_free(77)
+    eng.seq_free(a); eng.seq_free(b)
+    with pytest.raises(E.L.GvlError, match="bad seq"):
+        eng.seq_free(b)                                            # double free
+    assert eng.kv_info() == info0
+    # the sequence table: kMaxSeqs live sequences, then a clean refusal, then reuse of freed slots
+    live = []
+    with pytest.raises(E.L.GvlError, match="KV pages exhausted|too many live sequences"):
+        for _ in range(300):
+            live.append(eng.seq_alloc(1))
+    assert len(live) == 6                                          # one page each: the pool runs out first here
+    for s in live:
+        eng.seq_free(s)
+    assert eng.kv_info() == info0
+    eng.close()

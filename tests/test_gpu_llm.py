@@ -654,3 +654,43 @@ def test_resource_limits_are_refused_loudly_and_released_cleanly():
         eng.seq_free(s)
     assert eng.kv_info() == info0
     eng.close()
+
+
+@pytest.mark.parametrize("heads,kv_heads,head_dim", [(8, 1, 32), (16, 2, 16), (8, 2, 128), (6, 2, 64)])
+def test_grouped_query_decode_attention_other_group_sizes(heads, kv_heads, head_dim):
+    """The grouped-query decode kernel beyond Llama-3's 4-heads-per-KV-head case: groups of 8 (the 16-row variant of the kernel: MFMA
+    rows 4..15 live in the upper lane groups), group of 3 (odd: heads-per-block stays the whole group), head dims 64 (padded from 16 /
+    32) and 128 -- a context of 300 tokens (two splits, partial last page) decoded for 6 teacher-forced steps against the oracle, and
+    the same sequences decoded as one group against one at a time (bit-identical)."""
+    hidden = heads * head_dim
+    c = dict(hidden=hidden, inter=2 * hidden, layers=2, heads=heads, kv_heads=kv_heads, vocab=200)
+    geo = tiny_geo(llm="llama3", hidden=c["hidden"], inter=c["inter"], layers=c["layers"], heads=heads, kv_heads=kv_heads, vocab=c["vocab"],
+                   rope_theta=5e5, rope_orig_max_pos=0, max_seq=512, max_prefill=384, kv_pages=24)
+    W = synth.llm_weights("llama", c["hidden"], c["inter"], c["layers"], heads, kv_heads, c["vocab"], True, seed=f"t.gq{heads}.{kv_heads}")
+    eng = llm_engine(geo, W)
+    ocfg = _ocfg(geo)
+    x = synth.det_tensor(f"t.gq.x{heads}", (300, hidden), 0.5)
+    seq = eng.seq_alloc(320)
+    eng.prefill(seq, x.to(DEV).to(bf))
+    cache, cache32 = [None] * geo.layers, [None] * geo.layers
+    O.llm_forward(ocfg, W, x, True, cache, 0, last_only=True)
+    O.llm_forward(ocfg, W, x, False, cache32, 0, last_only=True)
+    e = W["model.embed_tokens.weight"].to(bf).float()
+    n = x.shape[0]
+    for step in range(6):
+        tok = 7 + 3 * step
+        lg = eng.decode_step_logits(seq, tok)
+        ref = O.llm_forward(ocfg, W, e[tok][None], True, cache, n, last_only=True)[0]
+        ref32 = O.llm_forward(ocfg, W, e[tok][None], False, cache32, n, last_only=True)[0]
+        n += 1
+        check_bf16_class(lg, ref32, ref, 1e-2, f"GQA {heads}/{kv_heads} x {head_dim}: decode step {step} vs fp32 oracle")
+    eng.seq_free(seq)
+    xs = [x[:n_].to(DEV).to(bf) for n_ in (300, 65, 130)]
+    single = [eng.generate_ids(xx, 8, None) for xx in xs]
+    seqs = [eng.seq_alloc(xx.shape[0] + 9) for xx in xs]
+    for s_, xx in zip(seqs, xs):
+        eng.prefill(s_, xx)
+    assert eng.decode_greedy_batch(seqs, 8, None) == single
+    for s_ in seqs:
+        eng.seq_free(s_)
+    eng.close()

@@ -35,6 +35,7 @@ struct Seq {
   int* d_out = nullptr;   // [outlist_cap] generated ids, index = generation step
   int* d_ngen = nullptr;  // device copy of n_gen: where the next generated id goes (a decode step carries no host counters)
   unsigned rng_stream = 0;  // sampling: which random stream this sequence draws from (assigned at its prefill)
+  int* d_eos = nullptr; volatile int* h_eos = nullptr;   // host-mapped word: generation count at which this sequence produced eos (0 = not yet)
 };
 
 struct ProfRec { int cat; hipEvent_t e0, e1; double work; };
@@ -82,6 +83,9 @@ struct gvl_ctx {
   // frame pre-processing scratch (tmp image + tap tables), grown on demand
   void* pre_scratch = nullptr; size_t pre_scratch_bytes = 0;
   int kv_total_pages = 0;
+  // eos watch of gvl_decode_greedy*: one host-mapped word per sequence slot, written by the token-selection kernel
+  int* h_eos_flags = nullptr; int* d_eos_flags = nullptr; int watch_eos = -1;
+  hipEvent_t step_ev[3] = {nullptr, nullptr, nullptr};
   // token selection (gvl_set_sampling): greedy argmax unless `on`
   struct { bool on = false; float inv_temp = 1.f, top_p = 0.f; int top_k = 0; unsigned long long seed = 0; unsigned next_stream = 0; } sample;
   // RCCL communicator owned by the ctx (gvl_comm_init); the library is dlopen'ed on first use

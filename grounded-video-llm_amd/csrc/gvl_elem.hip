@@ -764,7 +764,10 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a) {
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
     *a.tok_ptrs[b] = idx;
-    if (a.ngen_ptrs[b]) { const int g = *a.ngen_ptrs[b]; if (a.out_lists[b]) a.out_lists[b][g] = idx; *a.ngen_ptrs[b] = g + 1; }
+    if (a.ngen_ptrs[b]) {
+      const int g = *a.ngen_ptrs[b]; if (a.out_lists[b]) a.out_lists[b][g] = idx; *a.ngen_ptrs[b] = g + 1;
+      if (a.eos_flags[b] && idx == a.eos_id && *a.eos_flags[b] == 0) __hip_atomic_store(a.eos_flags[b], g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (a.pos_ptrs[b]) (*a.pos_ptrs[b])++;
   }
 }
@@ -877,7 +880,10 @@ __global__ __launch_bounds__(1024) void sample_kernel(const ArgmaxArgs a) {
   if (tid == 0) {
     for (int w = 1; w < 16; ++w) if (shf[w] > best || (shf[w] == best && shi[w] < idx)) { best = shf[w]; idx = shi[w]; }
     *a.tok_ptrs[b] = idx;
-    if (a.ngen_ptrs[b]) { const int g = *a.ngen_ptrs[b]; if (a.out_lists[b]) a.out_lists[b][g] = idx; *a.ngen_ptrs[b] = g + 1; }
+    if (a.ngen_ptrs[b]) {
+      const int g = *a.ngen_ptrs[b]; if (a.out_lists[b]) a.out_lists[b][g] = idx; *a.ngen_ptrs[b] = g + 1;
+      if (a.eos_flags[b] && idx == a.eos_id && *a.eos_flags[b] == 0) __hip_atomic_store(a.eos_flags[b], g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (a.pos_ptrs[b]) (*a.pos_ptrs[b])++;
   }
 }

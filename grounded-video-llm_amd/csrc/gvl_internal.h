@@ -245,6 +245,9 @@ struct ArgmaxArgs { const float* logits; int n, batch; int* tok_ptrs[GVL_MAX_DEC
                     int* ngen_ptrs[GVL_MAX_DECODE_BATCH]; int* pos_ptrs[GVL_MAX_DECODE_BATCH];
                     // sampling (gvl_launch_sample only): scores / temperature -> top-k -> top-p -> one draw per row; the draw of row b is a
                     // pure function of (seed, stream[b], generation step, logits row), i.e. independent of how sequences are grouped
+                    // eos watch (gvl_decode_greedy*): when row b's token == eos_id, its generation count is stored (once) into the host-mapped word
+                    // eos_flags[b] -- the host reads it two steps behind the GPU instead of draining the stream every 16 steps
+                    int eos_id; int* eos_flags[GVL_MAX_DECODE_BATCH];
                     float inv_temp, top_p; int top_k; unsigned seed_lo, seed_hi; unsigned stream[GVL_MAX_DECODE_BATCH];
                     const int* step_override; };   // operator tests: generation step of row b when the row has no ngen counter
 int gvl_launch_argmax(const ArgmaxArgs& a, hipStream_t st);

@@ -432,6 +432,7 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
     g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, proj(g, ctx->l_heads)); }
   { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = f.vocab; am.batch = B;   // token, output list, n_gen++ and pos++ on the device
     for (int b = 0; b < B; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.ngen_ptrs[b] = sqs[b]->d_ngen; am.pos_ptrs[b] = sqs[b]->d_pos; }
+    if (ctx->watch_eos >= 0) { am.eos_id = ctx->watch_eos; for (int b = 0; b < B; ++b) am.eos_flags[b] = sqs[b]->d_eos; }
     RUN(GVL_PROF_OTHER, 0, pick_tokens(ctx, am, sqs, st)); }
   for (int b = 0; b < B; ++b) { sqs[b]->pos += 1; sqs[b]->n_gen += 1; }
   return 0;
@@ -469,36 +470,53 @@ int decode_step_replay(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st, Ste
   return 0;
 }
 
-// greedy decode of one group (prefilled sequences at the same generation step) until every member hit eos / max_new / its capacity
+// decode of one group (prefilled sequences at the same generation step) until every member hit eos / max_new / its capacity.
+// eos: the token-selection kernel stores a sequence's generation count into its host-mapped flag word the moment it picks eos; the host
+// keeps at most two steps ahead of the GPU (an event per step) and reads the flags after each event -- at most two steps are decoded in
+// vain and the stream is never drained mid-answer (round 1 drained it every 16 steps and could run 15 steps past eos).
 int decode_group(gvl_ctx* ctx, Seq* const* sqs, int B, int max_new, int eos_id, int32_t* const* out_ids, int* const* n_out, hipStream_t st) {
-  const int CHECK_EVERY = 16;
-  int checked = 0;                       // steps already inspected for eos (all members advance together)
-  bool done[GVL_MAX_DECODE_BATCH] = {false};
   const int start_gen = sqs[0]->n_gen;   // members of a group must be in the same generation step
   for (int b = 1; b < B; ++b) if (sqs[b]->n_gen != start_gen) return fail(ctx, GVL_ERR_STATE, "decode batch: sequences are at different generation steps");
+  struct Watch { gvl_ctx* c; ~Watch() { c->watch_eos = -1; } } watch{ctx};
+  bool done[GVL_MAX_DECODE_BATCH] = {false};
+  int n_done = 0;
+  if (eos_id >= 0) {
+    // the tokens produced so far (the prefill's first token) were selected without a watch: look at them once, then arm the flags
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    for (int b = 0; b < B; ++b) {
+      HIPCHK(ctx, hipMemcpy(out_ids[b], sqs[b]->d_out, (size_t)start_gen * 4, hipMemcpyDeviceToHost));
+      for (int i = 0; i < start_gen && !done[b]; ++i) if (out_ids[b][i] == eos_id) { done[b] = true; ++n_done; }
+      *sqs[b]->h_eos = 0;
+    }
+    ctx->watch_eos = eos_id;
+  }
   StepGraph sg;
-  for (;;) {
+  int enq = 0;
+  while (n_done < B) {
     const int n_gen = sqs[0]->n_gen;
     bool full = n_gen >= max_new;
     for (int b = 0; b < B; ++b) full = full || sqs[b]->pos >= sqs[b]->max_tokens;
-    if (full || (eos_id >= 0 && n_gen - checked >= CHECK_EVERY) || (eos_id >= 0 && checked == 0)) {
-      HIPCHK(ctx, hipStreamSynchronize(st));
-      bool all_done = true;
-      for (int b = 0; b < B; ++b) {
-        if (done[b]) continue;
-        HIPCHK(ctx, hipMemcpy(out_ids[b] + checked, sqs[b]->d_out + checked, (size_t)(n_gen - checked) * 4, hipMemcpyDeviceToHost));
-        if (eos_id >= 0)
-          for (int i = checked; i < n_gen; ++i)
-            if (out_ids[b][i] == eos_id) { *n_out[b] = i + 1; done[b] = true; break; }
-        if (!done[b] && full) { *n_out[b] = n_gen < max_new ? n_gen : max_new; done[b] = true; }
-        all_done = all_done && done[b];
-      }
-      checked = n_gen;
-      if (all_done) return 0;
+    if (full) break;
+    if (eos_id >= 0 && enq >= 2) {
+      HIPCHK(ctx, hipEventSynchronize(ctx->step_ev[(enq - 2) % 3]));
+      for (int b = 0; b < B; ++b) if (!done[b] && *sqs[b]->h_eos != 0) { done[b] = true; ++n_done; }
+      if (n_done >= B) break;
     }
-    int rc = decode_step_replay(ctx, sqs, B, st, sg);
+    const int rc = decode_step_replay(ctx, sqs, B, st, sg);
     if (rc) return rc;
+    if (eos_id >= 0) HIPCHK(ctx, hipEventRecord(ctx->step_ev[enq % 3], st));
+    ++enq;
   }
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  const int n_gen = sqs[0]->n_gen;
+  for (int b = 0; b < B; ++b) {
+    const int n = n_gen < max_new ? n_gen : max_new;
+    HIPCHK(ctx, hipMemcpy(out_ids[b], sqs[b]->d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+    int cut = n;
+    if (eos_id >= 0) for (int i = 0; i < n; ++i) if (out_ids[b][i] == eos_id) { cut = i + 1; break; }
+    *n_out[b] = cut;
+  }
+  return 0;
 }
 
 }  // namespace
@@ -583,6 +601,9 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
     ok &= hipMalloc((void**)&ctx->d_x, NB * f.hidden * 2) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_xn, NB * f.hidden * 2) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_seq_ngen, (size_t)gvl_ctx::kMaxSeqs * 4) == hipSuccess;
+    ok &= hipHostMalloc((void**)&ctx->h_eos_flags, (size_t)gvl_ctx::kMaxSeqs * 4, hipHostMallocMapped) == hipSuccess;
+    if (ok) { memset(ctx->h_eos_flags, 0, (size_t)gvl_ctx::kMaxSeqs * 4); ok &= hipHostGetDevicePointer((void**)&ctx->d_eos_flags, ctx->h_eos_flags, 0) == hipSuccess; }
+    for (int i = 0; i < 3 && ok; ++i) ok &= hipEventCreateWithFlags(&ctx->step_ev[i], hipEventDisableTiming) == hipSuccess;
     {   // the skinny-GEMM decode path needs every projection's K to split over 8 waves x 32-wide MFMA steps, and rows that one wave normalises
       const char* e = getenv("GVL_DECODE_VALU");
       ctx->decode_mfma = !(e && atoi(e)) && f.hidden % 256 == 0 && f.inter % 256 == 0 && (f.heads * ctx->l_Dr) % 256 == 0 && f.hidden <= 4096 && (ctx->l_Dr & 1) == 0;
@@ -608,6 +629,8 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
 int gvl_destroy(gvl_ctx* ctx) {
   if (!ctx) return 0;
   hipDeviceSynchronize();
+  if (ctx->h_eos_flags) hipHostFree(ctx->h_eos_flags);
+  for (int i = 0; i < 3; ++i) if (ctx->step_ev[i]) hipEventDestroy(ctx->step_ev[i]);
   for (auto& kv : ctx->w) if (kv.second.p) hipFree(kv.second.p);
   for (void* p : ctx->dw_allocs) if (p) hipFree(p);
   if (ctx->comm) gvl_comm_destroy(ctx);
@@ -834,6 +857,7 @@ int gvl_seq_alloc(gvl_ctx* ctx, int max_tokens, int* seq_id) {
   s.d_tok = ctx->d_seq_tok + id;
   s.d_out = ctx->d_seq_out + (size_t)id * ctx->outlist_cap;
   s.d_ngen = ctx->d_seq_ngen + id;
+  s.d_eos = ctx->d_eos_flags + id; s.h_eos = ctx->h_eos_flags + id;
   HIPCHK(ctx, hipMemcpy(s.d_block_table, s.pages.data(), (size_t)np * 4, hipMemcpyHostToDevice));   // blocking; d_pos is set by gvl_prefill on ITS stream
   *seq_id = id;
   return 0;

@@ -694,3 +694,47 @@ def test_grouped_query_decode_attention_other_group_sizes(heads, kv_heads, head_
     for s_ in seqs:
         eng.seq_free(s_)
     eng.close()
+
+
+def test_eos_stops_the_decode_within_two_steps():
+    """eos is watched on the device: the token-selection kernel raises a host-mapped flag the moment a sequence produces eos and the host,
+    which never runs more than two steps ahead of the GPU, stops the group as soon as every member's flag is up.  Checked through the
+    sequences' own generation counters: a group whose members produce eos at steps 3, 5 and 9 has decoded at most 9 + 2 tokens when
+    the call returns (the budget was 200), the returned ids end at each member's eos, and a run without eos is unaffected."""
+    c = dict(hidden=64, inter=128, layers=2, heads=4, kv_heads=4, vocab=100)
+    geo = _phi_geo(c, max_seq=512, max_prefill=128, kv_pages=32)
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.eos", device=DEV)
+    eng = llm_engine(geo, W)
+    xs = [synth.det_tensor(f"t.eos.x{i}", (n, c["hidden"]), 0.5).to(DEV).to(bf) for i, n in enumerate((20, 33, 47))]
+    free = [eng.generate_ids(x, 40, None) for x in xs]
+    assert all(len(f) == 40 for f in free)
+    # pick an eos every member emits (at different steps) by construction: the first token the three free runs share, if any; else
+    # exercise one member at a time
+    common = [t for t in free[0] if t in free[1] and t in free[2]]
+    import ctypes as C
+    for eos in (common[:1] or [free[0][4]]):
+        seqs = [eng.seq_alloc(x.shape[0] + 201) for x in xs]
+        for s, x in zip(seqs, xs):
+            eng.prefill(s, x)
+        got = eng.decode_greedy_batch(seqs, 200, eos)
+        firsts = [f.index(eos) + 1 if eos in f else None for f in free]
+        for g_, f, k in zip(got, free, firsts):
+            if k is not None:
+                assert g_ == f[:k], "ids must end at the member's own eos"
+        if all(k is not None for k in firsts):
+            n_gen = C.c_int(0)
+            eng._chk(eng.lib.gvl_seq_read(eng.ctx, seqs[0], 0, None, 0, C.byref(n_gen), eng.stream), "gvl_seq_read")
+            assert n_gen.value <= max(firsts) + 2, f"decoded {n_gen.value} tokens, last eos at {max(firsts)}"
+        for s in seqs:
+            eng.seq_free(s)
+    # single sequence, eos = its 7th free-running token
+    eos = free[1][6]
+    k = free[1].index(eos) + 1
+    s = eng.seq_alloc(xs[1].shape[0] + 201)
+    eng.prefill(s, xs[1])
+    assert eng.decode_greedy(s, 200, eos) == free[1][:k]
+    n_gen = C.c_int(0)
+    eng._chk(eng.lib.gvl_seq_read(eng.ctx, s, 0, None, 0, C.byref(n_gen), eng.stream), "gvl_seq_read")
+    assert n_gen.value <= k + 2
+    eng.seq_free(s)
+    eng.close()

@@ -485,3 +485,43 @@ def test_committed_bench_line_meets_the_driver_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["oracle_ids_equal_reference_golden"] is True
+
+
+def test_generate_kwargs_map_to_hf_token_selection_semantics():
+    """generate(**kw) -> token selection (the reference forwards do_sample / num_beams / temperature / top_p to HF generate,
+    inference.py:170-176 -> models/llava_next_video.py:655-661): greedy unless do_sample; HF's defaults temperature 1.0 and top_k 50 when
+    not given; HF's argument checks; an unseeded call takes its seed from torch's CPU generator (so torch.manual_seed governs it)."""
+    from grounded_video_llm_amd.model import LLAVA_NEXT_VIDEO
+
+    class Rec:
+        def __init__(self):
+            self.calls = []
+
+        def set_sampling(self, *a, **k):
+            self.calls.append((a, k))
+
+    class Dummy:
+        pass
+
+    d = Dummy(); d.engine = Rec()
+    sel = lambda **kw: LLAVA_NEXT_VIDEO._select_tokens(d, kw)
+    sel(do_sample=False, num_beams=1, temperature=0.2, top_p=None)
+    assert d.engine.calls[-1] == ((False,), {})
+    sel()                                                            # no kwargs at all: greedy
+    assert d.engine.calls[-1] == ((False,), {})
+    sel(do_sample=True, temperature=0.2, top_p=None, seed=7)         # the reference CLI's defaults
+    assert d.engine.calls[-1] == ((True, 0.2, 50, None, 7), {})
+    sel(do_sample=True, seed=1)
+    assert d.engine.calls[-1] == ((True, 1.0, 50, None, 1), {})
+    sel(do_sample=True, temperature=0.7, top_k=None, top_p=0.9, seed=3)
+    assert d.engine.calls[-1] == ((True, 0.7, 0, 0.9, 3), {})
+    torch.manual_seed(123); sel(do_sample=True); s1 = d.engine.calls[-1][0][4]
+    torch.manual_seed(123); sel(do_sample=True); s2 = d.engine.calls[-1][0][4]
+    sel(do_sample=True); s3 = d.engine.calls[-1][0][4]
+    assert s1 == s2 and s3 != s1 and 0 <= s1 < 2 ** 62
+    for bad in (dict(do_sample=True, temperature=0.0), dict(do_sample=True, temperature=-1.0), dict(do_sample=True, top_p=0.0),
+                dict(do_sample=True, top_p=1.5)):
+        with pytest.raises(ValueError):
+            sel(**bad)
+    with pytest.raises(NotImplementedError):
+        sel(do_sample=False, num_beams=4)

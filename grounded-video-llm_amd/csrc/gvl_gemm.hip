@@ -388,7 +388,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
     if (c * 8 < BN) {
       const int lc = pc ^ ((row >> 1) & 7);
       int gr = n0 + row; gr = gr < a.N ? gr : a.N - 1;
-      src[i] = a.W + (size_t)gr * a.K + lc * 8;
+      src[i] = a.W + (size_t)gr * a.ldw + lc * 8;
     } else {
       const int ra = row - BN;
       const int lc = pc ^ ((ra >> 1) & 7);
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
       if (i < NI / 2) {
         const int lc = pc ^ ((row >> 1) & 7);
         int gr = on0 + row; gr = gr < a.N ? gr : a.N - 1;
-        voff[i] = ((unsigned)gr * (unsigned)a.K + lc * 8) * 2;
+        voff[i] = ((unsigned)gr * (unsigned)a.ldw + lc * 8) * 2;
       } else {
         const int ra = row - BN;
         const int lc = pc ^ ((ra >> 1) & 7);
@@ -770,8 +770,9 @@ double gvl_gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K;
 int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
   GemmArgs a = a_in;
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return -1;
+  if (a.ldw == 0) a.ldw = a.K;
   if (a.act == GVL_ACT_GELU && !a.act_table) { a.act_table = gelu_table_device(); if (!a.act_table) return -3; }   // every erf-GELU epilogue reads Phi from the table
-  if (a.K % BK != 0 || a.N % 4 != 0 || a.lda % 8 != 0) return -1;   // K padded to 64 by the packer; 16-byte rows
+  if (a.K % BK != 0 || a.N % 4 != 0 || a.lda % 8 != 0 || a.ldw % 8 != 0 || a.ldw < a.K) return -1;   // K padded to 64 by the packer; 16-byte rows
   if (a.act == GVL_ACT_SILU_MUL && (a.out_f32 || a.resid || a.gamma)) return -1;
   int cfg = a.tile_cfg;
   static const int env_cfg = [] { const char* e = getenv("GVL_GEMM_CFG"); return e ? atoi(e) : 0; }();   // experiments only
@@ -784,7 +785,7 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     cfg = (a.K >= 1024 && t256 >= 128) ? 82 : 21;   // CLIP qkv / fc1 (K = 1024, 336 / 448 tiles): 82 measured +8...17 % over 21
   }
-  if ((cfg == 82 || cfg == 85) && ((size_t)a.N * a.K * 2 >= (1ull << 32) || (size_t)a.M * a.lda * 2 >= (1ull << 32))) cfg = 21;   // 32-bit DMA offsets
+  if ((cfg == 82 || cfg == 85) && ((size_t)a.N * a.ldw * 2 >= (1ull << 32) || (size_t)a.M * a.lda * 2 >= (1ull << 32))) cfg = 21;   // 32-bit DMA offsets
   const int epi = (a.act & 3) | ((a.out_f32 ? 1 : 0) << 2) | ((a.resid ? 1 : 0) << 3) | ((a.gamma ? 1 : 0) << 4) | ((a.bias ? 1 : 0) << 5);
   if (cfg == 82 && a.tile_cfg == 0 && env_cfg == 0 && a.m_begin == 0) {
     // Wave-quantisation planner.  The persistent 256x256 kernel runs one block per CU, so a launch costs ceil(tiles / CUs)
@@ -828,7 +829,7 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
       const int es_ = a.out_f32 ? 4 : 2;
       auto cols = [&](const GemmArgs& g, int n0, int n1) {       // sub-problem on output columns [n0, n1): pointer offsets only
         GemmArgs r = g;
-        r.W = g.W + (size_t)n0 * g.K; r.N = n1 - n0;
+        r.W = g.W + (size_t)n0 * g.ldw; r.N = n1 - n0;
         r.C = (char*)g.C + (size_t)n0 * es_;
         if (g.resid) r.resid = (const char*)g.resid + (size_t)n0 * es_;
         if (g.bias) r.bias = g.bias + n0;

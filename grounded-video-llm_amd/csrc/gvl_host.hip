@@ -115,19 +115,33 @@ struct Rccl {
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, UID, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 } g_rccl;
 bool rccl_load() {
   if (g_rccl.tried) return g_rccl.h != nullptr;
   g_rccl.tried = true;
+  // GVL_RCCL_LIB names the library explicitly (a deployment knob like NCCL's own; also how the host test reaches the failure path)
+  const char* over = getenv("GVL_RCCL_LIB");
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) { g_rccl.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rccl.h) break; }
-  if (!g_rccl.h) { g_rccl.err = std::string("dlopen(librccl) failed: ") + (dlerror() ? dlerror() : "?"); return false; }
+  std::string last = "?";
+  if (over && *over) {
+    g_rccl.h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+    if (!g_rccl.h) { const char* e = dlerror(); if (e) last = e; }   // dlerror() clears the pending message: read it ONCE
+  } else {
+    for (const char* n : names) {
+      g_rccl.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (g_rccl.h) break;
+      const char* e = dlerror(); if (e) last = e;
+    }
+  }
+  if (!g_rccl.h) { g_rccl.err = std::string("dlopen(librccl) failed: ") + last; return false; }
   g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.h, "ncclGetUniqueId");
   g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.h, "ncclCommInitRank");
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.h, "ncclCommDestroy");
   g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.h, "ncclAllGather");
+  g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(g_rccl.h, "ncclCommCount");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.h, "ncclGetErrorString");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) { g_rccl.err = "librccl lacks a required symbol"; dlclose(g_rccl.h); g_rccl.h = nullptr; return false; }
   return true;
@@ -158,6 +172,14 @@ int gvl_comm_destroy(gvl_ctx* ctx) {
   if (!ctx) return GVL_ERR_ARG;
   if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
   ctx->comm = nullptr; ctx->comm_world = 1; ctx->comm_rank = 0;
+  return 0;
+}
+int gvl_comm_count(gvl_ctx* ctx, int* n_ranks) {
+  if (!ctx || !n_ranks) return fail(ctx, GVL_ERR_ARG, "gvl_comm_count: null");
+  if (!ctx->comm) { *n_ranks = 1; return 0; }      // no communicator: a single-rank job
+  if (!rccl_load() || !g_rccl.CommCount) return fail(ctx, GVL_ERR_STATE, g_rccl.CommCount ? g_rccl.err : "librccl lacks ncclCommCount");
+  const int rc = g_rccl.CommCount(ctx->comm, n_ranks);
+  if (rc) return fail(ctx, GVL_ERR_HIP, rccl_msg("ncclCommCount", rc));
   return 0;
 }
 int gvl_allgather_visual(gvl_ctx* ctx, void* comm, const uint16_t* local, int rows_per_rank, int hidden, uint16_t* all, void* stream) {

@@ -105,7 +105,7 @@ enum { GVL_ACT_NONE = 0, GVL_ACT_QUICK_GELU = 1, GVL_ACT_GELU = 2, GVL_ACT_SILU_
 
 struct GemmArgs {
   const bf16_t* A;  int lda;     // [M,K] bf16
-  const bf16_t* W;               // [N,K] bf16 (nn.Linear layout), ld = K
+  const bf16_t* W;  int ldw;     // [N,K] bf16 (nn.Linear layout); ldw = row pitch in elements (0: K)
   void* C;          int ldc;     // [M,N'] f32 or bf16
   int M, N, K;
   const float* bias;             // [N] or null

@@ -1100,6 +1100,7 @@ int gvl_op_gemm(gvl_ctx* ctx, const uint16_t* A, const uint16_t* W, void* C, int
   hipStream_t st = (hipStream_t)stream;
   GemmArgs g = gemm(A, K, W, C, act == GVL_ACT_SILU_MUL ? N / 2 : N, M, N, K);
   g.bias = bias; g.gamma = gamma; g.resid = resid; g.ldr = N; g.act = act; g.out_f32 = out_f32; g.round_pre_resid = 1; g.tile_cfg = tile_cfg;
+  if (const char* e = getenv("GVL_LAB_LD")) { int la = 0, lw = 0; if (sscanf(e, "%d,%d", &la, &lw) == 2) { g.lda = la; g.ldw = lw; } }   // LAB: operand row pitches (tools/gemm_lab.py)
   RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
   return 0;
 }

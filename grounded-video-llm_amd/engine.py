@@ -196,6 +196,12 @@ class Engine:
         self._chk(self.lib.gvl_comm_init(self.ctx, uid, int(rank), int(world)), "gvl_comm_init")
         self.comm_world = world
 
+    def comm_count(self) -> int:
+        """Ranks RCCL itself reports for the ctx's communicator (ncclCommCount); 1 without a communicator."""
+        n = C.c_int(0)
+        self._chk(self.lib.gvl_comm_count(self.ctx, C.byref(n)), "gvl_comm_count")
+        return n.value
+
     def allgather_visual(self, local: torch.Tensor) -> torch.Tensor:
         """local bf16 [rows, hidden] (same rows on every rank) -> [world * rows, hidden] in rank order (ncclAllGather on the current stream)."""
         local = local.contiguous()

@@ -174,13 +174,17 @@ int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, voi
  * addition: every rank encodes its segments, ONE all-gather moves the per-segment token blocks (llava_next_video.py:563) to
  * every rank.  RCCL is loaded with dlopen("librccl.so.1") on first use; a host without RCCL gets GVL_ERR_STATE.
  *   gvl_comm_unique_id : ncclGetUniqueId on rank 0; the 128 bytes travel to the other ranks by the host's own means
- *   gvl_comm_init      : ncclCommInitRank on the ctx's device (collective over all ranks)
+ *   gvl_comm_init      : ncclCommInitRank on the ctx's device (collective over all ranks).  Env GVL_RCCL_LIB overrides the
+ *                        library name (default: librccl.so.1, librccl.so, /opt/rocm/lib/librccl.so.1)
  *   gvl_allgather_visual : local bf16 [rows_per_rank, hidden] -> all bf16 [world * rows_per_rank, hidden] (rank order) with
  *                        ncclAllGather on the caller's stream; `comm` = an ncclComm_t the host already owns, or NULL for the
  *                        ctx's communicator; world == 1 degenerates to one device copy. */
 int gvl_comm_unique_id(char id_out[128]);
 int gvl_comm_init(gvl_ctx* ctx, const char id[128], int rank, int world);
 int gvl_comm_destroy(gvl_ctx* ctx);
+/* ranks RCCL itself reports for the ctx's communicator (ncclCommCount); 1 when there is none.  bench.py prints it so that a
+ * multi-GPU line shows how many ranks the collective really spanned. */
+int gvl_comm_count(gvl_ctx* ctx, int* n_ranks);
 int gvl_allgather_visual(gvl_ctx* ctx, void* comm, const uint16_t* local, int rows_per_rank, int hidden, uint16_t* all,
                          void* stream);
 

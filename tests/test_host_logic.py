@@ -5,6 +5,7 @@ import json
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -116,6 +117,24 @@ def test_product_fails_loudly_without_gpu():
     from grounded_video_llm_amd import engine as E
     with pytest.raises(RuntimeError):
         E.Engine(E.TowerGeometry(), "cpu")
+
+
+def test_rccl_missing_is_an_error_not_a_crash():
+    """A host without librccl: gvl_comm_unique_id must return GVL_ERR_STATE with a message (include/gvl.h), not crash the process.
+    GVL_RCCL_LIB points the loader at a file that does not exist; own process because the loader caches its first attempt."""
+    code = (
+        "import ctypes, sys\n"
+        f"lib = ctypes.CDLL({L.LIB_PATH!r})\n"
+        "lib.gvl_last_error.restype = ctypes.c_char_p; lib.gvl_last_error.argtypes = [ctypes.c_void_p]\n"
+        "buf = ctypes.create_string_buffer(128)\n"
+        "rc = lib.gvl_comm_unique_id(buf)\n"
+        "rc2 = lib.gvl_comm_unique_id(buf)\n"
+        "print(rc, rc2, lib.gvl_last_error(None).decode())\n")
+    env = dict(os.environ, GVL_RCCL_LIB="/nonexistent/librccl-missing.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, f"process died: rc {r.returncode} {r.stderr[-500:]}"
+    rc, rc2, msg = r.stdout.strip().split(" ", 2)
+    assert rc == "-2" and rc2 == "-2" and "dlopen(librccl) failed" in msg and "librccl-missing" in msg
 
 
 def test_product_never_imports_oracle():

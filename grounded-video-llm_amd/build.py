@@ -11,7 +11,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libgvl.so")
+# LAB builds (A/B of two kernel variants on one GPU box, loaded through GVL_LIB_PATH): GVL_BUILD_TAG=x GVL_BUILD_DEFS="-DFOO=1" -> libgvl_x.so
+TAG = os.environ.get("GVL_BUILD_TAG", "")
+OUT = os.path.join(HERE, f"libgvl_{TAG}.so" if TAG else "libgvl.so")
 SOURCES = ["gvl_gemm.hip", "gvl_attn.hip", "gvl_elem.hip", "gvl_decode.hip", "gvl_model.hip", "gvl_host.hip", "gvl_pre.hip", "gvl_probe.hip"]
 HEADERS = ["gvl_internal.h", "gvl_ctx.h", os.path.join("..", "..", "include", "gvl.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result", "-Wno-cuda-compat",
@@ -28,7 +30,8 @@ def _newer(dst, srcs):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build" + ("_" + TAG if TAG else ""))
+    flags = FLAGS + os.environ.get("GVL_BUILD_DEFS", "").split()
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
@@ -38,7 +41,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + flags + ["-c", src, "-o", obj]
             if verbose:
                 print("[gvl build]", " ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -490,27 +490,32 @@ int decode_group(gvl_ctx* ctx, Seq* const* sqs, int B, int max_new, int eos_id, 
     }
     ctx->watch_eos = eos_id;
   }
-  StepGraph sg;
+  // Only LIVE members are stepped: a sequence that produced eos (seen two steps late) or reached its own capacity / max_new leaves the
+  // group, so it can neither truncate the answers of longer-running members nor append past its pages.  A sequence's ids do not depend
+  // on the group it is decoded in (gvl_decode.hip), so shrinking the group changes no result; the captured step is re-recorded.
+  std::unique_ptr<StepGraph> sg(new StepGraph());
+  Seq* live[GVL_MAX_DECODE_BATCH]; int n_live = -1;
   int enq = 0;
-  while (n_done < B) {
-    const int n_gen = sqs[0]->n_gen;
-    bool full = n_gen >= max_new;
-    for (int b = 0; b < B; ++b) full = full || sqs[b]->pos >= sqs[b]->max_tokens;
-    if (full) break;
+  for (;;) {
     if (eos_id >= 0 && enq >= 2) {
       HIPCHK(ctx, hipEventSynchronize(ctx->step_ev[(enq - 2) % 3]));
       for (int b = 0; b < B; ++b) if (!done[b] && *sqs[b]->h_eos != 0) { done[b] = true; ++n_done; }
-      if (n_done >= B) break;
     }
-    const int rc = decode_step_replay(ctx, sqs, B, st, sg);
+    Seq* now[GVL_MAX_DECODE_BATCH]; int n_now = 0;
+    for (int b = 0; b < B; ++b) if (!done[b] && sqs[b]->n_gen < max_new && sqs[b]->pos < sqs[b]->max_tokens) now[n_now++] = sqs[b];
+    if (n_now == 0) break;
+    if (n_now != n_live || memcmp(now, live, sizeof(Seq*) * n_now) != 0) {
+      if (n_live >= 0) sg.reset(new StepGraph());
+      memcpy(live, now, sizeof(Seq*) * n_now); n_live = n_now;
+    }
+    const int rc = decode_step_replay(ctx, live, n_live, st, *sg);
     if (rc) return rc;
     if (eos_id >= 0) HIPCHK(ctx, hipEventRecord(ctx->step_ev[enq % 3], st));
     ++enq;
   }
   HIPCHK(ctx, hipStreamSynchronize(st));
-  const int n_gen = sqs[0]->n_gen;
   for (int b = 0; b < B; ++b) {
-    const int n = n_gen < max_new ? n_gen : max_new;
+    const int n = sqs[b]->n_gen < max_new ? sqs[b]->n_gen : max_new;
     HIPCHK(ctx, hipMemcpy(out_ids[b], sqs[b]->d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
     int cut = n;
     if (eos_id >= 0) for (int i = 0; i < n; ++i) if (out_ids[b][i] == eos_id) { cut = i + 1; break; }
@@ -1040,7 +1045,12 @@ int gvl_set_sampling(gvl_ctx* ctx, int do_sample, float temperature, int top_k, 
   if (!(temperature > 0.f) || top_k < 0 || !(top_p >= 0.f) || top_p > 1.f)
     return fail(ctx, GVL_ERR_ARG, "gvl_set_sampling: temperature must be > 0, top_k >= 0, 0 <= top_p <= 1");
   ctx->sample.on = true; ctx->sample.inv_temp = 1.0f / temperature; ctx->sample.top_k = top_k; ctx->sample.top_p = top_p;
-  ctx->sample.seed = seed; ctx->sample.next_stream = 0;
+  // stream numbering restarts with the call (same seed + same prefill order = same draws) -- unless sequences are LIVE: a scheduler that
+  // changes the sampling parameters mid-flight must not hand the stream ids of running sequences to newcomers
+  bool any_live = false;
+  for (const Seq& q : ctx->seqs) any_live = any_live || q.used;
+  if (!any_live || seed != ctx->sample.seed) ctx->sample.next_stream = 0;
+  ctx->sample.seed = seed;
   return 0;
 }
 

@@ -11,6 +11,8 @@ merged at load (#16), greedy decoding only on this tier (the reference CLI defau
 """
 from __future__ import annotations
 
+import dataclasses
+
 import os
 from typing import Dict, List, Optional, Sequence
 
@@ -64,6 +66,43 @@ class SyntheticTokenizer:
         return out
 
 
+def fit_geometry(geometry: TowerGeometry, llm: str, num_frames: int, num_segs: int, max_txt_len: int) -> TowerGeometry:
+    """A copy of `geometry` whose limits hold the reference's configuration (frames / segments / max_txt_len): the prefill workspace and
+    the RoPE tables must cover the visual prefix plus the longest prompt the reference accepts (llava_next_video.py:622-647).  Shared by
+    the model constructor and tools/pack_checkpoint.py, so a packed file's RoPE tables have the max_seq the loader will ask for.
+    The paged KV pool is sized from the free HBM (kv_pages = 0) only when the caller left kv_pages at the dataclass default or passed 0;
+    an explicit pool that cannot hold one full-length sequence is an error, never silently replaced by "all of the HBM"."""
+    g = dataclasses.replace(geometry)
+    g.frames_per_seg = num_frames // num_segs
+    g.max_segs = max(g.max_segs, num_segs)
+    tok_seg = (156 if llm == "phi3.5" else 64) + 16 * g.frames_per_seg + 1
+    need = num_segs * tok_seg + max_txt_len
+    g.max_prefill = max(g.max_prefill, need)
+    g.max_seq = max(g.max_seq, min(need + 256, 131072))
+    if g.kv_pages * 64 < need + 256:
+        default_pages = TowerGeometry.__dataclass_fields__["kv_pages"].default
+        if g.kv_pages in (0, default_pages):
+            g.kv_pages = 0                            # 0 = size the paged KV pool from the free HBM (gvl_finalize_weights)
+        else:
+            raise ValueError(f"kv_pages = {g.kv_pages} ({g.kv_pages * 64} tokens) cannot hold one sequence of {need + 256} tokens "
+                             f"({num_segs} segments x {tok_seg} visual tokens + max_txt_len {max_txt_len} + 256 new): pass a larger pool, "
+                             "a smaller max_txt_len, or kv_pages = 0 to size the pool from the free HBM")
+    return g
+
+
+def packed_file_metadata(path: str) -> Dict[str, str]:
+    """The __metadata__ dict of a `gvl-packed-1` safetensors file (8-byte little-endian header length + JSON header)."""
+    import json
+    import struct
+    with open(path, "rb") as f:
+        (n,) = struct.unpack("<Q", f.read(8))
+        hdr = json.loads(f.read(n))
+    meta = hdr.get("__metadata__") or {}
+    if meta.get("format") != "gvl-packed-1":
+        raise ValueError(f"{path}: not a gvl packed weight file")
+    return meta
+
+
 class LLAVA_NEXT_VIDEO:
     def __init__(self, dtype=torch.bfloat16, stage="pretrain", max_txt_len=2048, num_frames=96, num_segs=12, lora=False,
                  num_temporal_tokens=300, llm="llama3", attn_implementation="flash_attention_2",
@@ -81,18 +120,7 @@ class LLAVA_NEXT_VIDEO:
         self.group = group
         if geometry is None:
             geometry = geometry_from_checkpoint_dirs(llm, config_path, pretrained_vision_proj_llm_path, stage, num_temporal_tokens)
-        geometry.frames_per_seg = num_frames // num_segs
-        if geometry.max_segs < num_segs:
-            geometry.max_segs = num_segs
-        # the prefill workspace must hold the visual prefix plus the longest prompt the reference accepts (max_txt_len)
-        tok_seg = (156 if llm == "phi3.5" else 64) + 16 * geometry.frames_per_seg + 1
-        need = num_segs * tok_seg + max_txt_len
-        if geometry.max_prefill < need:
-            geometry.max_prefill = need
-        if geometry.max_seq < min(need + 256, 131072):
-            geometry.max_seq = min(need + 256, 131072)
-        if geometry.kv_pages * 64 < need + 256:
-            geometry.kv_pages = 0                     # 0 = size the paged KV pool from the free HBM (gvl_create)
+        geometry = fit_geometry(geometry, llm, num_frames, num_segs, max_txt_len)     # a COPY: the caller's object is never edited
         if llm == "phi3.5" and geometry.rope_short is None and geometry.rope_orig_max_pos > 0:
             raise ValueError("Phi-3.5 needs its LongRoPE short_factor / long_factor (config.json rope_scaling): Phi3LongRoPEScaledRotaryEmbedding "
                              "applies the short factors and the sqrt(1 + ln(s)/ln(4096)) scale even below 4096 tokens (modeling_phi3.py:380-409); "
@@ -112,7 +140,13 @@ class LLAVA_NEXT_VIDEO:
             if stage in ("grounded", "sft"):
                 self.tokenizer.add_tokens(P.temporal_token_strings(num_temporal_tokens))   # :235-236
         self.engine = Engine(geometry, device)
+        self._base_sd = None
         if packed_weights is not None:                    # file written by tools/pack_checkpoint.py: no per-start packing / LoRA merge;
+            meta = packed_file_metadata(packed_weights)
+            for key, have in (("max_seq", geometry.max_seq), ("frames_per_seg", geometry.frames_per_seg)):
+                if key in meta and int(meta[key]) != int(have):
+                    raise ValueError(f"{packed_weights}: packed for {key} = {meta[key]} but this model needs {key} = {have} (num_frames / num_segs / "
+                                     "max_txt_len differ from the ones given to tools/pack_checkpoint.py: re-pack, or pass the same values)")
             self.engine.load_packed_file(packed_weights)  # read by libgvl itself (gvl_load_packed: mmap + one upload per tensor)
             self.engine.finalize()
             return
@@ -147,6 +181,9 @@ class LLAVA_NEXT_VIDEO:
         """inference.py:156-162: overlay the fine-tuned groups {multi_modal_projector, video_projecter, language_model} on the base
         state dicts this object was built from (kept in memory: nothing is read from disk twice)."""
         base = base if base is not None else self._base_sd
+        if base is None:
+            raise RuntimeError("load_ckpt: this model was started from a packed weight file, which holds no base state dicts to overlay; "
+                               "pass base=..., or overlay the checkpoint when packing (tools/pack_checkpoint.py --ckpt_path)")
         proj = dict(base["projectors"])
         for grp in ("multi_modal_projector", "video_projecter"):
             for k, v in ckpt.get(grp, {}).items():

@@ -137,7 +137,9 @@ int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t
  * do_sample = 1: scores / temperature -> top-k (0 = off; ties with the k-th score are kept) -> top-p (0 or 1 = off; a token is kept
  * iff the probability mass of strictly larger scores is < top_p) -> ONE draw from the softmax of what is left, all on the device
  * inside the decode step.  The draw of a sequence is a pure function of (seed, the order in which sequences were prefilled since
- * this call, generation step, logits): reproducible, and independent of how sequences are grouped into decode batches.
+ * this call, generation step, logits): reproducible, and independent of how sequences are grouped into decode batches.  (A call
+ * that repeats the current seed while sequences are live continues the numbering instead, so newcomers never share a stream with
+ * a running sequence; callers that make several generate() calls per request pass a different seed per call.)
  * torch.multinomial's random stream is not reproduced (parity = same kept set + same distribution).  num_beams > 1 is not built. */
 int gvl_set_sampling(gvl_ctx* ctx, int do_sample, float temperature, int top_k, float top_p, uint64_t seed);
 /* Prefill of n_seqs sequences together, seq_lens[i] tokens each (ragged: prompts differ in length; the reference left-pads and

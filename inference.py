@@ -104,7 +104,7 @@ def main(argv=None):
             geo = {"phi3.5": TowerGeometry, "llama3": TowerGeometry.llama3_8b, "vicuna": TowerGeometry.vicuna_7b}[args.llm]()
         else:
             geo = TowerGeometry(llm=args.llm, clip_layers=3, iv2_depth=3, hidden=512, inter=1024, layers=2, heads=4, kv_heads=4, vocab=2048,
-                                max_seq=4608, max_prefill=4096, kv_pages=80)
+                                max_seq=4608, max_prefill=4096, kv_pages=96)   # 6144 tokens: one 96-frame sequence + max_txt_len 2048
         if geo.kind == "phi3":
             geo.rope_short, geo.rope_long = synth.longrope_factors(geo.hidden // geo.heads)
         geo.max_segs = args.num_segs
@@ -139,9 +139,11 @@ def main(argv=None):
         texts = model.generate_shared(per_mode[0], prompts, **kw)
         outs = {mode: (p, t) for mode, p, t in zip(modes, prompts, texts)}
     else:
-        for mode in modes:
+        for i, mode in enumerate(modes):
             samples = create_inputs(args, mode, frames, duration, model.engine)
-            outs[mode] = (samples["prompts"][0], model.generate(samples, **kw)[0])
+            # one sampler seed per call (HF's generator state advances between the reference's three generate() calls; the same seed
+            # for all three would make their draws perfectly correlated)
+            outs[mode] = (samples["prompts"][0], model.generate(samples, **{**kw, "seed": args.seed + i})[0])
     print("\n******grounding example******")
     print(outs["grounding"][0])
     print(P.parse_time_interval(outs["grounding"][1], duration, args.num_temporal_tokens, args.llm if args.llm != "vicuna" else "llama3"))

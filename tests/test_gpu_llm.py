@@ -738,3 +738,31 @@ def test_eos_stops_the_decode_within_two_steps():
     assert n_gen.value <= k + 2
     eng.seq_free(s)
     eng.close()
+
+
+def test_finished_members_do_not_truncate_the_group():
+    """A decode group advances in lock step, but a member that is done -- by eos or because ITS pages / budget are used up -- must leave
+    the group instead of ending everybody's answer: sequences allocated with room for 5 / 41 / 13 new tokens, decoded as
+    one group, return exactly what each returns decoded on its own; same with an eos that only some members emit."""
+    c = dict(hidden=64, inter=128, layers=2, heads=4, kv_heads=4, vocab=100)
+    geo = _phi_geo(c, max_seq=512, max_prefill=128, kv_pages=32)
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.eos", device=DEV)
+    eng = llm_engine(geo, W)
+    xs = [synth.det_tensor(f"t.eos.x{i}", (n, c["hidden"]), 0.5).to(DEV).to(bf) for i, n in enumerate((20, 33, 47))]
+    room = (5, 41, 13)
+
+    def run(batched, eos):
+        seqs = [eng.seq_alloc(x.shape[0] + r) for x, r in zip(xs, room)]
+        for s, x in zip(seqs, xs):
+            eng.prefill(s, x)
+        out = eng.decode_greedy_batch(seqs, 40, eos) if batched else [eng.decode_greedy(s, 40, eos) for s in seqs]
+        for s in seqs:
+            eng.seq_free(s)
+        return out
+
+    singles = run(False, None)
+    assert [len(o) for o in singles] == [6, 40, 14], [len(o) for o in singles]      # the prefill's token + one per free KV slot, capped by max_new
+    assert run(True, None) == singles
+    eos = singles[1][8]                                                               # member 1 stops at its 9th token (or earlier), others where they must
+    assert run(True, eos) == run(False, eos)
+    eng.close()

@@ -204,13 +204,34 @@ def test_reference_checkpoint_layout_roundtrip(tmp_path, llm):
     pc.main(["--llm", llm, "--pretrained_video_path", str(iv2_path), "--pretrained_vision_proj_llm_path", str(d), "--ckpt_path", str(ck_path),
              "--num_frames", "4", "--num_segs", "2", "--out", str(out)], geometry=geo)
     got = Wt.load_packed_file(str(out))
-    want = pc.pack_all({**sd, "projectors": dict(sd["projectors"])}, geo, llm)
+    fitted = M.fit_geometry(geo, llm, 4, 2, 2048)      # what the CLI (and later the model constructor) derives from frames / segments / max_txt_len
+    assert geo.max_seq == 256 and geo.frames_per_seg == 8, "fit_geometry must not edit the caller's object"
+    assert fitted.max_seq >= 2 * (fitted.frames_per_seg * 16 + 65) + 2048 and fitted.frames_per_seg == 2
+    want = pc.pack_all({**sd, "projectors": dict(sd["projectors"])}, fitted, llm)
+    meta = M.packed_file_metadata(str(out))
+    assert meta["max_seq"] == str(fitted.max_seq) and meta["frames_per_seg"] == "2" and meta["llm"] == llm
     assert set(got) == set(want)
     for k in want:
         assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k].cpu()), k
     with pytest.raises(ValueError):
         save_file({"x": torch.zeros(1)}, str(tmp_path / "other.safetensors"))
         Wt.load_packed_file(str(tmp_path / "other.safetensors"))
+
+
+def test_fit_geometry_kv_pool_policy():
+    """the constructor must not silently swap an explicit small KV pool for "all of the free HBM", nor edit the caller's geometry."""
+    from grounded_video_llm_amd import model as M
+    from grounded_video_llm_amd.engine import TowerGeometry
+    g = TowerGeometry(kv_pages=80)                                  # 5120 tokens < 12 x 285 + 2048 + 256
+    with pytest.raises(ValueError, match="kv_pages = 80"):
+        M.fit_geometry(g, "phi3.5", 96, 12, 2048)
+    assert g.kv_pages == 80 and g.max_prefill == 4096
+    ok = M.fit_geometry(g, "phi3.5", 96, 12, 1024)                  # 3420 + 1024 + 256 = 4700 tokens fit
+    assert ok.kv_pages == 80 and ok.max_prefill >= 4444 and ok is not g
+    assert M.fit_geometry(TowerGeometry(), "phi3.5", 96, 12, 2048).kv_pages == 128      # the default pool holds the default configuration
+    auto = M.fit_geometry(TowerGeometry.llama3_8b(), "llama3", 256, 32, 2048)           # 32 x 193 + 2048 + 256 > 8192 tokens: default pool -> sized from the free HBM
+    assert auto.kv_pages == 0 and auto.max_seq >= 8480
+    assert M.fit_geometry(TowerGeometry(kv_pages=0), "llama3", 256, 32, 2048).kv_pages == 0
 
 
 # ---- continuous-batching scheduler (SURVEY.md §8 f2) on a scripted engine ------------------------------------------------
@@ -464,10 +485,10 @@ def test_phi35_geometry_reads_longrope_from_config_json_and_refuses_without(tmp_
         TowerGeometry().apply_hf_config({"rope_scaling": {"type": "linear", "factor": 2.0}})
     # prompts up to max_txt_len must fit the prefill workspace (12 x 285 visual rows + 2048 text tokens > the old 4096 cap)
     g2 = TowerGeometry().apply_hf_config(cfg)
-    try:
-        M.LLAVA_NEXT_VIDEO(llm="phi3.5", stage="sft", geometry=g2, tokenizer=M.SyntheticTokenizer(32366), state_dicts={})
-    except RuntimeError:
-        pass                                  # no GPU here: Engine refuses -- after the geometry has been completed
+    g2.max_prefill = 2048
+    gf = M.fit_geometry(g2, "phi3.5", 96, 12, 2048)      # what the constructor does first -- on a copy
+    assert g2.max_prefill == 2048
+    g2 = gf
     assert g2.max_prefill >= 12 * 285 + 2048 and g2.max_seq >= g2.max_prefill and g2.kv_pages * 64 >= g2.max_prefill + 256
     assert geo.kv_pages == 0                  # geometry built from the checkpoint directories: KV pool sized from the free HBM
 

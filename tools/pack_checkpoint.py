@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import _gvl_bootstrap  # noqa
 from grounded_video_llm_amd import weights as Wt
 from grounded_video_llm_amd.engine import TowerGeometry
-from grounded_video_llm_amd.model import geometry_from_checkpoint_dirs, load_reference_checkpoints
+from grounded_video_llm_amd.model import fit_geometry, geometry_from_checkpoint_dirs, load_reference_checkpoints
 
 
 def pack_all(sd, geo: TowerGeometry, llm: str, stage: str = "sft"):
@@ -45,10 +45,11 @@ def main(argv=None, geometry=None):
     ap.add_argument("--num_frames", type=int, default=96)
     ap.add_argument("--num_segs", type=int, default=12)
     ap.add_argument("--num_temporal_tokens", type=int, default=300)
+    ap.add_argument("--max_txt_len", type=int, default=2048, help="as given to LLAVA_NEXT_VIDEO at load time: sizes the RoPE tables (max_seq)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args(argv)
     geo = geometry or geometry_from_checkpoint_dirs(a.llm, a.config_path, a.pretrained_vision_proj_llm_path, a.stage, a.num_temporal_tokens)
-    geo.frames_per_seg = a.num_frames // a.num_segs
+    geo = fit_geometry(geo, a.llm, a.num_frames, a.num_segs, a.max_txt_len)      # the limits the model constructor will derive
     sd = load_reference_checkpoints(a.llm, a.pretrained_video_path, a.pretrained_vision_proj_llm_path)
     if a.ckpt_path:
         ck = torch.load(a.ckpt_path, map_location="cpu")
@@ -59,7 +60,7 @@ def main(argv=None, geometry=None):
         if "language_model" in ck:
             sd["language_model"] = ck["language_model"]
     packed = pack_all(sd, geo, a.llm, a.stage)
-    Wt.save_packed(a.out, packed, {"llm": a.llm, "frames_per_seg": str(geo.frames_per_seg)})
+    Wt.save_packed(a.out, packed, {"llm": a.llm, "frames_per_seg": str(geo.frames_per_seg), "max_seq": str(geo.max_seq)})
     print(f"wrote {a.out}: {len(packed)} tensors, {sum(v.numel() * v.element_size() for v in packed.values()) / 2**20:.1f} MiB")
     return packed
 

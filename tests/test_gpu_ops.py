@@ -210,6 +210,49 @@ def test_gemm_planner_full_shapes(eng, M, N, K, epi):
     check(got, ref, 8e-3, f"gemm planner {M}x{N}x{K} {epi}")
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(24588, 1408, 1408, "bias_gamma_resid"), (24588, 4224, 1408, "plain"), (24588, 6144, 1408, "bias_gelu"),
+                                       (24588, 1408, 6144, "bias_gamma_resid"), (3519, 16384, 3072, "silu"), (27696, 1024, 4096, "bias_resid32"),
+                                       (6924, 3072, 1024, "bias"), (7000, 2560, 1024, "plain")])
+def test_gemm_auto_plan_is_bit_identical_and_stream_safe(eng, M, N, K, epi):
+    """The automatic launch plan at the real tower shapes (persistent 256x256 kernel + remainder rows / tail columns on the small kernels)
+    accumulates every output element in the same k order as the plain 128x128 kernel (cfg 21): bit-identical on every repetition, also
+    while a second stream runs its own planned GEMM beside it and the chip is loaded unevenly.  (Round 3 ran the same test against an
+    in-kernel in-order split of the last partial round -- green, but slower than the planner: profiles/r03_gemm_split_ab.txt.)"""
+    g = torch.Generator(device=DEV); g.manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((M, K), device=DEV, generator=g).to(bf)
+    W = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).to(bf)
+    kw = {}
+    if "bias" in epi:
+        kw["bias"] = torch.randn((N,), device=DEV, generator=g) * 0.5
+    if "gamma" in epi:
+        kw["gamma"] = torch.randn((N,), device=DEV, generator=g) * 0.05 + 0.1
+    if "resid32" in epi:
+        kw["resid"] = torch.randn((M, N), device=DEV, generator=g); kw["out_f32"] = True
+    elif "resid" in epi:
+        kw["resid"] = torch.randn((M, N), device=DEV, generator=g).to(bf)
+    if "gelu" in epi:
+        kw["act"] = L.ACT_GELU
+    if "silu" in epi:
+        kw["act"] = L.ACT_SILU_MUL
+    want = eng.op_gemm(A, W, tile_cfg=21, **kw)
+    for rep in range(4):
+        assert torch.equal(eng.op_gemm(A, W, **kw), want), f"auto gemm {M}x{N}x{K} {epi}: repetition {rep} differs from cfg 21"
+    # a second stream with its own GEMM (other shape) running beside it, and a burst of small kernels as uneven load
+    A2 = torch.randn((5000, 2048), device=DEV, generator=g).to(bf)
+    W2 = (torch.randn((4096, 2048), device=DEV, generator=g) * 2048 ** -0.5).to(bf)
+    want2 = eng.op_gemm(A2, W2, tile_cfg=21)
+    s2 = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs, outs2 = [], []
+    for rep in range(3):
+        with torch.cuda.stream(s2):
+            outs2.append(eng.op_gemm(A2, W2))
+            junk = [torch.randn((257, 1031), device=DEV) for _ in range(4)]
+        outs.append(eng.op_gemm(A, W, **kw))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, want) for o in outs) and all(torch.equal(o, want2) for o in outs2), "auto gemm under a concurrent stream differs"
+
+
 # ---- do_sample=True token selection (gvl_op_sample == the kernel inside every prefill / decode step after gvl_set_sampling) ----------------
 @pytest.mark.parametrize("n,temperature,top_k,top_p", [
     (100, 1.0, 0, None), (100, 0.7, 5, None), (1000, 0.2, 50, None), (1000, 1.0, 0, 0.9), (5000, 1.3, 50, 0.5),

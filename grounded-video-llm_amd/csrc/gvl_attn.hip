@@ -270,301 +270,14 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
       }
   }
 }
-// Software-pipelined variant (non-causal: the vision towers).  Iteration t issues the S^T = K.Q^T MFMAs of tile t + 1 FIRST, then runs the
-// softmax of tile t (VALU) while the matrix pipe works on them, then P.V of tile t: the overlap between the two pipes is created inside
-// one wave's instruction stream instead of being left to chance between three co-resident waves.  Costs a second score tile (32 VGPRs:
-// two waves per SIMD) and a third ring slot (tile t's V^T and tile t + 1's K are live together while tile t + 2 is in flight).
-template <int D, int NWAVES, int ONES = 0>
-__global__ __launch_bounds__(NWAVES * 64) void attn_fwd_pipe_kernel(const AttnArgs a) {
-  constexpr int NS = 3;
-  constexpr int NT = NWAVES * 64;
-  constexpr int DK = D / 16;          // k-steps of the QK^T contraction
-  constexpr int DB = D / 32;          // 32-row d blocks of O^T
-  constexpr int CPR = D / 8;          // 16-byte chunks per K row
-  constexpr int KCH = 64 * CPR;       // chunks in a K tile (== chunks in a V^T tile)
-  constexpr int NIK = KCH / NT;       // DMA instructions per thread for K (and for V^T)
-  constexpr int TILE_BYTES = 64 * D * 2;
-  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-  static_assert(KCH % NT == 0, "tile/threads mismatch");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, h = lane >> 5;
-  // XCD-aware block -> (query block, head, batch): consecutive workgroup ids go round-robin over the 8 XCDs, so with the
-  // natural (q-block fastest) order the 17 query blocks of one (batch, head) would pull the same K/V pages through 8 different
-  // L2s (measured 2.5x fetch amplification).  Here every (batch, head) lives on ONE XCD: id = 8*j + xcd, j = local*nq + qb.
-  // (With grouped-query attention the unit is the (batch, KV head) GROUP: its H/KV query heads share the pages too.)
-  const int nq = (a.S + NWAVES * 32 - 1) / (NWAVES * 32), rep = a.H / a.KV;
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int qb = j % nq, t_ = j / nq, member = t_ % rep, grp = (t_ / rep) * 8 + xcd;
-  if (grp >= a.KV * a.B) return;                     // grid is padded to a multiple of 8 groups; uniform per block
-  const int b = grp / a.KV, head = (grp - b * a.KV) * rep + member;
-  const int hkv = head / (a.H / a.KV);
-  const int q0 = qb * (NWAVES * 32);
-  const int qw = q0 + wave * 32;
-  const int n_tiles_all = (a.S + 63) >> 6;
-  int last_q = q0 + NWAVES * 32 - 1; if (last_q > a.S - 1) last_q = a.S - 1;
-  const int n_tiles = n_tiles_all;                  // (non-causal only: the launcher sends causal problems to attn_fwd_kernel)
-
-  // ---- DMA source offsets inside a page (elements), loop invariant --------------------------------
-  unsigned koff[NIK], voff[NIK];              // BYTE offsets (32-bit): the page base stays in SGPRs, no 64-bit VALU adds per piece
-#pragma unroll
-  for (int i = 0; i < NIK; ++i) {
-    const int pos = i * NT + tid;
-    const int kr = pos / CPR, kpc = pos - kr * CPR;
-    koff[i] = (unsigned)(kr * D + KSwz<D>::logical(kr, kpc) * 8) * 2;
-    const int vr = pos >> 3, vpc = pos & 7;
-    voff[i] = (unsigned)(vr * 64 + (vpc ^ ((vr >> 1) & 7)) * 8) * 2;
-  }
-  // ---- Q fragments (MFMA B operand): lane (q = qw + l31, h) holds d = kk*16 + 8h + 0..7 ----------
-  bf16x8_t qf[DK];
-  {
-    int qi = qw + l31; if (qi > a.S - 1) qi = a.S - 1;
-    const bf16_t* qp = a.Q + (((size_t)b * a.H + head) * a.S + qi) * D + 8 * h;
-#pragma unroll
-    for (int kk = 0; kk < DK; ++kk) qf[kk] = *(const bf16x8_t*)(qp + kk * 16);
-    // make hipcc retire these loads HERE: otherwise its scoreboard keeps them pending around the loop back-edge and
-    // emits vmcnt(5..0) waits inside every iteration, which (in hardware) also drain our un-counted DMA ring
-#pragma unroll
-    for (int kk = 0; kk < DK; ++kk) asm volatile("" ::"v"(qf[kk]));
-  }
-
-  // page ids of this (b) row of the block table, staged in LDS once: a per-iteration global load of the table would
-  // make hipcc wait vmcnt(0) (draining the DMA ring) every tile
-  int* pages_s = (int*)(smem + NS * STAGE_BYTES);
-  for (int i = tid; i < n_tiles; i += NT) pages_s[i] = a.block_table ? a.block_table[b * a.max_pages + i] : b * n_tiles_all + i;
-  __syncthreads();
-  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-  auto stage = [&](int buf, int t) {
-    const int pg = __builtin_amdgcn_readfirstlane(pages_s[t]);
-    const size_t pb = ((size_t)pg * a.KV + hkv) * (size_t)(64 * D);
-    const bf16_t* kp = a.Kt + pb;
-    const bf16_t* vp = a.Vt + pb;
-    const unsigned base = smem_base + buf * STAGE_BYTES + wave * 1024;
-    if constexpr (NIK == 2 || NIK == 3) {
-      glds16xn<NIK>(kp, koff, base, NT * 16);
-      glds16xn<NIK>(vp, voff, base + TILE_BYTES, NT * 16);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NIK; ++i) glds16((const char*)kp + koff[i], base + i * NT * 16);
-#pragma unroll
-      for (int i = 0; i < NIK; ++i) glds16((const char*)vp + voff[i], base + TILE_BYTES + i * NT * 16);
-    }
-  };
-
-  f32x16_t o[DB];
-#pragma unroll
-  for (int i = 0; i < DB; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  const float sc = a.scale * 1.4426950408889634f;  // scores in log2 units
-
-  // K fragment rows (permuted) and their swizzled chunk offsets; V^T fragment rows
-  const int krow0 = kperm(l31);
-  const int vswz = (l31 >> 1) & 7;
-  const int my_q = qw + l31;
-
-  // 3-slot ring, one tile in flight at every loop top: tile t + 2 is requested at the top of iteration t and awaited at the top of t + 1.
-  // A wave issues in order, so the overlap has to be written into the instruction stream: region C interleaves the 12 S^T MFMAs of
-  // tile t + 1 with the exp2 / scale VALU work of tile t, region D the 12 P.V MFMAs of tile t with the row-max VALU work of tile t + 1
-  // (sched_group_barrier: one LDS read, one MFMA, a handful of VALU instructions, twelve times).  The data-dependent rescale branch sits
-  // between the regions; the partial-tile mask only exists in the peeled last iterations.
-  auto qk = [&](f32x16_t (&s)[2], int slot) {
-    const char* kb_ = smem + slot * STAGE_BYTES;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < DK; ++kk) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const int row = kb * 32 + krow0;
-        const bf16x8_t kf = *(const bf16x8_t*)(kb_ + row * (D * 2) + (KSwz<D>::phys(row, kk * 2 + h) << 4));
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
-      }
-    }
-  };
-  auto mask_tail = [&](f32x16_t (&s)[2], int t) {  // keys >= S of the last, partial tile
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = t * 64 + kb * 32 + (r >> 3) * 16 + 8 * h + (r & 7);
-        s[kb][r] = key >= a.S ? -1e30f : s[kb][r];
-      }
-  };
-  auto maxp = [&](f32x16_t (&s)[2]) -> float {
-    float mx = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; r += 1) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-  };
-  auto rescale = [&](float mx) {
-    if (!__all((mx - m_run) * sc <= a.lazy)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
-      m_run = m_new;
-#pragma unroll
-      for (int i = 0; i < DB; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
-      if constexpr (!ONES) l_run *= alpha;
-    }
-  };
-  auto expp = [&](f32x16_t (&s)[2]) {
-    const float nm = -m_run * sc;
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, nm));
-        s[kb][r] = p;
-        if constexpr (!ONES) psum += p;
-      }
-    if constexpr (!ONES) l_run += psum;
-  };
-  auto pv = [&](f32x16_t (&s)[2], int slot) {
-    const char* vb_ = smem + slot * STAGE_BYTES + TILE_BYTES;
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      const int kb = st >> 1, r0 = (st & 1) * 8;
-      union { bf16x8_t v; unsigned u[4]; } pf;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pf.u[e] = pack2bf(s[kb][r0 + 2 * e], s[kb][r0 + 2 * e + 1]);
-      const int coff = ((st * 2 + h) ^ vswz) << 4;
-#pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        const bf16x8_t vf = *(const bf16x8_t*)(vb_ + (db * 32 + l31) * 128 + coff);
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o[db], 0, 0, 0);
-      }
-    }
-  };
-  auto top = [&](int t) {                          // tile t + 1 landed for everybody, slot of tile t - 1 free; request tile t + 2
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (t + 2 < n_tiles) stage((t + 2) % 3, t + 2);
-  };
-#define GVL_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-  constexpr int NM_QK = 2 * DK, NM_PV = 4 * DB;    // MFMAs of a tile's S^T / P.V
-  auto iter = [&](f32x16_t (&cur)[2], f32x16_t (&nxt)[2], float mxc, float& mxn, int t, bool mask_next) {
-    top(t);
-    rescale(mxc);
-    __builtin_amdgcn_sched_barrier(0);
-    qk(nxt, (t + 1) % 3);                          // region C
-    expp(cur);
-#pragma unroll
-    for (int i = 0; i < NM_QK; ++i) { GVL_SGB(0x100, 1); GVL_SGB(0x008, 1); GVL_SGB(0x002, (64 + NM_QK - 1) / NM_QK + (ONES ? 0 : 3)); }
-    __builtin_amdgcn_sched_barrier(0);
-    if (mask_next) mask_tail(nxt, t + 1);
-    pv(cur, t % 3);                                // region D
-    mxn = maxp(nxt);
-    if (!mask_next) {
-#pragma unroll
-      for (int i = 0; i < NM_PV; ++i) { GVL_SGB(0x100, 1); GVL_SGB(0x008, 1); GVL_SGB(0x002, 3); }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto last = [&](f32x16_t (&cur)[2], float mxc, int t) {
-    top(t);
-    rescale(mxc);
-    expp(cur);
-    pv(cur, t % 3);
-  };
-  f32x16_t sA[2], sB[2];
-  float mxA = 0.f, mxB = 0.f;
-  const bool tail_mask = (a.S & 63) != 0;
-  stage(0, 0);
-  if (n_tiles > 1) stage(1, 1);
-  if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIK) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  qk(sA, 0);
-  if (n_tiles == 1 && tail_mask) mask_tail(sA, 0);
-  mxA = maxp(sA);
-  int t = 0;
-  for (; t + 3 < n_tiles; t += 2) {                // two tiles per trip (the score tiles swap roles without register moves); tiles t + 1,
-    iter(sA, sB, mxA, mxB, t, false);              // t + 2 <= n - 2 are never the partial one
-    iter(sB, sA, mxB, mxA, t + 1, false);
-  }
-  // 1, 2 or 3 tiles left, scores of tile t in sA
-  if (t + 2 < n_tiles) {                           // three: t (plain next), t + 1 (next = last), t + 2
-    iter(sA, sB, mxA, mxB, t, false);
-    iter(sB, sA, mxB, mxA, t + 1, tail_mask);
-    last(sA, mxA, t + 2);
-  } else if (t + 1 < n_tiles) {                    // two
-    iter(sA, sB, mxA, mxB, t, tail_mask);
-    last(sB, mxB, t + 1);
-  } else {
-    last(sA, mxA, t);
-  }
-#undef GVL_SGB
-
-  // ---- epilogue -------------------------------------------------------------------------------------
-  float l_tot;
-  if constexpr (ONES) {
-    // row Dout of O^T: block DB-1, local row lr = Dout - 32 (DB-1); MFMA layout row = (reg & 3) + 8 (reg >> 2) + 4 h -> held by the
-    // h = 0 lane of the query in register (lr / 8) * 4 + lr % 4 (the launcher only selects ONES when lr % 8 < 4)
-    const int lr = a.Dout - 32 * (DB - 1);
-    float mine = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) mine = (e == (lr >> 3) * 4 + (lr & 3)) ? o[DB - 1][e] : mine;
-    const float other = __shfl_xor(mine, 32, 64);
-    l_tot = h ? other : mine;
-  } else {
-    l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  }
-  const float inv = 1.f / l_tot;
-  // Row-per-lane store, widened (MI355X guide T21): lanes l and l+32 hold columns 8g..8g+3 / 8g+4..8g+7 of the SAME row, so
-  // one v_permlane32_swap per dword pairs the column groups (g, g+1): afterwards the lower half-wave owns all 8 columns of
-  // group g and the upper half-wave those of group g+1 -> one 16-byte store per lane per pair instead of two 8-byte ones.
-  {
-    const int qs = my_q < a.S ? my_q : a.S - 1;
-    char* op = (char*)(a.O + ((size_t)b * a.S + qs) * (size_t)(a.H * a.Dout) + head * a.Dout);
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        const int g0 = 2 * gp;
-        unsigned ax = pack2bf(o[db][4 * g0] * inv, o[db][4 * g0 + 1] * inv), ay = pack2bf(o[db][4 * g0 + 2] * inv, o[db][4 * g0 + 3] * inv);
-        unsigned bx = pack2bf(o[db][4 * g0 + 4] * inv, o[db][4 * g0 + 5] * inv), by = pack2bf(o[db][4 * g0 + 6] * inv, o[db][4 * g0 + 7] * inv);
-        const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false); ax = rx[0]; bx = rx[1];
-        const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false); ay = ry[0]; by = ry[1];
-        const int grp = db * 4 + g0 + h;           // column group this lane now owns entirely
-        if (my_q < a.S && grp * 8 < a.Dout) {
-          const u32x4_t w = {ax, ay, bx, by};
-          *(u32x4_t*)(op + grp * 16) = w;
-        }
-      }
-  }
-}
+// (A software-pipelined variant -- S^T of tile t + 1 issued under the softmax of tile t, third ring slot, second score tile, two waves per
+//  SIMD -- was built in round 2, passed every test and measured 16 % SLOWER (19.6 vs 16.9 ms of attention per clip): removed in round 3,
+//  DESIGN.md §3.2 keeps the numbers.)
 template <int D, int NWAVES, int NS, int ONES = 0>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
   constexpr int LDS = NS * 2 * 64 * D * 2 + 1024;   // ring + page-id table (256 pages)
   static bool attr_set = false;
   auto kern = attn_fwd_kernel<D, NWAVES, NS, ONES>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-    attr_set = true;
-  }
-  const int nq = (a.S + NWAVES * 32 - 1) / (NWAVES * 32);
-  dim3 grid((unsigned)(((a.KV * a.B + 7) / 8) * 8 * (a.H / a.KV) * nq));
-  hipLaunchKernelGGL(kern, grid, dim3(NWAVES * 64), LDS, st, a);
-  return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
-template <int D, int NWAVES, int ONES = 0>
-static int launch_attn_pipe(const AttnArgs& a, hipStream_t st) {
-  constexpr int LDS = 3 * 2 * 64 * D * 2 + 1024;
-  static bool attr_set = false;
-  auto kern = attn_fwd_pipe_kernel<D, NWAVES, ONES>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
     attr_set = true;
@@ -583,24 +296,19 @@ double gvl_attn_flops(const AttnArgs& a) {
 
 int gvl_launch_attention(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
-  static const float lazy = [] { const char* e = getenv("GVL_ATTN_LAZY"); return e ? (float)atof(e) : 8.f; }();      // A/B: 0 = move the reference whenever a max grows
+  static const float lazy = [] { const char* e = gvl_lab_env("GVL_ATTN_LAZY"); return e ? (float)atof(e) : 8.f; }();      // A/B: 0 = move the reference whenever a max grows
   a.lazy = lazy >= 0.f && lazy <= 64.f ? lazy : 8.f;
-  // opt-in: the software-pipelined loop for the vision towers (attn_fwd_pipe_kernel).  Correct (the operator / tower / C0 tests pass with
-  // it) but SLOWER on this compiler: 19.6 ms of attention per clip against 16.9 -- two waves per SIMD with hipcc's best-effort
-  // interleave lose to three un-pipelined ones.  Kept as the starting point for a hand-scheduled loop body.
-  static const bool pipe = [] { const char* e = getenv("GVL_ATTN_PIPE"); return e ? atoi(e) != 0 : false; }();
   if (a.B <= 0 || a.S <= 0 || a.S > 256 * 64 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 7) || ((uintptr_t)a.O & 15)) return -1;   // 16-byte O stores
   switch (a.D) {
     // ring depth 2: 48 KB (D=96) -> 3 blocks / CU at 151 VGPRs (measured 427 us vs 461 us for the 73 KB depth-3 ring, which
     // caps residency at 2 blocks / CU; DMA latency is not the limiter -- PMC shows the kernel is VALU-issue-bound)
-    case 64: return (pipe && !a.causal) ? launch_attn_pipe<64, 4>(a, st) : launch_attn<64, 4, 2>(a, st);
+    case 64: return launch_attn<64, 4, 2>(a, st);
     case 96: {
-      static const bool no_ones = getenv("GVL_ATTN_NO_ONES") != nullptr;                       // A/B
+      static const bool no_ones = gvl_lab_env("GVL_ATTN_NO_ONES") != nullptr;                       // A/B
       // (192-query blocks of 6 waves -- 3 % instead of 5.9 % tail waste at S = 2049, K/V tiles shared by more waves -- measured 24.6 ms
       //  of attention per clip against 18.0: two 98 KB blocks per CU hide less latency than three 49 KB ones.  Round 2, dropped.)
       const int lr = a.Dout - 64;
       const bool ones = a.ones_row && !no_ones && a.Dout < 96 && lr >= 0 && (lr & 7) < 4 && !a.causal;
-      if (pipe && !a.causal) return ones ? launch_attn_pipe<96, 4, 1>(a, st) : launch_attn_pipe<96, 4>(a, st);
       return ones ? launch_attn<96, 4, 2, 1>(a, st) : launch_attn<96, 4, 2>(a, st);
     }
     case 128: return launch_attn<128, 4, 2>(a, st);
@@ -1091,14 +799,14 @@ __global__ __launch_bounds__(256, 2) void decode_attn_gqa_kernel(const DecodeAtt
 
 template <int D>
 static int launch_decode_g(const DecodeAttnArgs& a, hipStream_t st) {
-  static const bool no_gqa = getenv("GVL_DECODE_ATTN_NOGQA") != nullptr;      // A/B: the round-1 grid for GQA models
+  static const bool no_gqa = gvl_lab_env("GVL_DECODE_ATTN_NOGQA") != nullptr;      // A/B: the round-1 grid for GQA models
   const int G = a.H / a.KV;
-  static const bool gqa_valu = getenv("GVL_DECODE_ATTN_GQA_VALU") != nullptr;  // A/B: the per-head VALU kernel on the XCD-aware grid
+  static const bool gqa_valu = gvl_lab_env("GVL_DECODE_ATTN_GQA_VALU") != nullptr;  // A/B: the per-head VALU kernel on the XCD-aware grid
   if (G > 1 && G <= 16 && !no_gqa && !gqa_valu && D % 32 == 0) {
     DecodeAttnArgs b = a;
     if (b.hpb < 1 || b.hpb > G || G % b.hpb) b.hpb = G;
     const int units = (b.H / b.hpb) * b.gsplit * b.batch;
-    static const bool direct_env = getenv("GVL_DECODE_ATTN_GQA_DIRECT") != nullptr;   // A/B: operands straight from global memory
+    static const bool direct_env = gvl_lab_env("GVL_DECODE_ATTN_GQA_DIRECT") != nullptr;   // A/B: operands straight from global memory
     const bool direct = direct_env || (D & (D - 1)) != 0;                            // the staged tiles need power-of-two rows (64 / 128)
     if (direct) {
       if (b.hpb <= 4) hipLaunchKernelGGL((decode_attn_gqa_kernel<D, 4, 0>), dim3(units), dim3(256), 0, st, b);

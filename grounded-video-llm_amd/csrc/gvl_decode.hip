@@ -374,7 +374,7 @@ int gvl_launch_dgemm(const GemvArgs& a_in, hipStream_t st) {
   if (a.rope_on && ((a.Dr & 1) || (a.N & 3))) return -1;
   if (a.act == GVL_ACT_SILU_MUL && (a.N & 3)) return -1;
   // variant (experiments: GVL_DGEMM_VARIANT = rb*1000 + nw*100 + u*10 + nt; 0 = the measured default)
-  static const int env_variant = [] { const char* e = getenv("GVL_DGEMM_VARIANT"); return e ? atoi(e) : 0; }();
+  static const int env_variant = [] { const char* e = gvl_lab_env("GVL_DGEMM_VARIANT"); return e ? atoi(e) : 0; }();
   int variant = a.variant ? a.variant : env_variant;
   if (variant == 0) {                              // measured (tools/decode_bench.py, profiles/r02_decode_microbench.txt)
     variant = (a.N >= 16384 ? 2000 : 1000) + 800 + 40 + 1;

@@ -717,9 +717,9 @@ static int launch_pp(const GemmArgs& a_in, hipStream_t st) {
   GemmArgs a = a_in;
   const int tiles_m = (a.M - a.m_begin + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const int tiles = tiles_m * tiles_n;
-  static const bool no_persist = getenv("GVL_GEMM_NO_PERSIST") != nullptr;                // A/B only
+  static const bool no_persist = gvl_lab_env("GVL_GEMM_NO_PERSIST") != nullptr;                // A/B only
   const int grid = (tiles <= n_cu || no_persist) ? tiles : n_cu;
-  static const bool timing = getenv("GVL_GEMM_TIMING") != nullptr;                        // anatomy probe (tools/gemm_one.py)
+  static const bool timing = gvl_lab_env("GVL_GEMM_TIMING") != nullptr;                        // anatomy probe (tools/gemm_one.py)
   if (timing) {
     GemmArgs b = a;
     const size_t n = (size_t)grid * 8 * 4;
@@ -775,7 +775,7 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
   if (a.K % BK != 0 || a.N % 4 != 0 || a.lda % 8 != 0 || a.ldw % 8 != 0 || a.ldw < a.K) return -1;   // K padded to 64 by the packer; 16-byte rows
   if (a.act == GVL_ACT_SILU_MUL && (a.out_f32 || a.resid || a.gamma)) return -1;
   int cfg = a.tile_cfg;
-  static const int env_cfg = [] { const char* e = getenv("GVL_GEMM_CFG"); return e ? atoi(e) : 0; }();   // experiments only
+  static const int env_cfg = [] { const char* e = gvl_lab_env("GVL_GEMM_CFG"); return e ? atoi(e) : 0; }();   // experiments only
   if (cfg == 0 && env_cfg) cfg = env_cfg;
   if (cfg == 0) {
     // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_microbench*.txt):
@@ -799,7 +799,7 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     // cost of up to one CU-count of small tiles, in big-tile times.  Half the FLOPs at ~0.76x the rate would be 0.33, but an
     // under-filled small launch runs its lone blocks far below that rate: same-box A/B of the whole bench, 0.33 / 0.45-0.75 / 0.90
     // -> GEMM time 73.4 / 73.0 / 75.7 ms per clip (GVL_GEMM_SMALLCOST = percent, experiments only)
-    static const double small_unit = [] { const char* e = getenv("GVL_GEMM_SMALLCOST"); return e ? atoi(e) / 100.0 : 0.5; }();
+    static const double small_unit = [] { const char* e = gvl_lab_env("GVL_GEMM_SMALLCOST"); return e ? atoi(e) / 100.0 : 0.5; }();
     auto small_cost = [&](long t) { const long halves = (t + n_cu - 1) / n_cu; return t > 0 ? small_unit * (double)halves : 0.0; };
     struct Plan { double cost; int big_rows; };   // big_rows = tile rows given to the big kernel (all of them: no M split)
     auto plan_mw = [&](int M, int N) {            // best of W and M for an [M, N] problem
@@ -855,7 +855,7 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
   const bool stg_ok = a.N % 16 == 0 && a.grp_rows == 0 && ((size_t)a.ldc * es) % 16 == 0 && ((uintptr_t)a.C & 15) == 0 &&
                       (!a.resid || (((size_t)a.ldr * es) % 16 == 0 && ((uintptr_t)a.resid & 15) == 0));
   if (cfg == 21 && a.tile_cfg == 21 && env_cfg == 0) {   // planner remainder / tail launches only
-    static const int small64 = [] { const char* e = getenv("GVL_GEMM_SMALL64"); return e ? atoi(e) : 3; }();   // 0 = off (A/B); measured -0.6 ms of GEMM time per clip
+    static const int small64 = [] { const char* e = gvl_lab_env("GVL_GEMM_SMALL64"); return e ? atoi(e) : 3; }();   // 0 = off (A/B); measured -0.6 ms of GEMM time per clip
     static const int n_cu2 = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
     const long t128 = (long)((a.M - a.m_begin + 127) / 128) * ((a.N + 127) / 128);
     if (small64 && t128 * 2 <= (long)small64 * n_cu2) cfg = 22;
@@ -877,16 +877,9 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     // ONE 128x128 block (remainder rows / tail columns of the planner: 193-264 tiles on 512 slots).  Same k-order per output
     // element as every other cfg, so the results are bit-identical.
     case 22: {
-      // 3-slot ring (two k-tiles of DMA in flight, 72 KB: still 2 blocks per CU) unless GVL_GEMM_RING=2 (A/B)
-      static const int ring = [] { const char* e = getenv("GVL_GEMM_RING"); return e ? atoi(e) : 3; }();
-      if (stg_ok && ring == 3) switch (epi) {
-#define S_CASE(E) case E: return launch_cfg<64, 128, 2, 2, 1, E, 1, 3>(a, st);
-        S_CASE(0) S_CASE(32) S_CASE(33) S_CASE(34) S_CASE(3) S_CASE(44) S_CASE(56) S_CASE(8) S_CASE(4) S_CASE(36)
-#undef S_CASE
-        default: break;
-      }
+      // 3-slot ring (two k-tiles of DMA in flight, 72 KB: still 2 blocks per CU); the 2-slot form measured 3-15 % slower on these launches (round 2)
       if (stg_ok) switch (epi) {
-#define S_CASE(E) case E: return launch_cfg<64, 128, 2, 2, 1, E, 1>(a, st);
+#define S_CASE(E) case E: return launch_cfg<64, 128, 2, 2, 1, E, 1, 3>(a, st);
         S_CASE(0) S_CASE(32) S_CASE(33) S_CASE(34) S_CASE(3) S_CASE(44) S_CASE(56) S_CASE(8) S_CASE(4) S_CASE(36)
 #undef S_CASE
         default: break;

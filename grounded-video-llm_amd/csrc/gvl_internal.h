@@ -5,6 +5,16 @@
 
 typedef uint16_t bf16_t;  // raw bf16 bits
 
+// Kernel-selection switches of the A/B history exist only in LAB builds (GVL_BUILD_DEFS=-DGVL_LAB, tools/): the shipped library
+// reads no such environment variable -- neither per launch nor per token.  Deployment knobs (GVL_RCCL_LIB, GVL_KV_FRACTION) are documented in
+// include/gvl.h; result-neutral launch parameters that tests vary go through gvl_debug_set().
+#include <cstdlib>
+#ifdef GVL_LAB
+inline const char* gvl_lab_env(const char* name) { return getenv(name); }
+#else
+inline const char* gvl_lab_env(const char*) { return nullptr; }
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA A/B operand (4 VGPRs)
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 MFMA accumulator
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;

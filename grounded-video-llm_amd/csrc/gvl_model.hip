@@ -366,14 +366,13 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
   // block works through (cpb) are free.  cpb stays 1: letting a block amortise its publish -> ticket tail over 8 / 16 pages was
   // measured neutral to slower (Phi-3.5, 3.5 k context, 16 sequences: 2631 tok/s at cpb 1, 2613 at 2, 2574 at 4; one sequence:
   // 455 / 445 / 408) -- at 5.5 TB/s over pages scattered through a 244 GB pool the page reads, not the tail, are the limit.
-  // GVL_DECODE_ATTN_CPB overrides (A/B, tests).  Under stream capture the shape must stay valid for later steps: every slot.
+  // gvl_debug_set("decode_attn_cpb") overrides (tests).  Under stream capture the shape must stay valid for later steps: every slot.
   int gsplit = ctx->nsplit, cpb = 1, hpb = 0;
   { hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (st == nullptr || hipStreamIsCapturing(st, &cs) != hipSuccess || cs == hipStreamCaptureStatusNone) {
       int nsb[GVL_MAX_DECODE_BATCH];
       for (int b = 0; b < B; ++b) { const int np = (sqs[b]->pos + 1 + 63) >> 6; const int n = (np + 3) >> 2; nsb[b] = n < 1 ? 1 : (n > ctx->nsplit ? ctx->nsplit : n); }
-      const char* fe = getenv("GVL_DECODE_ATTN_CPB");           // A/B and tests/test_gpu_llm.py (read per step on purpose: the test flips it)
-      const int force_cpb = fe ? atoi(fe) : 0;
+      const int force_cpb = ctx->dbg.decode_attn_cpb;          // gvl_debug_set: tests vary this result-neutral launch parameter
       if (force_cpb >= 1 && force_cpb <= 16) cpb = force_cpb;
       gsplit = 1; for (int b = 0; b < B; ++b) { const int g = (nsb[b] + cpb - 1) / cpb; gsplit = g > gsplit ? g : gsplit; }
       // grouped-query models: the whole group per block when that still gives >= ~1.5 blocks per CU, else fewer heads per block
@@ -384,8 +383,8 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
         hpb = G;
         while (hpb > 2 && hpb % 2 == 0 && (long)(H / hpb) * splits < 400) hpb >>= 1;
         if (hpb == 2 && (long)(H / 2) * splits < 200) hpb = 1;
-        const char* he = getenv("GVL_DECODE_ATTN_HPB");          // A/B and tests (read per step on purpose)
-        if (he && atoi(he) >= 1 && G % atoi(he) == 0) hpb = atoi(he);
+        const int fh = ctx->dbg.decode_attn_hpb;                 // gvl_debug_set
+        if (fh >= 1 && G % fh == 0) hpb = fh;
       }
     } }
   auto proj = [&](GemvArgs& g, const float* wscale) {
@@ -450,8 +449,7 @@ struct StepGraph {
   ~StepGraph() { if (e) hipGraphExecDestroy(e); if (g) hipGraphDestroy(g); }
 };
 int decode_step_replay(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st, StepGraph& sg) {
-  static const int graph_on = [] { const char* e = getenv("GVL_DECODE_GRAPH"); return e ? atoi(e) : 0; }();
-  if (!graph_on || ctx->prof || st == nullptr || sg.failed) return decode_step(ctx, sqs, B, st);
+  if (!ctx->dbg.decode_graph || ctx->prof || st == nullptr || sg.failed) return decode_step(ctx, sqs, B, st);
   if (!sg.e) {
     if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); sg.failed = true; return decode_step(ctx, sqs, B, st); }
     const int rc = decode_step(ctx, sqs, B, st);               // recorded, not executed; the host counters advance once
@@ -610,7 +608,7 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
     if (ok) { memset(ctx->h_eos_flags, 0, (size_t)gvl_ctx::kMaxSeqs * 4); ok &= hipHostGetDevicePointer((void**)&ctx->d_eos_flags, ctx->h_eos_flags, 0) == hipSuccess; }
     for (int i = 0; i < 3 && ok; ++i) ok &= hipEventCreateWithFlags(&ctx->step_ev[i], hipEventDisableTiming) == hipSuccess;
     {   // the skinny-GEMM decode path needs every projection's K to split over 8 waves x 32-wide MFMA steps, and rows that one wave normalises
-      const char* e = getenv("GVL_DECODE_VALU");
+      const char* e = gvl_lab_env("GVL_DECODE_VALU");
       ctx->decode_mfma = !(e && atoi(e)) && f.hidden % 256 == 0 && f.inter % 256 == 0 && (f.heads * ctx->l_Dr) % 256 == 0 && f.hidden <= 4096 && (ctx->l_Dr & 1) == 0;
     }
     ok &= hipMalloc((void**)&ctx->d_qkv, (size_t)qkvw * 2) == hipSuccess;
@@ -1039,6 +1037,16 @@ int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, voi
   return 0;
 }
 
+int gvl_debug_set(gvl_ctx* ctx, const char* key, int value) {
+  if (!ctx || !key) return GVL_ERR_ARG;
+  const std::string k = key;
+  if (k == "decode_attn_cpb") { if (value < 0 || value > 16) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: decode_attn_cpb must be 0 (default) .. 16"); ctx->dbg.decode_attn_cpb = value; }
+  else if (k == "decode_attn_hpb") { if (value < 0) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: decode_attn_hpb must be >= 0"); ctx->dbg.decode_attn_hpb = value; }
+  else if (k == "decode_graph") ctx->dbg.decode_graph = value != 0;
+  else return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: unknown key " + k);
+  return 0;
+}
+
 int gvl_set_sampling(gvl_ctx* ctx, int do_sample, float temperature, int top_k, float top_p, uint64_t seed) {
   if (!ctx) return GVL_ERR_ARG;
   if (!do_sample) { ctx->sample.on = false; return 0; }
@@ -1110,7 +1118,7 @@ int gvl_op_gemm(gvl_ctx* ctx, const uint16_t* A, const uint16_t* W, void* C, int
   hipStream_t st = (hipStream_t)stream;
   GemmArgs g = gemm(A, K, W, C, act == GVL_ACT_SILU_MUL ? N / 2 : N, M, N, K);
   g.bias = bias; g.gamma = gamma; g.resid = resid; g.ldr = N; g.act = act; g.out_f32 = out_f32; g.round_pre_resid = 1; g.tile_cfg = tile_cfg;
-  if (const char* e = getenv("GVL_LAB_LD")) { int la = 0, lw = 0; if (sscanf(e, "%d,%d", &la, &lw) == 2) { g.lda = la; g.ldw = lw; } }   // LAB: operand row pitches (tools/gemm_lab.py)
+  if (const char* e = gvl_lab_env("GVL_LAB_LD")) { int la = 0, lw = 0; if (sscanf(e, "%d,%d", &la, &lw) == 2) { g.lda = la; g.ldw = lw; } }   // LAB: operand row pitches (tools/gemm_lab.py)
   RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
   return 0;
 }

@@ -397,6 +397,10 @@ class Engine:
                   "gvl_op_rmsnorm")
         return y
 
+    def debug_set(self, key: str, value: int):
+        """gvl_debug_set: result-neutral launch parameters ("decode_attn_cpb", "decode_attn_hpb", "decode_graph"); 0 = the launcher's choice."""
+        self._chk(self.lib.gvl_debug_set(self.ctx, key.encode(), int(value)), "gvl_debug_set")
+
     def set_sampling(self, do_sample, temperature=1.0, top_k=50, top_p=None, seed=0):
         """Token selection of every later prefill / decode call: greedy argmax (do_sample False) or temperature / top-k / top-p sampling
         on the device (HF generate's do_sample=True; `top_k` 50 is HF's GenerationConfig default, `top_p` None / 1.0 = off)."""

@@ -74,6 +74,7 @@ _SIGS = {
                                    C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "gvl_op_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "gvl_op_rmsnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "gvl_debug_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "gvl_set_sampling": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint64]),
     "gvl_op_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gvl_op_dgemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -218,6 +218,13 @@ enum { GVL_PROF_GEMM = 0, GVL_PROF_ATTN = 1, GVL_PROF_GEMV = 2, GVL_PROF_DECODE_
 int gvl_prof_enable(gvl_ctx* ctx, int on);
 int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launches, double* work);
 
+/* Result-neutral launch parameters, for tests and A/B measurements (the shipped library reads no kernel-selection environment variable):
+ *   "decode_attn_cpb"  consecutive context splits one decode-attention block works through (0 = launcher's choice, 1..16)
+ *   "decode_attn_hpb"  query heads of a KV head served by one block of the grouped-query decode kernel (0 = launcher's choice)
+ *   "decode_graph"     1 (default): a decode group's step is captured once and replayed as a hipGraph for the following tokens; 0: eager
+ * None of them may change a single output bit (asserted in tests/test_gpu_llm.py). */
+int gvl_debug_set(gvl_ctx* ctx, const char* key, int value);
+
 /* ---- operator-level entry points (parity tests call the kernels through these) --------------- */
 /* C[M,N] = act(A[M,K] W[N,K]^T + bias) (+ resid); A,W bf16; bias/gamma f32 or NULL.
  * act: 0 none, 1 quick_gelu, 2 gelu(erf), 3 silu(gate)*up on interleaved (gate,up) column pairs

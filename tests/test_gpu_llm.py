@@ -560,10 +560,10 @@ def test_sampling_inside_the_decode_loop_is_reproducible_and_batch_invariant():
 @pytest.mark.parametrize("kind", ["mha", "gqa"])
 def test_decode_attention_result_is_independent_of_the_launch_shape(kind):
     """Decode attention splits a sequence's context into one split per 4 pages of ITS OWN length and publishes one partial per split;
-    how many consecutive splits a block works through (cpb, a launch parameter; default 1, GVL_DECODE_ATTN_CPB overrides), how many
+    how many consecutive splits a block works through (cpb, a launch parameter; default 1, gvl_debug_set("decode_attn_cpb") overrides), how many
     block slots the grid offers and -- in the grouped-query kernel (matrix pipe, the page read once for the query heads of a KV
     head) -- how many of the group's heads share a block (hpb: the host takes the whole group for large launches, fewer heads per
-    block for a single sequence; GVL_DECODE_ATTN_HPB overrides) are free choices of the host.  The ids and logits must not depend on
+    block for a single sequence; gvl_debug_set("decode_attn_hpb") overrides) are free choices of the host.  The ids and logits must not depend on
     them: contexts of 9 and 17 splits (one past a page boundary, one crossing 4096 tokens where the split count is clamped to 16),
     forced cpb = 1, 2, 3, 4, 16 (and hpb = 1, 2, 4 for the GQA model: 8 query heads on 2 KV heads) against the default choice."""
     import os
@@ -591,23 +591,18 @@ def test_decode_attention_result_is_independent_of_the_launch_shape(kind):
             eng.seq_free(s)
         return ids, lg
 
-    keys = ("GVL_DECODE_ATTN_CPB", "GVL_DECODE_ATTN_HPB")
-    old = {k: os.environ.pop(k, None) for k in keys}
-    try:
-        ref_ids, ref_lg = run()
-        shapes = [(cpb, None) for cpb in (1, 2, 3, 4, 16)] + ([(1, 1), (1, 2), (1, 4), (4, 2)] if kind == "gqa" else [])
+    ref_ids, ref_lg = run()
+    shapes = [(cpb, None) for cpb in (1, 2, 3, 4, 16)] + ([(1, 1), (1, 2), (1, 4), (4, 2)] if kind == "gqa" else [])
+    for graph in (1, 0):                            # replayed (default) and eager decode steps
+        eng.debug_set("decode_graph", graph)
         for cpb, hpb in shapes:
-            os.environ["GVL_DECODE_ATTN_CPB"] = str(cpb)
-            if hpb is not None:
-                os.environ["GVL_DECODE_ATTN_HPB"] = str(hpb)
+            eng.debug_set("decode_attn_cpb", cpb)
+            eng.debug_set("decode_attn_hpb", hpb or 0)
             ids, lg = run()
-            assert ids == ref_ids, f"cpb {cpb} hpb {hpb}: ids differ"
-            assert all(torch.equal(a, b) for a, b in zip(lg, ref_lg)), f"cpb {cpb} hpb {hpb}: logits differ"
-    finally:
-        for k in keys:
-            os.environ.pop(k, None)
-            if old[k] is not None:
-                os.environ[k] = old[k]
+            assert ids == ref_ids, f"cpb {cpb} hpb {hpb} graph {graph}: ids differ"
+            assert all(torch.equal(a, b) for a, b in zip(lg, ref_lg)), f"cpb {cpb} hpb {hpb} graph {graph}: logits differ"
+    with pytest.raises(RuntimeError):
+        eng.debug_set("no_such_key", 1)
     eng.close()
 
 

@@ -1,6 +1,6 @@
 """Decode-only throughput of the full-size LLM through the C ABI: tokens/s for groups of 1 / 4 / 16 sequences at a short and at the
 BASELINE context (3.5 k), and the fraction of the HBM roofline (weights 7.45 GB + KV 384 KB x context per Phi-3.5 token).
-  GVL_DECODE_GRAPH=1 GVL_E2E_S=64,3519 GVL_E2E_B=1,16 python tools/decode_e2e.py [phi|llama]"""
+  GVL_E2E_GRAPH=0 GVL_E2E_S=64,3519 GVL_E2E_B=1,16 python tools/decode_e2e.py [phi|llama]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import _gvl_bootstrap  # noqa
@@ -26,7 +26,9 @@ W = synth.llm_weights(kind, geo.hidden, geo.inter, geo.layers, geo.heads, geo.kv
 eng.load_packed(Wt.pack_llm(W, kind, geo.layers, geo.heads, geo.kv_heads, geo.max_seq, geo.rope_theta, geo.rope_short, geo.rope_long)); del W
 torch.cuda.empty_cache()
 eng.finalize()
-print("kv pool", eng.kv_info(), "graph", os.environ.get("GVL_DECODE_GRAPH", "0"), "fp8", geo.decode_fp8, flush=True)
+graph = int(os.environ.get("GVL_E2E_GRAPH", "1"))     # 1 (library default): a group's decode step is captured once and replayed
+eng.debug_set("decode_graph", graph)
+print("kv pool", eng.kv_info(), "graph", graph, "fp8", geo.decode_fp8, flush=True)
 g = torch.Generator(device=dev); g.manual_seed(1)
 new = 33
 SS = [int(x) for x in os.environ.get("GVL_E2E_S", "64,3519").split(",")]

@@ -3,31 +3,37 @@ tokens/s) for the 96-frame Phi-3.5-3.8B configuration (BASELINE.json configs[1])
 
 A "step" = one pass of the hot path over one batch of synthetic input: for every rank `--clips-per-step` (default 8)
 96-frame clips, each (12 x 336^2 spatial frames + 96 x 224^2 temporal frames, already resident in HBM) -> CLIP ViT-L/14-336
-(23 layers) + InternVideo2-1B (39 blocks) -> merge/pool + projectors -> 3420 visual tokens spliced into a
-~100-token prompt -> Phi-3.5 prefill (S ~ 3520) -> greedy decode of 12 new tokens through the paged KV cache.
-The clips of a step are prefilled one after the other and decoded TOGETHER (gvl_decode_greedy_batch: every weight matrix is
-streamed once per token for all of them -- the reference batches clips in generate() too, llava_next_video.py:622-647), while
-the vision encode of the next step's clips runs on a second stream (the CLIP tower once over the 12 x 4 key frames of the step --
-gvl_clip_encode -- then InternVideo2 + projectors per clip: gvl_iv2_encode / gvl_build_visual).  `single_clip_latency_ms` (one clip, stages back to back)
-is reported next to `value`; `--clips-per-step 1` gives the one-clip-per-step pipeline (8.6 clips/s); 4 / 8 / 12 clips per
-step measured 10.0 / 10.3 / 10.15 clips/s on one box (the decode of a step's clips is ONE skinny-GEMM group of up to 16 sequences).
-Random-init weights of the real architecture, synthetic pixels (no network for checkpoints/datasets).
+(23 layers) + InternVideo2-1B (39 blocks) -> merge/pool + projectors -> 3420 visual tokens spliced into a prompt of 60..140 tokens
+-> Phi-3.5 prefill (S ~ 3480..3560, the clips of a step packed into ONE ragged pass: gvl_prefill_varlen) -> greedy decode of 12 new
+tokens through the paged KV cache, the clips of a step decoded TOGETHER at their different lengths (gvl_decode_greedy_batch: every
+weight matrix is streamed once per token for all of them -- the reference batches clips in generate() too,
+llava_next_video.py:622-647), while the vision encode of the next step's clips runs on a second stream (the CLIP tower once over the
+12 x cps key frames of the step, then InternVideo2 + projectors per clip).  EVERY clip of a step has its own pixels and its own
+prompt (ids and length), and consecutive steps use different clips (a resident pool of 2 x cps seeded clips is cycled).
+Random-init weights of the real architecture, synthetic pixels (no network for checkpoints / datasets).
 
-N > 1 (one process per GPU, RCCL): N clips in flight per step; every clip's 12-segment frame batch is
-sharded over ALL N ranks (rotated per clip so the 12 % N remainder balances: each rank encodes exactly 12
-segments), ONE all-gather of the visual tokens over xGMI, then rank c runs the LLM for clip c.
-Weak scaling: per-GPU work is fixed.
+N > 1 (one process per GPU, RCCL), two plans, both reported:
+  * `value` (weak scaling): N x cps clips in flight per step; every clip's 12-segment frame batch is sharded over ALL N ranks
+    (rotated per clip so the 12 % N remainder balances: each rank encodes exactly 12 segments per clip round), ONE all-gather of the
+    visual tokens over xGMI per step, then rank c runs the LLM for clip c.
+  * `single_clip_latency_ms_sharded` (the north-star plan, strong scaling): ONE clip, its 12 segments sharded over the N ranks,
+    all-gather of the visual tokens, prefill + decode on rank 0 (llava_next_video.py:503-505,530-532,563 are the independent
+    segments that make the shard).
+A watchdog thread turns a hung collective into a JSON line that names the stage every rank was in (`hang`), instead of a silent
+time-out; `n_ranks_seen_by_rccl` is ncclCommCount of a communicator libgvl itself builds over all ranks (gvl_comm_init).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (the bf16 MFMA GEMM), measured
-live with HIP events on the launch stream in one extra profiled step; `cpu_baseline` is the CPU oracle timed on
-a bounded sample on the host cores (rank 0, N == 1 only).
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (the bf16 MFMA GEMM), measured live with HIP events
+on the launch stream in one extra profiled ONE-CLIP serial pass (keys say `per_clip_serial`); `cpu_baseline` is the CPU oracle
+timed on a bounded sample on the host cores (rank 0, N == 1 only).
 """
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -41,6 +47,82 @@ from grounded_video_llm_amd import dist as gdist, engine as E, lib as L, synth, 
 bf = torch.bfloat16
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+PROMPT_LEN_RANGE = (60, 140)   # text tokens of a clip's prompt (the reference's grounding / QA templates land in this range)
+
+
+# ---- progress + watchdog -------------------------------------------------------------------------------------------------------
+class Progress:
+    """What this rank is doing right now (stage name + when it started).  The watchdog thread reads it: if a stage lasts longer than
+    `limit` seconds (a hung collective, a dead peer), rank 0 still prints the ONE JSON line -- with `hang` = the stage of this rank and
+    whatever per-rank stage times were gathered so far -- and every rank says on stderr where it stood; then the process exits."""
+
+    def __init__(self, rank: int, world: int, limit_s: float, args_echo: dict):
+        self.rank, self.world, self.limit = rank, world, limit_s
+        self.stage, self.t0, self.done = "init", time.monotonic(), False
+        self.partial = {"metric": "clips/sec + grounding tokens/sec, 96-frame Phi3.5-3.8B @1/2/4/8 MI355X", "value": None, "unit": "clips/s",
+                        "n_gpus": world, "higher_is_better": True, **args_echo}
+        self.thread = None
+
+    def enter(self, stage: str):
+        self.stage, self.t0 = stage, time.monotonic()
+
+    def start(self):
+        if self.limit <= 0:
+            return
+        self.thread = threading.Thread(target=self._watch, daemon=True)
+        self.thread.start()
+
+    def _watch(self):
+        while not self.done:
+            time.sleep(min(5.0, max(0.05, self.limit / 4)))
+            stuck = time.monotonic() - self.t0
+            if not self.done and stuck > self.limit:
+                msg = {"rank": self.rank, "stage": self.stage, "seconds_in_stage": round(stuck, 1)}
+                print(f"bench: WATCHDOG rank {self.rank}/{self.world} stuck in stage '{self.stage}' for {stuck:.0f} s", file=sys.stderr, flush=True)
+                if self.rank == 0:
+                    print(json.dumps({**self.partial, "hang": msg}), flush=True)
+                os._exit(3)
+
+    def finish(self):
+        self.done = True
+
+
+# ---- device shim: the N > 1 plumbing test runs this file on CPU (gloo, stub engine) --------------------------------------------
+class _NullStream:
+    def wait_event(self, ev): pass
+    def synchronize(self): pass
+
+
+class _NullEvent:
+    def __init__(self, enable_timing=False): self.t = 0.0
+    def record(self, stream=None): self.t = time.perf_counter()
+    def elapsed_time(self, other): return 1e3 * (other.t - self.t)
+
+
+class Dev:
+    def __init__(self, dev: torch.device):
+        self.dev, self.gpu = dev, dev.type == "cuda"
+
+    def sync(self):
+        if self.gpu:
+            torch.cuda.synchronize()
+
+    def stream(self):
+        return torch.cuda.Stream(self.dev) if self.gpu else _NullStream()
+
+    def event(self, timing=False):
+        return torch.cuda.Event(enable_timing=timing) if self.gpu else _NullEvent()
+
+    def on(self, stream):
+        return torch.cuda.stream(stream) if self.gpu else contextlib.nullcontext()
+
+    def current_stream_sync(self):
+        if self.gpu:
+            torch.cuda.current_stream().synchronize()
+
+    def generator(self, seed):
+        g = torch.Generator(device=self.dev); g.manual_seed(seed)
+        return g
 
 
 def build_engine(dev, frames_per_seg=8, max_segs=12, new_tokens=12, clips_per_step=1, kv_pages=None):
@@ -64,36 +146,62 @@ def build_engine(dev, frames_per_seg=8, max_segs=12, new_tokens=12, clips_per_st
     return eng, geo
 
 
-def make_inputs(dev, rank, n_segs=12, fps=8, n_text=100):
-    g = torch.Generator(device=dev); g.manual_seed(42 + rank)
-    sp = torch.randn((n_segs, 3, 336, 336), device=dev, generator=g)
-    tp = torch.randn((n_segs, 3, fps, 224, 224), device=dev, generator=g)
-    gi = torch.Generator(); gi.manual_seed(42)
+def make_prompt(seed: int, n_text: int = 0):
+    """Token ids of one clip's prompt: n_text tokens (drawn from PROMPT_LEN_RANGE when 0) with the <image> slot (-200) after the
+    36-token system prompt, as the reference's templates place it (datasets/chat/base_template.py)."""
+    gi = torch.Generator(); gi.manual_seed(seed)
+    if n_text <= 0:
+        n_text = int(torch.randint(PROMPT_LEN_RANGE[0], PROMPT_LEN_RANGE[1] + 1, (1,), generator=gi).item())
     ids = torch.randint(3, 32000, (n_text,), generator=gi).tolist()
-    ids[36] = -200                      # the template's image slot sits after the system prompt
-    return sp, tp, ids
+    ids[36] = -200
+    return ids
+
+
+def make_pixels(D: Dev, seed: int, n_segs=12, fps=8, hw=(336, 224)):
+    g = D.generator(seed)
+    sp = torch.randn((n_segs, 3, hw[0], hw[0]), device=D.dev, generator=g)
+    tp = torch.randn((n_segs, 3, fps, hw[1], hw[1]), device=D.dev, generator=g)
+    return sp, tp
 
 
 class Stepper:
-    def __init__(self, eng, geo, rank, world, new_tokens):
+    """The stages of the hot path on one rank, over a resident POOL of distinct inputs.
+    world == 1: pool entry i = clip i (12 segments) and its prompt.  world > 1: pool entry i = the 12 segment blocks this rank encodes in
+    clip round i (rotated plan) -- every rank generates the pixels of the segments it encodes itself -- and the prompt of clip == rank."""
+
+    def __init__(self, eng, geo, rank, world, new_tokens, pool=2, hw=(336, 224)):
         self.eng, self.geo, self.rank, self.world, self.new_tokens = eng, geo, rank, world, new_tokens
-        self.dev = eng.device
-        self.sp, self.tp, self.ids = make_inputs(self.dev, rank)
+        self.D = Dev(torch.device(eng.device))
+        self.dev = self.D.dev
         self.L = eng.tokens_per_seg
         self.decode_s = 0.0
         self.h2d = False
+        self.pool = max(1, pool)
+        self.cursor = 0
+        fps = geo.frames_per_seg
+        px = [make_pixels(self.D, 42 + 1009 * i + 7919 * rank, 12, fps, hw) for i in range(self.pool)]
+        self.sp_pool = torch.cat([p[0] for p in px], 0)          # [pool * 12, 3, 336, 336]: a window of cps clips is one contiguous slice
+        self.tp_pool = torch.cat([p[1] for p in px], 0)
+        self.prompts = [make_prompt(77 + 31 * i + 7919 * rank) for i in range(self.pool)]
         if world > 1:
-            # clip c's segment block b goes to rank (b + c) % world (dist.rotated_encode_plan): every rank encodes exactly 12
-            # segments.  Synthetic pixels: every rank generates the segments it encodes itself.
+            # clip c's segment block b goes to rank (b + c) % world (dist.rotated_encode_plan): every rank encodes exactly 12 segments
             self.mine = gdist.rotated_encode_plan(12, rank, world)
             self.gather = gdist.rotated_gather_index(12, rank, world)
-            n_mine = sum(h - l for _, l, h in self.mine)
-            assert n_mine == 12
-            g = torch.Generator(device=self.dev); g.manual_seed(1000 + rank)
-            self.sp = torch.randn((n_mine, 3, 336, 336), device=self.dev, generator=g)
-            self.tp = torch.randn((n_mine, 3, 8, 224, 224), device=self.dev, generator=g)
+            assert sum(h - l for _, l, h in self.mine) == 12
 
-    # ---- the three stages of one clip ---------------------------------------------------------------------
+    # ---- pool access -------------------------------------------------------------------------------------------
+    def px(self, i):
+        i %= self.pool
+        return self.sp_pool[i * 12:(i + 1) * 12], self.tp_pool[i * 12:(i + 1) * 12]
+
+    def window(self, cps):
+        """pool indices of the next cps clips; the pool size is a multiple of cps, so the window is one contiguous slice"""
+        start = self.cursor % self.pool
+        self.cursor += cps
+        assert start + cps <= self.pool
+        return list(range(start, start + cps))
+
+    # ---- the stages of one clip ---------------------------------------------------------------------------------------
     def _exchange(self, vis, force=False):
         return self._exchange_multi([vis], force)[0]
 
@@ -106,64 +214,70 @@ class Stepper:
         cps, rows = len(vis_list), vis_list[0].shape[0]
         send = torch.cat(vis_list, 0) if cps > 1 else vis_list[0]
         recv = torch.empty((self.world * send.shape[0], send.shape[1]), dtype=bf, device=self.dev)
-        if torch.distributed.get_backend() == "gloo":                 # debug only (GVL_BENCH_BACKEND=gloo): stage through the host
+        if torch.distributed.get_backend() == "gloo" and send.device.type != "cpu":   # debug only (GVL_BENCH_BACKEND=gloo on a GPU): stage through the host
             rc = recv.cpu(); torch.distributed.all_gather_into_tensor(rc, send.cpu()); recv.copy_(rc)
         else:
-            torch.distributed.all_gather_into_tensor(recv, send)      # RCCL over xGMI
+            torch.distributed.all_gather_into_tensor(recv, send)      # RCCL over xGMI (gloo on CPU tensors in the plumbing test)
         recv = recv.view(self.world, cps, rows, -1)
         gather = self.gather if self.world > 1 else [(0, 0, rows // self.L)]
         return [torch.cat([recv[src, c, off * self.L:(off + n) * self.L] for src, off, n in gather], 0) for c in range(cps)]   # clip == rank, segment order
 
-    def encode(self):
-        """vision towers + projectors for this rank's 12 segments (+ the all-gather for N > 1) -> visual tokens of THIS rank's clip."""
+    def encode(self, i):
+        """vision towers + projectors for pool entry i (+ the all-gather for N > 1) -> visual tokens of THIS rank's clip."""
+        sp, tp = self.px(i)
         if self.h2d:                                                    # extra (untimed for `value`): pixels arrive over PCIe
-            self.sp.copy_(self.sp_host, non_blocking=True)
-            self.tp.copy_(self.tp_host, non_blocking=True)
-        return self._exchange(self.eng.encode_segments(self.sp, self.tp))   # [12*L, hidden]
+            k = i % self.pool
+            sp.copy_(self.sp_host[k * 12:(k + 1) * 12], non_blocking=True)
+            tp.copy_(self.tp_host[k * 12:(k + 1) * 12], non_blocking=True)
+        return self._exchange(self.eng.encode_segments(sp, tp))   # [12*L, hidden]
 
-    def encode_multi(self, cps):
-        """Vision encode of the next `cps` clip rounds.  The CLIP tower runs ONCE over the 12 x cps key frames of the step (per clip
-        its N = 1024 GEMMs have only 112 tiles: +1.6 % clips/s measured); InternVideo2 + projectors (+ the all-gather) stay per clip.
-        GVL_BENCH_CLIP_BATCH=0 restores one gvl_encode_segments call per clip."""
+    def encode_multi(self, idx):
+        """Vision encode of the clips `idx` (a contiguous pool window).  The CLIP tower runs ONCE over the 12 x cps key frames of the step
+        (per clip its N = 1024 GEMMs have only 112 tiles: +1.6 % clips/s measured); InternVideo2 + projectors (+ the all-gather) stay per
+        clip.  GVL_BENCH_CLIP_BATCH=0 restores one gvl_encode_segments call per clip."""
         if not self.clip_batch:
             if self.h2d:
-                return [self.encode() for _ in range(cps)]
-            return self._exchange_multi([self.eng.encode_segments(self.sp, self.tp) for _ in range(cps)])
+                return [self.encode(i) for i in idx]
+            return self._exchange_multi([self.eng.encode_segments(*self.px(i)) for i in idx])
+        lo, hi = idx[0] * 12, (idx[-1] + 1) * 12
         if self.h2d:
-            for c in range(cps):
-                self.sp_multi[c * 12:(c + 1) * 12].copy_(self.sp_host, non_blocking=True)
-            self.tp.copy_(self.tp_host, non_blocking=True)
-        cf = self.eng.clip_encode(self.sp_multi)
-        return self._exchange_multi([self.eng.build_visual(cf[c * 12:(c + 1) * 12], self.eng.iv2_encode(self.tp)) for c in range(cps)])
+            self.sp_pool[lo:hi].copy_(self.sp_host[lo:hi], non_blocking=True)
+            self.tp_pool[lo:hi].copy_(self.tp_host[lo:hi], non_blocking=True)
+        cf = self.eng.clip_encode(self.sp_pool[lo:hi])
+        return self._exchange_multi([self.eng.build_visual(cf[c * 12:(c + 1) * 12], self.eng.iv2_encode(self.px(i)[1])) for c, i in enumerate(idx)])
 
-    def stage_times(self):
-        """One clip round on this rank, stages back to back with HIP events between them (diagnosis of the N > 1 runs):
+    def stage_times(self, prog=None):
+        """One clip round on this rank, stages back to back with events between them (diagnosis of the N > 1 runs):
         vision encode of 12 segments / exchange / splice + prefill / greedy decode, in ms."""
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-        torch.cuda.synchronize()
+        ev = [self.D.event(True) for _ in range(5)]
+        self.D.sync()
+        names = ("vision_ms", "exchange_ms", "prefill_ms", "decode_ms")
+        if prog: prog.enter("stage_times:vision")
         ev[0].record()
-        vis = self.eng.encode_segments(self.sp, self.tp)
-        ev[1].record()
+        vis = self.eng.encode_segments(*self.px(0))
+        ev[1].record(); self.D.sync()
+        if prog: prog.enter("stage_times:exchange (all_gather_into_tensor)")
         vis = self._exchange(vis)
-        ev[2].record()
-        seq, _ = self.llm(vis)
-        ev[3].record()
+        ev[2].record(); self.D.sync()
+        if prog: prog.enter("stage_times:prefill")
+        seq, _ = self.llm(vis, 0)
+        ev[3].record(); self.D.sync()
+        if prog: prog.enter("stage_times:decode")
         self.decode(seq)
         ev[4].record()
-        torch.cuda.synchronize()
-        names = ("vision_ms", "exchange_ms", "prefill_ms", "decode_ms")
+        self.D.sync()
         return {n: round(ev[i].elapsed_time(ev[i + 1]), 3) for i, n in enumerate(names)}
 
-    def llm(self, vis):
+    def llm(self, vis, i):
         eng = self.eng
-        emb = eng.splice(self.ids, vis)
+        emb = eng.splice(self.prompts[i % self.pool], vis)
         seq = eng.seq_alloc(emb.shape[0] + self.new_tokens)
         eng.prefill(seq, emb)
         return seq, emb.shape[0]
 
     def decode(self, seq):
         if self.time_decode:
-            torch.cuda.current_stream().synchronize()
+            self.D.current_stream_sync()
         t0 = time.perf_counter()
         out = self.eng.decode_greedy(seq, self.new_tokens, None)       # synchronises its stream
         if self.time_decode:
@@ -171,73 +285,112 @@ class Stepper:
         self.eng.seq_free(seq)
         return out
 
-    def step(self):
+    def step(self, i=None):
         """One clip, stages back to back on one stream (single-clip latency)."""
-        vis = self.encode()
-        seq, S = self.llm(vis)
+        if i is None:
+            i = self.window(1)[0]
+        vis = self.encode(i)
+        seq, S = self.llm(vis, i)
         return self.decode(seq), S
+
+    def step_sharded(self, i=0):
+        """The north-star plan for ONE clip on N ranks: every rank encodes its contiguous share of the clip's 12 segments (the same clip
+        on every rank: pixels from a rank-independent seed), ONE all-gather of the token blocks, prefill + greedy decode on rank 0
+        (the other ranks wait at the caller's barrier).  Returns rank 0's ids."""
+        if not hasattr(self, "_shared_px"):
+            self._shared_px = make_pixels(self.D, 4242, 12, self.geo.frames_per_seg, (self.sp_pool.shape[-1], self.tp_pool.shape[-1]))
+            self._shared_prompt = make_prompt(4242)
+        sp, tp = self._shared_px
+        lo, hi = gdist.my_shard(12, self.rank, self.world)
+        local = self.eng.encode_segments(sp[lo:hi], tp[lo:hi]) if hi > lo else torch.empty((0, self.geo.hidden), dtype=bf, device=self.dev)
+        if self.world > 1:
+            if torch.distributed.get_backend() == "gloo" and local.device.type != "cpu":
+                vis = gdist.allgather_visual(local.cpu(), 12, self.L).to(self.dev)
+            else:
+                vis = gdist.allgather_visual(local, 12, self.L)
+        else:
+            vis = local
+        if self.rank != 0:
+            return None
+        emb = self.eng.splice(self._shared_prompt, vis)
+        seq = self.eng.seq_alloc(emb.shape[0] + self.new_tokens)
+        self.eng.prefill(seq, emb)
+        out = self.eng.decode_greedy(seq, self.new_tokens, None)
+        self.eng.seq_free(seq)
+        return out
 
     # ---- two clips in flight per GPU: vision of clip k+1 overlaps the (HBM-bound) decode of clip k ---------------
     def pipe_start(self):
-        self.sV, self.sL = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
-        self.evV, self.evL = torch.cuda.Event(), torch.cuda.Event()
-        with torch.cuda.stream(self.sV):
-            self.vis_next = self.encode()
+        self.sV, self.sL = self.D.stream(), self.D.stream()
+        self.evV, self.evL = self.D.event(), self.D.event()
+        with self.D.on(self.sV):
+            self.idx_next = self.window(1)
+            self.vis_next = self.encode(self.idx_next[0])
             self.evV.record(self.sV)
 
     def pipe_start_multi(self, cps):
         self.cps = cps
         self.clip_batch = os.environ.get("GVL_BENCH_CLIP_BATCH", "1") != "0" and cps > 1
-        self.sp_multi = self.sp.repeat(cps, 1, 1, 1) if self.clip_batch else None     # the key frames of the step's clips, resident
-        self.sV, self.sL = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
-        self.evV, self.evL = torch.cuda.Event(), torch.cuda.Event()
-        with torch.cuda.stream(self.sV):
-            self.vis_next = self.encode_multi(cps)
+        self.sV, self.sL = self.D.stream(), self.D.stream()
+        self.evV, self.evL = self.D.event(), self.D.event()
+        with self.D.on(self.sV):
+            self.idx_next = self.window(cps)
+            self.vis_next = self.encode_multi(self.idx_next)
             self.evV.record(self.sV)
 
     def pipe_step_multi(self):
-        """Completes `cps` clips (prefill each, then ONE batched greedy decode: the LLM weights are streamed once per token for all
-        of them -- continuous batching) and launches the vision encode of the next `cps` clips beside them."""
-        with torch.cuda.stream(self.sL):
+        """Completes `cps` clips (ONE ragged prefill over all of them, then ONE batched greedy decode: the LLM weights are streamed once
+        per token for all of them -- continuous batching) and launches the vision encode of the next `cps` clips beside them."""
+        idx = self.idx_next
+        with self.D.on(self.sL):
             self.sL.wait_event(self.evV)
             embs = []
-            for vis in self.vis_next:
-                vis.record_stream(self.sL)
-                embs.append(self.eng.splice(self.ids, vis))
-            S = embs[0].shape[0]
-            seqs = [self.eng.seq_alloc(S + self.new_tokens) for _ in embs]
+            for vis, i in zip(self.vis_next, idx):
+                if self.D.gpu:
+                    vis.record_stream(self.sL)
+                embs.append(self.eng.splice(self.prompts[i % self.pool], vis))
+            S = max(e.shape[0] for e in embs)
+            seqs = [self.eng.seq_alloc(e.shape[0] + self.new_tokens) for e in embs]
             if self.batch_prefill:
-                self.eng.prefill_batch(seqs, embs)       # the decoder GEMMs run over the rows of all clips of the step at once
+                self.eng.prefill_batch(seqs, embs)       # gvl_prefill_varlen: the decoder GEMMs run over the packed rows of all clips of the step
             else:
                 for seq, emb in zip(seqs, embs):
                     self.eng.prefill(seq, emb)
-        with torch.cuda.stream(self.sV):
-            self.vis_next = self.encode_multi(self.cps)
+        with self.D.on(self.sV):
+            self.idx_next = self.window(self.cps)
+            self.vis_next = self.encode_multi(self.idx_next)
             self.evV.record(self.sV)
-        with torch.cuda.stream(self.sL):
+        with self.D.on(self.sL):
             outs = self.eng.decode_greedy_batch(seqs, self.new_tokens, None)   # synchronises its stream
             for seq in seqs:
                 self.eng.seq_free(seq)
+        self.last_idx = idx[-1]
         return outs[-1], S
 
     def pipe_step(self):
         """Completes ONE clip (prefill + decode) and launches ONE clip's vision encode for the next step."""
-        with torch.cuda.stream(self.sL):
+        i = self.idx_next[0]
+        with self.D.on(self.sL):
             self.sL.wait_event(self.evV)                   # this clip's visual tokens are ready
             vis = self.vis_next
-            vis.record_stream(self.sL)
-            seq, S = self.llm(vis)                         # splice + prefill (uses the workspace arena)
+            if self.D.gpu:
+                vis.record_stream(self.sL)
+            seq, S = self.llm(vis, i)                      # splice + prefill (uses the workspace arena)
             self.evL.record(self.sL)
-        with torch.cuda.stream(self.sV):
+        with self.D.on(self.sV):
             if self.overlap == "decode":
                 self.sV.wait_event(self.evL)               # next clip's towers start after this clip's prefill ...
-            self.vis_next = self.encode()                  # ... and run concurrently with the decode below (MFMA-bound vs HBM-bound);
+            self.idx_next = self.window(1)
+            self.vis_next = self.encode(self.idx_next[0])  # ... and run concurrently with the decode below (MFMA-bound vs HBM-bound);
             self.evV.record(self.sV)                       # "full": also beside the prefill (separate workspace arenas), filling its tail/launch bubbles
-        with torch.cuda.stream(self.sL):
+        with self.D.on(self.sL):
             out = self.decode(seq)
+        self.last_idx = i
         return out, S
 
     time_decode = False
+    clip_batch = False
+    last_idx = 0
     batch_prefill = os.environ.get("GVL_BENCH_BATCH_PREFILL", "1") != "0"
     overlap = os.environ.get("GVL_BENCH_OVERLAP", "full")
 
@@ -309,7 +462,24 @@ def cpu_baseline(dev, new_tokens=12):
                                        + json.dumps({k: round(v, 3) for k, v in t.items()})}
 
 
-def main():
+def rccl_ranks_seen(eng, rank, world, dev, backend):
+    """libgvl's OWN communicator over all ranks (gvl_comm_unique_id on rank 0 -> broadcast -> gvl_comm_init), ncclCommCount of it, and a
+    gvl_allgather_visual of one row per rank checked against the expected rank order.  Returns (n_ranks, all-gather ok) or (None, None)
+    when the engine has no RCCL path (the CPU plumbing test's stub)."""
+    if not hasattr(eng, "comm_unique_id") or os.environ.get("GVL_BENCH_SAME_DEVICE"):      # RCCL refuses two ranks on one device (debug runs)
+        return None, None
+    uid = [eng.comm_unique_id() if rank == 0 else None]
+    torch.distributed.broadcast_object_list(uid, src=0)
+    eng.comm_init(uid[0], rank, world)
+    n = eng.comm_count()
+    local = torch.full((1, 64), float(rank + 1), dtype=bf, device=dev)
+    got = eng.allgather_visual(local)
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(got[:, 0].float().cpu(), torch.arange(1, world + 1, dtype=torch.float32)))
+    return n, ok
+
+
+def main(argv=None, engine_factory=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -318,136 +488,183 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plain", action="store_true", help="timed region only (warmup + steps clips in the process): the target of the rocprofv3 passes")
     ap.add_argument("--clips-per-step", type=int, default=int(os.environ.get("GVL_BENCH_CPS", "8")),
-                    help="pipelined mode: clips per GPU per step; their greedy decode is batched (one weight stream per token for all of them)")
+                    help="pipelined mode: clips per GPU per step; their prefill is one ragged pass and their greedy decode is batched (one weight stream per token for all of them)")
     ap.add_argument("--mode", choices=["pipelined", "serial"], default="pipelined",
-                    help="pipelined: 2 clips in flight per GPU (vision of clip k+1 overlaps decode of clip k); serial: one clip at a time")
-    args = ap.parse_args()
+                    help="pipelined: 2 x cps clips in flight per GPU (vision of the next clips overlaps prefill + decode of the current ones); serial: one clip at a time")
+    ap.add_argument("--watchdog-s", type=float, default=float(os.environ.get("GVL_BENCH_WATCHDOG_S", "900")),
+                    help="seconds one stage may last before the run is declared hung (0 = off)")
+    args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    backend = os.environ.get("GVL_BENCH_BACKEND", "nccl")        # "gloo" + GVL_BENCH_SAME_DEVICE=1: debug the N>1 path on one GPU
+    backend = os.environ.get("GVL_BENCH_BACKEND", "nccl")        # "gloo" + GVL_BENCH_SAME_DEVICE=1: debug the N>1 path on one GPU; "gloo" + a CPU engine_factory: plumbing test
+    prog = Progress(rank, world, args.watchdog_s, {"steps": args.steps, "warmup": args.warmup, "mode": args.mode})
+    prog.start()
     if os.environ.get("GVL_BENCH_SAME_DEVICE"):
         local = 0
+    cpu_run = engine_factory is not None and not torch.cuda.is_available()
     if world > 1:
+        prog.enter("init_process_group")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-        else:
-            torch.distributed.init_process_group(backend)
+        if not cpu_run:
+            torch.cuda.set_device(local)
+        if not torch.distributed.is_initialized():
+            if backend == "nccl":
+                torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            else:
+                torch.distributed.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
-    dev = torch.device(f"cuda:{local}")
-    torch.cuda.set_device(dev)
+    dev = torch.device("cpu") if cpu_run else torch.device(f"cuda:{local}")
+    if not cpu_run:
+        torch.cuda.set_device(dev)
+    D = Dev(dev)
 
     cps = args.clips_per_step if args.mode == "pipelined" else 1
     clip_batch = os.environ.get("GVL_BENCH_CLIP_BATCH", "1") != "0" and cps > 1
-    eng, geo = build_engine(dev, max_segs=12 * cps if clip_batch else 12, new_tokens=args.new_tokens, clips_per_step=cps,
-                            kv_pages=int(os.environ.get("GVL_BENCH_KV_PAGES", "0")))
-    st = Stepper(eng, geo, rank, world, args.new_tokens)
+    prog.enter("build_engine (weights)")
+    if engine_factory is not None:
+        eng, geo = engine_factory(dev)
+    else:
+        eng, geo = build_engine(dev, max_segs=12 * cps if clip_batch else 12, new_tokens=args.new_tokens, clips_per_step=cps,
+                                kv_pages=int(os.environ.get("GVL_BENCH_KV_PAGES", "0")))
+    hw = getattr(eng, "bench_hw", (336, 224))
+    st = Stepper(eng, geo, rank, world, args.new_tokens, pool=2 * cps, hw=hw)
 
-    def barrier():
+    def barrier(stage):
+        prog.enter(stage + ": barrier")
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        D.sync()
+
+    # ---- N > 1: diagnostics FIRST, so that a run that later hangs has already said what every rank can do ------------------------
+    per_rank, ranks_seen, gvl_gather_ok = None, None, None
+    if world > 1:
+        prog.enter("gvl_comm_init / ncclCommCount")
+        ranks_seen, gvl_gather_ok = rccl_ranks_seen(eng, rank, world, dev, backend)
+        prog.partial["n_ranks_seen_by_rccl"] = ranks_seen
+        mine = dict(st.stage_times(prog), rank=rank)
+        prog.enter("all_gather_object(per-rank stage times)")
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, mine)
+        per_rank = gathered
+        prog.partial["per_rank_stage_ms"] = per_rank
 
     S = 0
     if args.mode == "pipelined" and cps > 1:
+        prog.enter("pipe_start (first vision encode + exchange)")
         st.pipe_start_multi(cps)
         stepfn = st.pipe_step_multi
     elif args.mode == "pipelined":
+        prog.enter("pipe_start (first vision encode + exchange)")
         st.pipe_start()
         stepfn = st.pipe_step
     else:
         stepfn = st.step
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
+        prog.enter(f"warmup step {w}")
         _, S = stepfn()
-    barrier()
+    barrier("before timed region")
     t0 = time.perf_counter()
     out_timed = None
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        prog.enter(f"timed step {k} (vision + exchange + prefill + decode)")
         out_timed, S = stepfn()
-    barrier()                       # torch.cuda.synchronize(): every stream, incl. the vision encode launched by the last step
+    barrier("after timed region")   # synchronises every stream, incl. the vision encode launched by the last step
     dt = time.perf_counter() - t0
     if world > 1:
+        prog.enter("all_reduce(MAX) of the step time")
         tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     clips_per_s = world * args.steps * cps / dt
+    last_idx = st.last_idx if args.mode == "pipelined" else (st.cursor - 1)
 
     if args.plain:
         if rank == 0:
             print(json.dumps({"metric": "clips/sec (plain run for profiling)", "value": round(clips_per_s, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "mode": args.mode, "clips_in_process": (args.steps + args.warmup) * cps + (cps if args.mode == "pipelined" else 0)}), flush=True)
+        prog.finish()
         if world > 1:
             torch.distributed.destroy_process_group()
         return
+    # ---- the north-star plan: ONE clip sharded over the N ranks, LLM on rank 0 (strong scaling; N == 1: the serial single-clip latency) --
+    prog.enter("single clip, sharded over the ranks (warm)")
+    st.step_sharded()
+    barrier("sharded clip")
+    ts = time.perf_counter()
+    for k in range(2):
+        prog.enter(f"single clip, sharded over the ranks ({k})")
+        st.step_sharded()
+        barrier("sharded clip")
+    sharded_ms = 1e3 * (time.perf_counter() - ts) / 2
     # ---- untimed extras: PCIe-inclusive rate, single-clip latency, decode-only rate, per-kernel-family profile, CPU baseline -----
     # The boundary takes DEVICE pixel tensors (`value` above); here every clip's 74 MB of f32 pixels is first copied from pinned
     # host memory on the vision stream, as a caller holding CPU-preprocessed frames would (inference.py:119-120 of the reference).
     clips_per_s_h2d = None
-    if world == 1:
-        st.sp_host, st.tp_host = st.sp.cpu().pin_memory(), st.tp.cpu().pin_memory()
+    if world == 1 and D.gpu:
+        prog.enter("PCIe-inclusive passes")
+        st.sp_host, st.tp_host = st.sp_pool.cpu().pin_memory(), st.tp_pool.cpu().pin_memory()
         st.h2d = True
         _ = stepfn()
-        barrier()
+        barrier("h2d")
         th = time.perf_counter()
         for _ in range(args.steps):
             _ = stepfn()
-        barrier()
+        barrier("h2d")
         clips_per_s_h2d = args.steps * cps / (time.perf_counter() - th)
         st.h2d = False
         _ = stepfn()                      # the next vision encode in flight reads resident pixels again
-    torch.cuda.synchronize()
+        del st.sp_host, st.tp_host
+    prog.enter("serial single-clip passes")
+    D.sync()
     tl = time.perf_counter()
+    out_serial = None
     for _ in range(2):
-        out_serial, _ = st.step()
-    torch.cuda.synchronize()
+        out_serial, _ = st.step(last_idx)
+    D.sync()
     latency_ms = 1e3 * (time.perf_counter() - tl) / 2
-    same_ids = list(out_timed) == list(out_serial)       # overlapped streams must not change the generated ids (same inputs every step)
+    same_ids = list(out_timed) == list(out_serial)       # overlapped streams / ragged batches must not change a clip's ids: the last timed clip again, alone
     if not same_ids:
         print(f"bench: WARNING timed-mode ids {list(out_timed)} differ from serial ids {list(out_serial)}", file=sys.stderr)
     st.time_decode = True
     st.decode_s = 0.0
     for _ in range(2):
-        st.step()
+        st.step(0)
     decode_tok_s = 2 * (args.new_tokens - 1) / st.decode_s if st.decode_s > 0 else None
     st.time_decode = False
-    # batched decode alone (cps sequences share one weight stream per token)
+    # batched decode alone (cps sequences of different lengths share one weight stream per token)
+    prog.enter("decode-only passes")
     decode_tok_s_batched = None
+
+    def decode_only(n):
+        seqs = [st.llm(st.encode(i), i)[0] for i in range(n)]
+        D.sync()
+        tb = time.perf_counter()
+        eng.decode_greedy_batch(seqs, args.new_tokens, None)
+        r = n * (args.new_tokens - 1) / (time.perf_counter() - tb)
+        for q in seqs:
+            eng.seq_free(q)
+        return r
     if cps > 1:
-        vis = st.encode()
-        seqs = [st.llm(vis)[0] for _ in range(cps)]
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        eng.decode_greedy_batch(seqs, args.new_tokens, None)
-        decode_tok_s_batched = cps * (args.new_tokens - 1) / (time.perf_counter() - tb)
-        for q in seqs:
-            eng.seq_free(q)
+        decode_tok_s_batched = decode_only(cps)
     # the decode path at the width it is built for: 16 sequences share one weight stream per step (skinny MFMA GEMM, gvl_decode.hip)
-    decode_tok_s_16 = None
-    if os.environ.get("GVL_BENCH_DECODE16", "1") != "0":
-        vis = st.encode()
-        seqs = [st.llm(vis)[0] for _ in range(16)]
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        eng.decode_greedy_batch(seqs, args.new_tokens, None)
-        decode_tok_s_16 = 16 * (args.new_tokens - 1) / (time.perf_counter() - tb)
-        for q in seqs:
-            eng.seq_free(q)
-    eng.prof_enable(True)
-    st.step()
+    decode_tok_s_16 = decode_only(16) if os.environ.get("GVL_BENCH_DECODE16", "1") != "0" and hasattr(eng, "prof_enable") else None
+    prog.enter("profiled one-clip serial pass")
     prof = {}
-    for name, cat in (("gemm", L.PROF_GEMM), ("attention", L.PROF_ATTN), ("gemv", L.PROF_GEMV), ("decode_attention", L.PROF_DECODE_ATTN), ("other", L.PROF_OTHER)):
-        ms, n, work = eng.prof_read(cat)
-        prof[name] = {"ms": ms, "launches": n, "work": work}
-    eng.prof_enable(False)
-    g = prof["gemm"]
+    if hasattr(eng, "prof_enable"):
+        eng.prof_enable(True)
+        st.step(0)
+        for name, cat in (("gemm", L.PROF_GEMM), ("attention", L.PROF_ATTN), ("gemv", L.PROF_GEMV), ("decode_attention", L.PROF_DECODE_ATTN), ("other", L.PROF_OTHER)):
+            ms, n, work = eng.prof_read(cat)
+            prof[name] = {"ms": ms, "launches": n, "work": work}
+        eng.prof_enable(False)
+    g = prof.get("gemm", {"ms": 0.0, "launches": 0, "work": 0.0})
     gemm_tflops = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
     # HBM-side bytes per GEMM launch: NOT measured by this run -- PMC counters need their own rocprofv3 passes (MI355X_MICROARCH.md);
     # the figure is read from the committed summary of those passes over this same command and labelled as such (traffic_source)
     traffic, traffic_src = None, None
-    for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         if os.path.exists(os.path.join(ROOT, "profiles", cand)):
             traffic_src = "profiles/" + cand
             break
@@ -460,47 +677,53 @@ def main():
     roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)", "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "traffic_source": None if traffic is None else traffic_src + " (separate rocprofv3 --pmc passes of this command; not measured by this run)",
-                "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 2), "launches_per_step": g["launches"],
-                "algorithmic_tflop_per_step": round(g["work"] / 1e12, 2)}
+                "measured_on": "ONE clip, stages back to back on one stream, hipEvent pairs around every launch (NOT the 8-clip overlapped step that `ms_per_step` times)",
+                "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 2), "launches_per_clip_serial": g["launches"],
+                "algorithmic_tflop_per_clip": round(g["work"] / 1e12, 2), "gemm_ms_per_clip_serial": round(g["ms"], 3)}
     stages = {}
-    a = prof["attention"]
+    a = prof.get("attention", {"ms": 0})
     if a["ms"] > 0:
         stages["attention_tflops"] = round(a["work"] / (a["ms"] * 1e-3) / 1e12, 1)
-    v = prof["gemv"]
+    v = prof.get("gemv", {"ms": 0})
     if v["ms"] > 0:
         stages["decode_gemv_gbs"] = round(v["work"] / (v["ms"] * 1e-3) / 1e9, 1)      # work = 2*N*K flops == N*K*2 bytes of bf16 weights
         stages["decode_gemv_frac_hbm"] = round(stages["decode_gemv_gbs"] / PEAK_HBM_GBS, 4)
     for k, p in prof.items():
-        stages[k + "_ms_per_step"] = round(p["ms"], 3)
+        stages[k + "_ms_per_clip_serial"] = round(p["ms"], 3)
 
-    per_rank = None
-    if world > 1:                                       # per-rank stage times of one un-overlapped clip round: makes a scaling run diagnosable
-        mine = dict(st.stage_times(), rank=rank)
-        gathered = [None] * world
-        torch.distributed.all_gather_object(gathered, mine)
-        per_rank = gathered
     if rank == 0:
         out = {"metric": "clips/sec + grounding tokens/sec, 96-frame Phi3.5-3.8B @1/2/4/8 MI355X", "value": round(clips_per_s, 4), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights at full shape, N(0,1) pixels)",
-               "config": {"workload": "Phi-3.5-3.8B, 96 frames (12 segs x 8), 336^2 spatial + 224^2 temporal, ~100-token prompt, "
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "data": "synthetic (random-init weights at full shape; every clip of a step has its own N(0,1) pixels and its own prompt ids and length; consecutive steps use different clips)",
+               "config": {"workload": "Phi-3.5-3.8B, 96 frames (12 segs x 8), 336^2 spatial + 224^2 temporal, "
+                                      f"prompts of {PROMPT_LEN_RANGE[0]}..{PROMPT_LEN_RANGE[1]} tokens (ragged), "
                                       f"{args.new_tokens} greedy tokens, {cps} clip{'s' if cps > 1 else ''} per GPU per step" +
-                                      ((f" ({2 * cps} clips in flight per GPU: the vision encode of the next {cps} overlaps the prefill + " +
+                                      ((f" ({2 * cps} clips in flight per GPU: the vision encode of the next {cps} overlaps the ragged prefill + " +
                                         ("batched greedy decode" if cps > 1 else "decode") + f" of the current {cps}" +
                                         (f"; CLIP tower batched over the {12 * cps} key frames of a step" if clip_batch else "") + ")") if args.mode == "pipelined" else ""),
-                          "clips_per_step": cps, "ms_per_clip": round(1e3 * dt / (args.steps * cps), 2), "prefill_len": S, "visual_tokens": 12 * st.L,
+                          "clips_per_step": cps, "ms_per_clip": round(1e3 * dt / (args.steps * cps), 2), "prefill_len_max": S, "visual_tokens": 12 * st.L,
+                          "distinct_clips_resident": st.pool,
                           "parallelism": "1 GPU" if world == 1 else f"frame-batch sharded over {world} GPUs + all-gather of visual tokens, LLM replica per clip"},
                "decode_tokens_per_s": None if decode_tok_s is None else round(world * decode_tok_s, 1),
                "decode_tokens_per_s_batched": None if decode_tok_s_batched is None else round(world * decode_tok_s_batched, 1),
                "decode_tokens_per_s_16seq": None if decode_tok_s_16 is None else round(world * decode_tok_s_16, 1),
-               "clips_per_s_incl_pixel_h2d": None if clips_per_s_h2d is None else round(clips_per_s_h2d, 4), "single_clip_latency_ms": round(latency_ms, 2), "mode": args.mode, "ids_match_serial": same_ids,
+               "clips_per_s_incl_pixel_h2d": None if clips_per_s_h2d is None else round(clips_per_s_h2d, 4), "single_clip_latency_ms": round(latency_ms, 2),
+               "single_clip_latency_ms_sharded": round(sharded_ms, 2),
+               "single_clip_sharded_plan": f"one clip's 12 segments over {world} rank{'s' if world > 1 else ''}, one all-gather, prefill + decode on rank 0 (strong scaling; `value` is the weak-scaling plan)",
+               "mode": args.mode, "ids_match_serial": same_ids,
                "roofline": roofline, "stages": stages, "kv_pool": eng.kv_info()}
-        if per_rank is not None:
+        if world > 1:
             out["per_rank_stage_ms"] = per_rank
-        if world == 1 and not args.no_cpu_baseline:
+            out["n_ranks_seen_by_rccl"] = ranks_seen
+            out["gvl_allgather_matches_rank_order"] = gvl_gather_ok
+        if world == 1 and not args.no_cpu_baseline and D.gpu:
+            prog.enter("cpu_baseline (host cores)")
+            prog.limit = max(prog.limit, 1800.0) if prog.limit > 0 else 0
             eng.close()                                  # give the HBM back: the C0 weights are generated on the GPU, then copied to the host
             out["cpu_baseline"] = cpu_baseline(dev, args.new_tokens)
         print(json.dumps(out), flush=True)
+    prog.finish()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -1,0 +1,71 @@
+"""bench.py's launch / argument / exchange / reporting plumbing at world_size 2 on CPU (gloo) with a stub engine (tests/bench_stub.py):
+what the driver's N > 1 run exercises besides the kernels -- rendezvous from the environment, the rotated frame-batch plan and its ONE
+all-gather per step, ragged prompts, max-over-ranks timing, the per-rank stage table, the sharded single-clip plan, the one JSON line --
+and the watchdog that turns a dead peer into a diagnosable line instead of a silent time-out."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(world, extra_args=(), extra_env=None, timeout=300):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GVL_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2", **(extra_env or {}))
+        env.pop("GVL_BENCH_SAME_DEVICE", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_stub.py"), "--gpus", str(world), *extra_args],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill(); o, e = p.communicate()
+        outs.append((p.returncode, o, e))
+    return outs
+
+
+@pytest.mark.parametrize("world,mode_args", [(2, ()), (2, ("--clips-per-step", "1")), (1, ("--mode", "serial"))])
+def test_bench_main_end_to_end_on_cpu(world, mode_args):
+    if __import__("torch").cuda.is_available():
+        pytest.skip("plumbing test is for the GPU-less container")
+    outs = _run(world, ("--steps", "3", "--warmup", "1", "--new-tokens", "6", *mode_args))
+    for rc, o, e in outs:
+        assert rc == 0, e[-2000:]
+    lines = [l for l in outs[0][1].splitlines() if l.startswith("{")]
+    assert len(lines) == 1, outs[0][1]                          # ONE JSON line, rank 0 only
+    assert all(not l.startswith("{") for rc, o, e in outs[1:] for l in o.splitlines())
+    d = json.loads(lines[0])
+    cps = 1 if ("--mode" in mode_args or "1" in mode_args) else 8
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["unit"] == "clips/s" and d["scaling"] == "weak"
+    assert abs(d["value"] - world * 3 * cps / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-2      # whole-job clips / max-over-ranks time
+    assert d["ids_match_serial"] is True                         # the last timed clip, alone and un-batched, gives the same ids: pixels, prompt and exchange all landed
+    assert d["single_clip_latency_ms_sharded"] > 0 and d["config"]["clips_per_step"] == cps
+    if world > 1:
+        assert [p["rank"] for p in d["per_rank_stage_ms"]] == list(range(world))
+        assert all(set(p) >= {"vision_ms", "exchange_ms", "prefill_ms", "decode_ms"} for p in d["per_rank_stage_ms"])
+        assert d["n_ranks_seen_by_rccl"] is None                 # the stub has no RCCL communicator; a real engine reports ncclCommCount
+    assert "launches_per_clip_serial" in d["roofline"] and not any(k.endswith("_per_step") for k in d["stages"])
+
+
+def test_bench_watchdog_names_the_hung_stage():
+    if __import__("torch").cuda.is_available():
+        pytest.skip("plumbing test is for the GPU-less container")
+    outs = _run(2, ("--steps", "2", "--warmup", "1", "--new-tokens", "4", "--watchdog-s", "6"), {"GVL_STUB_HANG_RANK": "1", "GVL_STUB_HANG_AFTER": "3"}, timeout=120)
+    rc0, o0, e0 = outs[0]
+    assert rc0 == 3, (rc0, e0[-1500:])
+    lines = [l for l in o0.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["hang"]["rank"] == 0 and d["hang"]["seconds_in_stage"] >= 6
+    assert "step" in d["hang"]["stage"] or "barrier" in d["hang"]["stage"], d["hang"]
+    assert len(d["per_rank_stage_ms"]) == 2                      # the diagnostics gathered BEFORE the timed region survive the hang
+    assert "WATCHDOG rank 0/2 stuck in stage" in e0
+    assert outs[1][0] == 3 and "WATCHDOG rank 1/2" in outs[1][2]

@@ -31,7 +31,7 @@
 // ---- erf-GELU by table --------------------------------------------------------------------------------------------------
 // The GELU input is ALREADY rounded to bf16 (reference: nn.GELU on a bf16 tensor), so gelu(x) = x * Phi(x) needs Phi only at
 // bf16 points.  Phi(x) in f32 is tabulated for 2^-12 <= |x| <= 5.5 (1841 bf16 values per sign, 2 x 8 KiB, built on the host
-// in double precision); below 2^-12 Phi is 0.5 to 2e-4 relative, above 5.5 it is 1 (resp. < 2e-8) in f32 -- both ends clamp.
+// in double precision); below 2^-12 Phi is 0.5 to 2e-4 relative, above 5.5 it is 1 (resp. 0: the reference's f32 1 + erf is exactly 0 there) -- both ends clamp.
 // 7 full-rate VALU + one ds_read_b32 per element instead of ~16 issue slots with v_rcp + v_exp: the epilogue of
 // InternVideo2's fc1 tile drops from ~16 k to ~7 k cycles (tools/gemm_one.py, GVL_GEMM_TIMING=1).
 constexpr int GELU_LO = 0x3980, GELU_HI = 0x40B0, GELU_NE = GELU_HI - GELU_LO + 1;
@@ -691,6 +691,9 @@ static const float* gelu_table_device() {
         float x; memcpy(&x, &bits, 4);
         h[sgn * (GELU_NEG_OFF / 4) + k] = (float)(0.5 * std::erfc(-(double)x * 0.70710678118654752440));
       }
+    // every x <= -5.5 clamps onto the last negative entry: Phi = 0 there, as in the reference's fp32 arithmetic (1 + erf(x / sqrt 2) is exactly 0
+    // below x ~ -5.4) -- with Phi(-5.5) = 1.9e-8 instead the product x * Phi would GROW with |x| for huge negative inputs
+    h[GELU_NEG_OFF / 4 + GELU_NE - 1] = 0.f;
     float* dptr = nullptr;
     if (hipMalloc((void**)&dptr, GELU_TAB_BYTES) != hipSuccess) return nullptr;
     if (hipMemcpy(dptr, h.data(), GELU_TAB_BYTES, hipMemcpyHostToDevice) != hipSuccess) return nullptr;

@@ -47,3 +47,31 @@ def check_bf16_class(got, ref32, ref_emu, floor, what=""):
     e_emu = rel_err(ref_emu, ref32)
     tol = max(floor, 2.5 * e_emu)
     return check(got, ref32, tol, what + f" [bf16-emulation itself is {e_emu:.2e} from fp32]")
+
+
+BF16_CLASS_CAP = 1.25   # err(HIP, fp32) <= max(floor, CAP x err(reference evaluated in bf16, fp32)); round 2 allowed 1.5, the largest ratio observed is 1.23
+
+
+def noise_class(got, ref32, ref_bf16, what, floor=1e-2, cap=BF16_CLASS_CAP, rms_cap=1.15):
+    """Is the HIP result in the same noise class as the REFERENCE's own modules evaluated in bf16 (stored in the golden next to their fp32
+    evaluation)?  `got` / `ref32` / `ref_bf16`: same-shape arrays (rows x logits, or a strided feature map).  Prints and asserts
+      * max-abs error of HIP vs fp32, of reference-bf16 vs fp32, their ratio (<= cap, or HIP below the floor),
+      * the same with RMS errors (a far less noisy statistic than the max over ~10^4 logits; <= rms_cap),
+      * HIP vs reference-bf16 directly: two bf16 evaluations with independent rounding differ by ~sqrt(2) x their distance from fp32 (<= 1.6 x).
+    Everything in units of max|ref32|.  Returns (err_hip, err_ref_bf16)."""
+    g = torch.as_tensor(np.asarray(got.detach().float().cpu() if isinstance(got, torch.Tensor) else got)).double()
+    r = torch.as_tensor(np.asarray(ref32)).double()
+    b = torch.as_tensor(np.asarray(ref_bf16)).double()
+    assert g.shape == r.shape == b.shape, (g.shape, r.shape, b.shape)
+    assert torch.isfinite(g).all(), "non-finite values in HIP output"
+    scale = float(r.abs().max()) + 1e-30
+    e_h, e_b = float((g - r).abs().max()) / scale, float((b - r).abs().max()) / scale
+    rms = lambda t: float(t.pow(2).mean().sqrt()) / scale
+    r_h, r_b, r_hb = rms(g - r), rms(b - r), rms(g - b)
+    d_hb = float((g - b).abs().max()) / scale
+    print(f"[parity] {what}: HIP vs fp32 max {e_h:.3e} rms {r_h:.3e} | reference-bf16 vs fp32 max {e_b:.3e} rms {r_b:.3e} | ratio max {e_h / e_b:.2f} rms {r_h / r_b:.2f} "
+          f"| HIP vs reference-bf16 max {d_hb:.3e} rms {r_hb:.3e} (= {r_hb / r_b:.2f} x rms of reference-bf16 vs fp32)")
+    assert e_h <= max(floor, cap * e_b), f"{what}: HIP {e_h:.3e} > max({floor:.0e}, {cap} x {e_b:.3e})"
+    assert r_h <= rms_cap * r_b or e_h <= floor, f"{what}: rms error of HIP {r_h:.3e} > {rms_cap} x {r_b:.3e} of the reference's own bf16 evaluation"
+    assert r_hb <= 1.6 * max(r_b, r_h), f"{what}: HIP and the reference's bf16 evaluation are further apart ({r_hb:.3e}) than two bf16 evaluations should be"
+    return e_h, e_b

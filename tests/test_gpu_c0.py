@@ -5,7 +5,9 @@ streams regenerated ON THE GPU (bit-identical to what the reference consumed on 
 
 Tolerances (of the output scale; north_star: bf16 logits within 1e-2 rel).  The golden also stores the reference's own modules
 evaluated in bf16 on the CPU (`*_bf16ref`): how far a bf16 evaluation of the REFERENCE is from its fp32 evaluation at this depth.
-The HIP path must be within max(floor, 1.5 x that).  Observed numbers are printed and recorded in DESIGN.md §4."""
+The HIP path must be within max(floor, 1.25 x that) on the max-abs error (round 2: 1.5 x; the largest ratio observed is 1.23) AND
+within 1.15 x on the RMS error, and is also compared with the bf16 evaluation directly (gpu_util.noise_class).  Observed numbers are
+printed; profiles/r03_parity_observed.txt keeps them."""
 import numpy as np
 import pytest
 import torch
@@ -13,7 +15,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from conftest import load_golden  # noqa: E402
-from gpu_util import DEV, bf, check, rel_err  # noqa: E402
+from gpu_util import DEV, BF16_CLASS_CAP, bf, check, noise_class, rel_err  # noqa: E402
 from grounded_video_llm_amd import engine as E, synth, weights as Wt  # noqa: E402
 
 
@@ -59,10 +61,7 @@ def test_c0_internvideo2_39_blocks(c0):
     eng, geo, meta, g, sp, tseg = c0
     st = meta["stride"]["iv2"]
     got = eng.iv2_encode(tseg)
-    ref_bf = rel_err(torch.as_tensor(g["iv2_out_bf16ref"]), g["iv2_out"])
-    print(f"[parity] the reference's own bf16 InternVideo2 is {ref_bf:.3e} from its fp32 evaluation")
-    e = check(got[:, ::st[0], ::st[1]], g["iv2_out"], max(1e-2, 1.5 * ref_bf), "C0 InternVideo2-1B, 39 blocks, S=2049, vs reference (fp32)")
-    assert e <= max(1e-2, 1.5 * ref_bf)
+    noise_class(got[:, ::st[0], ::st[1]], g["iv2_out"], g["iv2_out_bf16ref"], "C0 InternVideo2-1B, 39 blocks, S=2049")
 
 
 def test_c0_encode_images_splice_prefill_greedy(c0):
@@ -79,7 +78,7 @@ def test_c0_encode_images_splice_prefill_greedy(c0):
     # ---- prefill: last-row logits of the 32-layer Phi-3.5 on the HIP path's OWN visual prefix (end to end)
     scale = float(np.abs(g["logits_steps"]).max())
     ref_bf = float(np.abs(g["logits_steps_bf16ref"] - g["logits_steps"]).max()) / scale
-    tol = max(1e-2, 1.5 * ref_bf)
+    tol = max(1e-2, BF16_CLASS_CAP * ref_bf)
     print(f"[parity] the reference's own bf16 Phi-3.5 (32 L) is {ref_bf:.3e} from its fp32 logits (scale {scale:.3f}); tolerance {tol:.2e}")
     seq = eng.seq_alloc(S + 32)
     lg = eng.prefill(seq, emb, want_logits=True).clone()
@@ -90,12 +89,15 @@ def test_c0_encode_images_splice_prefill_greedy(c0):
     gold_ids = meta["greedy_ids"]
     ls = meta["stride"]["logits"]
     errs = [e0]
+    rows_c0 = [lg]
     for step in range(1, meta["new_tokens"]):
         ld = eng.decode_step_logits(seq, gold_ids[step - 1])
+        rows_c0.append(ld.clone())
         errs.append(float((ld[::ls].cpu().double() - torch.as_tensor(g["logits_steps"][step]).double()).abs().max()) / scale)
     eng.seq_free(seq)
     print("[parity] C0 teacher-forced decode logits per step (of the logit scale):", " ".join(f"{e:.2e}" for e in errs))
     assert max(errs) <= tol
+    noise_class(torch.stack([r[::ls].cpu() for r in rows_c0]), g["logits_steps"], g["logits_steps_bf16ref"], "C0 Phi-3.5 32 L logits, prefill row + 11 teacher-forced decode rows")
     # ---- free-running greedy: same ids as the reference wherever its top-1 margin exceeds the logit tolerance
     got_ids = eng.generate_ids(emb, meta["new_tokens"], None)
     margins = np.asarray(g["top1"]) - np.asarray(g["top2"])
@@ -128,7 +130,7 @@ def test_c1_headline_config_96_frames_vs_reference_golden(c0):
     assert emb.shape[0] == S == 3519
     scale = float(np.abs(g["logits_rows"]).max())
     ref_bf = float(np.abs(g["logits_rows_bf16ref"] - g["logits_rows"]).max()) / scale
-    tol = max(1e-2, 1.5 * ref_bf)
+    tol = max(1e-2, BF16_CLASS_CAP * ref_bf)
     ls = st["logits"]
     seq = eng.seq_alloc(S + 32)
     rows = [eng.prefill(seq, emb, want_logits=True).clone()]
@@ -139,6 +141,7 @@ def test_c1_headline_config_96_frames_vs_reference_golden(c0):
     print(f"[parity] C1 Phi-3.5 32 L, S={S}: the reference's own bf16 evaluation is {ref_bf:.3e} from its fp32 logits (scale {scale:.3f}); bound {tol:.2e}")
     print("[parity] C1 logits, prefill row + 11 teacher-forced decode rows (of the logit scale):", " ".join(f"{e:.2e}" for e in errs))
     assert max(errs) <= tol
+    noise_class(torch.stack([r[::ls].cpu() for r in rows]), g["logits_rows"], g["logits_rows_bf16ref"], f"C1 Phi-3.5 32 L logits, S={S}, prefill row + 11 decode rows")
     margins = np.asarray(g["top1"]) - np.asarray(g["top2"])
     for i, r in enumerate(rows):
         if margins[i] > 2 * tol * scale:

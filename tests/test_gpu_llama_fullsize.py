@@ -120,11 +120,11 @@ def test_c4_llama3_8b_256_frames_long_context(llama):
 
 def _full_depth_vs_reference_golden(llama, name):
     """HIP path: segment encode (in chunks of the per-call workspace) -> splice -> prefill (row S-1) -> teacher-forced decode steps
-    through the paged KV cache; every `row_step`-th row against the golden.  Bound: max(1e-2, 1.5 x the error of the reference's own
-    bf16 evaluation stored in the golden)."""
+    through the paged KV cache; every `row_step`-th row against the golden.  Bound: max(1e-2, 1.25 x the error of the reference's own
+    bf16 evaluation stored in the golden) on the max-abs error, 1.15 x on the RMS error (gpu_util.noise_class)."""
     import numpy as np
     from conftest import load_golden
-    from gpu_util import check
+    from gpu_util import BF16_CLASS_CAP, check, noise_class
     eng, geo = llama
     meta, g = load_golden(name)
     sd, st = meta["seeds"], meta["stride"]
@@ -141,7 +141,7 @@ def _full_depth_vs_reference_golden(llama, name):
     assert emb.shape[0] == S
     scale = float(np.abs(g["logits_rows"]).max())
     ref_bf = float(np.abs(g["logits_rows_bf16ref"] - g["logits_rows"]).max()) / scale
-    tol = max(1e-2, 1.5 * ref_bf)
+    tol = max(1e-2, BF16_CLASS_CAP * ref_bf)
     ls = st["logits"]
     seq = eng.seq_alloc(S + len(meta["forced"]) + 8)
     rows = [eng.prefill(seq, emb, want_logits=True).clone()]
@@ -155,6 +155,7 @@ def _full_depth_vs_reference_golden(llama, name):
     print(f"[parity] {name} Llama-3-8B 32 L, S={S}: the reference's own bf16 evaluation is {ref_bf:.3e} from its fp32 logits (scale {scale:.3f}); bound {tol:.2e}")
     print(f"[parity] {name} logits, prefill row + teacher-forced decode rows (every {step}; of the logit scale):", " ".join(f"{e:.2e}" for e in errs))
     assert max(errs) <= tol
+    noise_class(torch.stack([r[::ls].cpu() for r in rows]), g["logits_rows"], g["logits_rows_bf16ref"], f"{name} Llama-3-8B 32 L logits, S={S}, {len(rows)} rows")
     margins = np.asarray(g["top1"]) - np.asarray(g["top2"])
     for i, r in enumerate(rows):
         if margins[i] > 2 * tol * scale:

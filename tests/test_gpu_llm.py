@@ -376,6 +376,10 @@ def test_llama3_8b_full_width_layer_prefill_and_decode():
     eng.seq_free(seq)
     check(ld, gold[63], tol, "llama-3-8B full-width layer, paged-KV decode step (row 63) vs reference (fp32)")
     check(ld, l64, 1e-2, "llama-3-8B full-width layer, decode step vs the prefill path on the same row")
+    # the same three rows as ONE sample against the reference's own bf16 evaluation (max over 64 logits of one row is a very noisy statistic)
+    from gpu_util import noise_class
+    noise_class(torch.stack([l63.cpu(), l64.cpu(), ld.cpu()]), np.stack([gold[62], gold[63], gold[63]]), np.stack([gold_bf[62], gold_bf[63], gold_bf[63]]),
+                "llama-3-8B full-width layer, rows 62 / 63 (prefill) / 63 (decode)", cap=1.5, rms_cap=1.25)
     eng.close()
 
 

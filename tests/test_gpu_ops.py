@@ -319,3 +319,38 @@ def test_sampler_distribution(eng):
     assert N == 8000 and cnt[~keep].sum() == 0
     sigma = np.sqrt(p * (1 - p) / N)
     assert np.all(np.abs(cnt / N - p) <= 4.5 * sigma + 1e-9), (cnt / N, p)
+
+
+@pytest.mark.parametrize("cfg", [0, 21])
+def test_gelu_epilogue_is_correctly_rounded_on_every_bf16_input(eng, cfg):
+    """The erf-GELU epilogue looks Phi(x) up in a table indexed by the bf16 bit pattern of its (already bf16) input.  Ablation of the
+    round-2 suspicion that the table costs accuracy: ALL normal bf16 values (and zero) go through the fused epilogue of both GEMM kernels
+    (A carries x in column 0, W row n = e_0, so the accumulator IS x) and must equal the erf GELU of the bf16 value (what nn.GELU
+    computes in the reference, internvideo2.py:631-634) evaluated in DOUBLE precision and rounded to bf16 -- on all but a handful of inputs
+    that sit within 1e-7 of a rounding boundary (one ulp there)."""
+    bits = torch.arange(65536, dtype=torch.int32)
+    x = bits.to(torch.int16).view(bf)                                  # every bf16 bit pattern
+    # all normal bf16 values up to 2^60 and zero: the MFMA pipe flushes subnormal inputs, and torch's own vectorised erf overflows (gelu = inf)
+    # beyond |x| ~ 1e19, where the kernel returns x resp. -0
+    xf = x.float()
+    finite = torch.isfinite(xf) & (((xf.abs() >= 2.0 ** -125) & (xf.abs() <= 2.0 ** 60)) | (xf == 0))
+    K, N = 1024, 256                                                    # cfg 0 -> the persistent 256x256 kernel (LDS-resident table), 21 -> 128x128 (global table)
+    A = torch.zeros((65536, K), dtype=bf)
+    A[:, 0] = torch.where(finite, x, torch.zeros_like(x))
+    W = torch.zeros((N, K), dtype=bf); W[:, 0] = 1.0
+    got = eng.op_gemm(A.to(DEV), W.to(DEV), act=L.ACT_GELU, tile_cfg=cfg).cpu()
+    # reference in float64 (torch's vectorised CPU gelu is itself only ~1e-3 accurate in the negative tail on some hosts): x * Phi(x) with
+    # Phi = erfc(-x / sqrt 2) / 2, rounded to bf16.  The kernel multiplies the bf16 x by an f32 table entry of Phi (6e-8 relative), so it can
+    # differ from the correctly rounded value only where x * Phi sits within ~1e-7 of a bf16 rounding boundary: a handful of inputs, by one ulp.
+    xd = A[:, 0].double()
+    want = (xd * 0.5 * torch.special.erfc(-xd * 2.0 ** -0.5)).float().to(bf)
+    # value comparison (-0.0 == +0.0); below x ~ -5.4 the reference's own fp32 arithmetic returns 0 or one quantum of (1 + erf) ~ 6e-8 x |x| / 2: anything
+    # within 2^-21 of the true (tiny) value counts as equal there
+    diff = (got.float() != want.float()[:, None]) & finite[:, None] & ((got.float() - want.float()[:, None]).abs() > 2.0 ** -21)
+    rows = diff.any(dim=1)
+    assert (diff == diff[:, :1]).all(), "columns of one row disagree"
+    n_bad = int(rows.sum())
+    ulp = (got[rows, 0].view(torch.int16).int() - want[rows].view(torch.int16).int()).abs()
+    print(f"[parity] erf-GELU epilogue cfg {cfg}: {n_bad} of {int(finite.sum())} bf16 inputs differ from the correctly rounded double-precision value" +
+          (f" (by at most {int(ulp.max())} bf16 ulp: x = {A[rows, 0].float().tolist()[:8]})" if n_bad else ""))
+    assert n_bad <= 8 and (n_bad == 0 or int(ulp.max()) <= 1), f"cfg {cfg}: {n_bad} inputs differ, max {int(ulp.max()) if n_bad else 0} ulp"

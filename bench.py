@@ -244,7 +244,12 @@ class Stepper:
             self.sp_pool[lo:hi].copy_(self.sp_host[lo:hi], non_blocking=True)
             self.tp_pool[lo:hi].copy_(self.tp_host[lo:hi], non_blocking=True)
         cf = self.eng.clip_encode(self.sp_pool[lo:hi])
-        return self._exchange_multi([self.eng.build_visual(cf[c * 12:(c + 1) * 12], self.eng.iv2_encode(self.px(i)[1])) for c, i in enumerate(idx)])
+        # InternVideo2 over `iv2_batch` clips per call (default: the whole step -- M = 197 k rows: the GEMM rounds fill better, -3.9 % tower time
+        # against one call per clip, tools/iv2_batch_lab.py; the towers are bit-exactly batch-invariant, and ids_match_serial re-checks it)
+        nb = max(1, min(self.iv2_batch, len(idx)))
+        vf = torch.cat([self.eng.iv2_encode(self.tp_pool[(idx[c]) * 12:(idx[min(c + nb, len(idx)) - 1] + 1) * 12]) for c in range(0, len(idx), nb)], 0) if nb > 1 else None
+        return self._exchange_multi([self.eng.build_visual(cf[c * 12:(c + 1) * 12], vf[c * 12:(c + 1) * 12] if vf is not None else self.eng.iv2_encode(self.px(i)[1]))
+                                     for c, i in enumerate(idx)])
 
     def stage_times(self, prog=None):
         """One clip round on this rank, stages back to back with events between them (diagnosis of the N > 1 runs):
@@ -292,6 +297,17 @@ class Stepper:
         vis = self.encode(i)
         seq, S = self.llm(vis, i)
         return self.decode(seq), S
+
+    def step_multi_serial(self, idx):
+        """The launches of ONE timed step (CLIP over the step's key frames, InternVideo2 + projectors per clip, one ragged prefill, one
+        batched decode of the clips `idx`) back to back on the CURRENT stream: what the profiled pass brackets with events."""
+        embs = [self.eng.splice(self.prompts[i % self.pool], vis) for vis, i in zip(self.encode_multi(idx), idx)]
+        seqs = [self.eng.seq_alloc(e.shape[0] + self.new_tokens) for e in embs]
+        self.eng.prefill_batch(seqs, embs)
+        outs = self.eng.decode_greedy_batch(seqs, self.new_tokens, None)
+        for seq in seqs:
+            self.eng.seq_free(seq)
+        return outs
 
     def step_sharded(self, i=0):
         """The north-star plan for ONE clip on N ranks: every rank encodes its contiguous share of the clip's 12 segments (the same clip
@@ -390,6 +406,7 @@ class Stepper:
 
     time_decode = False
     clip_batch = False
+    iv2_batch = int(os.environ.get("GVL_BENCH_IV2_BATCH", "0")) or 64      # clips per InternVideo2 call (capped by the clips of a step)
     last_idx = 0
     batch_prefill = os.environ.get("GVL_BENCH_BATCH_PREFILL", "1") != "0"
     overlap = os.environ.get("GVL_BENCH_OVERLAP", "full")
@@ -489,8 +506,10 @@ def main(argv=None, engine_factory=None):
     ap.add_argument("--plain", action="store_true", help="timed region only (warmup + steps clips in the process): the target of the rocprofv3 passes")
     ap.add_argument("--clips-per-step", type=int, default=int(os.environ.get("GVL_BENCH_CPS", "8")),
                     help="pipelined mode: clips per GPU per step; their prefill is one ragged pass and their greedy decode is batched (one weight stream per token for all of them)")
-    ap.add_argument("--mode", choices=["pipelined", "serial"], default="pipelined",
-                    help="pipelined: 2 x cps clips in flight per GPU (vision of the next clips overlaps prefill + decode of the current ones); serial: one clip at a time")
+    ap.add_argument("--mode", choices=["pipelined", "serial", "serial_step"], default="pipelined",
+                    help="pipelined: 2 x cps clips in flight per GPU (vision of the next clips overlaps prefill + decode of the current ones); serial: one clip at a "
+                         "time; serial_step: the launches of a pipelined step (cps clips, batched CLIP / InternVideo2 / prefill / decode) back to back on ONE stream -- "
+                         "the rocprofv3 target whose per-kernel times `roofline` must agree with")
     ap.add_argument("--watchdog-s", type=float, default=float(os.environ.get("GVL_BENCH_WATCHDOG_S", "900")),
                     help="seconds one stage may last before the run is declared hung (0 = off)")
     args = ap.parse_args(argv)
@@ -520,7 +539,7 @@ def main(argv=None, engine_factory=None):
         torch.cuda.set_device(dev)
     D = Dev(dev)
 
-    cps = args.clips_per_step if args.mode == "pipelined" else 1
+    cps = args.clips_per_step if args.mode in ("pipelined", "serial_step") else 1
     clip_batch = os.environ.get("GVL_BENCH_CLIP_BATCH", "1") != "0" and cps > 1
     prog.enter("build_engine (weights)")
     if engine_factory is not None:
@@ -540,9 +559,6 @@ def main(argv=None, engine_factory=None):
     # ---- N > 1: diagnostics FIRST, so that a run that later hangs has already said what every rank can do ------------------------
     per_rank, ranks_seen, gvl_gather_ok = None, None, None
     if world > 1:
-        prog.enter("gvl_comm_init / ncclCommCount")
-        ranks_seen, gvl_gather_ok = rccl_ranks_seen(eng, rank, world, dev, backend)
-        prog.partial["n_ranks_seen_by_rccl"] = ranks_seen
         mine = dict(st.stage_times(prog), rank=rank)
         prog.enter("all_gather_object(per-rank stage times)")
         gathered = [None] * world
@@ -559,6 +575,14 @@ def main(argv=None, engine_factory=None):
         prog.enter("pipe_start (first vision encode + exchange)")
         st.pipe_start()
         stepfn = st.pipe_step
+    elif args.mode == "serial_step":
+        st.cps, st.clip_batch = cps, clip_batch
+
+        def stepfn():
+            idx = st.window(cps)
+            outs = st.step_multi_serial(idx)
+            st.last_idx = idx[-1]
+            return outs[-1], 0
     else:
         stepfn = st.step
     for w in range(args.warmup):
@@ -578,12 +602,15 @@ def main(argv=None, engine_factory=None):
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     clips_per_s = world * args.steps * cps / dt
-    last_idx = st.last_idx if args.mode == "pipelined" else (st.cursor - 1)
+    # from here on a hang (watchdog) or a failure of an EXTRA still reports the measured headline value
+    prog.partial.update(value=round(clips_per_s, 4), ms_per_step=round(1e3 * dt / args.steps, 2), scaling="weak", dtype="bf16", vs_baseline=None,
+                        note="the run stopped after the timed region: extras missing")
+    last_idx = st.last_idx if args.mode in ("pipelined", "serial_step") else (st.cursor - 1)
 
     if args.plain:
         if rank == 0:
             print(json.dumps({"metric": "clips/sec (plain run for profiling)", "value": round(clips_per_s, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
-                              "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "mode": args.mode, "clips_in_process": (args.steps + args.warmup) * cps + (cps if args.mode == "pipelined" else 0)}), flush=True)
+                              "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "mode": args.mode, "clips_per_step": cps, "clips_in_process": (args.steps + args.warmup) * cps + (cps if args.mode == "pipelined" else 0)}), flush=True)
         prog.finish()
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -598,6 +625,14 @@ def main(argv=None, engine_factory=None):
         st.step_sharded()
         barrier("sharded clip")
     sharded_ms = 1e3 * (time.perf_counter() - ts) / 2
+    prog.partial["single_clip_latency_ms_sharded"] = round(sharded_ms, 2)
+    if world > 1:                                        # libgvl's own communicator over all ranks: how many ranks RCCL itself reports, and its all-gather
+        prog.enter("gvl_comm_init / ncclCommCount / gvl_allgather_visual")
+        try:
+            ranks_seen, gvl_gather_ok = rccl_ranks_seen(eng, rank, world, dev, backend)
+        except Exception as e:                           # a diagnostic must not cost the measurement
+            print(f"bench: rank {rank}: libgvl communicator check failed: {e}", file=sys.stderr, flush=True)
+        prog.partial["n_ranks_seen_by_rccl"] = ranks_seen
     # ---- untimed extras: PCIe-inclusive rate, single-clip latency, decode-only rate, per-kernel-family profile, CPU baseline -----
     # The boundary takes DEVICE pixel tensors (`value` above); here every clip's 74 MB of f32 pixels is first copied from pinned
     # host memory on the vision stream, as a caller holding CPU-preprocessed frames would (inference.py:119-120 of the reference).
@@ -650,17 +685,38 @@ def main(argv=None, engine_factory=None):
         decode_tok_s_batched = decode_only(cps)
     # the decode path at the width it is built for: 16 sequences share one weight stream per step (skinny MFMA GEMM, gvl_decode.hip)
     decode_tok_s_16 = decode_only(16) if os.environ.get("GVL_BENCH_DECODE16", "1") != "0" and hasattr(eng, "prof_enable") else None
-    prog.enter("profiled one-clip serial pass")
-    prof = {}
+    # ---- per-kernel-family profile (hipEvent pairs around every launch, on the launch stream): (1) the launches of ONE TIMED STEP -- cps clips:
+    # CLIP batched over the step's key frames, ONE ragged prefill, ONE batched decode -- back to back on one stream (what `roofline` reports: the
+    # dominant kernel family as the timed region runs it), (2) one clip alone (rounds 1-2 reported this; kept as `roofline_one_clip_serial`)
+    prog.enter("profiled passes")
+    prof, prof1 = {}, {}
+    fams = (("gemm", L.PROF_GEMM), ("attention", L.PROF_ATTN), ("gemv", L.PROF_GEMV), ("decode_attention", L.PROF_DECODE_ATTN), ("other", L.PROF_OTHER))
+    n_prof = 1
     if hasattr(eng, "prof_enable"):
-        eng.prof_enable(True)
-        st.step(0)
-        for name, cat in (("gemm", L.PROF_GEMM), ("attention", L.PROF_ATTN), ("gemv", L.PROF_GEMV), ("decode_attention", L.PROF_DECODE_ATTN), ("other", L.PROF_OTHER)):
+        if args.mode in ("pipelined", "serial_step") and cps > 1:
+            idx = list(range(cps))
+            st.step_multi_serial(idx)                         # warm (workspace, allocator)
+            D.sync()
+            eng.prof_enable(True)
+            st.step_multi_serial(idx)
+            n_prof = cps
+        else:
+            eng.prof_enable(True)
+            st.step(0)
+        for name, cat in fams:
             ms, n, work = eng.prof_read(cat)
             prof[name] = {"ms": ms, "launches": n, "work": work}
         eng.prof_enable(False)
+        eng.prof_enable(True)
+        st.step(0)
+        for name, cat in fams:
+            ms, n, work = eng.prof_read(cat)
+            prof1[name] = {"ms": ms, "launches": n, "work": work}
+        eng.prof_enable(False)
     g = prof.get("gemm", {"ms": 0.0, "launches": 0, "work": 0.0})
+    g1 = prof1.get("gemm", {"ms": 0.0, "launches": 0, "work": 0.0})
     gemm_tflops = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+    gemm1_tflops = g1["work"] / (g1["ms"] * 1e-3) / 1e12 if g1["ms"] > 0 else 0.0
     # HBM-side bytes per GEMM launch: NOT measured by this run -- PMC counters need their own rocprofv3 passes (MI355X_MICROARCH.md);
     # the figure is read from the committed summary of those passes over this same command and labelled as such (traffic_source)
     traffic, traffic_src = None, None
@@ -671,15 +727,21 @@ def main(argv=None, engine_factory=None):
     try:
         with open(os.path.join(ROOT, traffic_src)) as fpm:
             pm = json.load(fpm)
-            traffic = int(pm["families"]["gemm"]["total_traffic_bytes"] / (pm["clips_in_trace"] * max(1, g["launches"])))   # per LOGICAL GEMM launch
+            # per LOGICAL GEMM launch of the traced mode: serial_step traces hold the step's batched launches, older ones one clip at a time
+            per_clip = g["launches"] / n_prof if "serial_step" in pm.get("source", "") else g1["launches"]
+            traffic = int(pm["families"]["gemm"]["total_traffic_bytes"] / max(1.0, pm["clips_in_trace"] * per_clip))
     except Exception:
         pass
     roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)", "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_source": None if traffic is None else traffic_src + " (separate rocprofv3 --pmc passes of this command; not measured by this run)",
-                "measured_on": "ONE clip, stages back to back on one stream, hipEvent pairs around every launch (NOT the 8-clip overlapped step that `ms_per_step` times)",
-                "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 2), "launches_per_clip_serial": g["launches"],
-                "algorithmic_tflop_per_clip": round(g["work"] / 1e12, 2), "gemm_ms_per_clip_serial": round(g["ms"], 3)}
+                "traffic_source": None if traffic is None else traffic_src + " (separate rocprofv3 --pmc passes of the serial bench; not measured by this run)",
+                "measured_on": (f"the launches of ONE timed step ({n_prof} clips: CLIP batched over {12 * n_prof} key frames, one ragged prefill, one batched decode) "
+                                "back to back on one stream, hipEvent pairs around every launch" if n_prof > 1 else
+                                "ONE clip, stages back to back on one stream, hipEvent pairs around every launch"),
+                "clips_in_profiled_pass": n_prof, "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 2), "launches_in_profiled_pass": g["launches"],
+                "algorithmic_tflop_per_clip": round(g["work"] / 1e12 / n_prof, 2), "gemm_ms_per_clip": round(g["ms"] / n_prof, 3),
+                "one_clip_serial": {"achieved": round(gemm1_tflops, 1), "frac": round(gemm1_tflops / PEAK_BF16_TFLOPS, 4), "launches_per_clip_serial": g1["launches"],
+                                    "gemm_ms_per_clip_serial": round(g1["ms"], 3), "note": "one clip alone: CLIP on 12 frames and a 3.5 k-row prefill leave the 256 CUs under-filled (rounds 1-2 reported this figure)"}}
     stages = {}
     a = prof.get("attention", {"ms": 0})
     if a["ms"] > 0:
@@ -689,7 +751,9 @@ def main(argv=None, engine_factory=None):
         stages["decode_gemv_gbs"] = round(v["work"] / (v["ms"] * 1e-3) / 1e9, 1)      # work = 2*N*K flops == N*K*2 bytes of bf16 weights
         stages["decode_gemv_frac_hbm"] = round(stages["decode_gemv_gbs"] / PEAK_HBM_GBS, 4)
     for k, p in prof.items():
-        stages[k + "_ms_per_clip_serial"] = round(p["ms"], 3)
+        stages[k + "_ms_per_clip"] = round(p["ms"] / n_prof, 3)          # the timed step's launches, per clip
+    for k, p in prof1.items():
+        stages[k + "_ms_per_clip_serial"] = round(p["ms"], 3)           # one clip alone
 
     if rank == 0:
         out = {"metric": "clips/sec + grounding tokens/sec, 96-frame Phi3.5-3.8B @1/2/4/8 MI355X", "value": round(clips_per_s, 4), "unit": "clips/s",

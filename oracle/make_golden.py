@@ -570,6 +570,17 @@ def g_c4(ns):
     return _g_llama_e2e(ns, "c4", 32, 63, 4)
 
 
+def _feats_cache_name(tag, n_segs, weight_seeds, sp, tp):
+    """/tmp cache of an encode_images result, keyed by everything that determines it: tag, segment count, the weight seeds, a digest of the
+    pixel streams and of the generator's own source (synth.py) -- VERDICT r2: a cache from an earlier weight stream must never be reused."""
+    import hashlib
+    h = hashlib.sha1()
+    h.update(repr((tag, n_segs, tuple(weight_seeds))).encode())
+    h.update(sp.flatten()[::9973].numpy().tobytes()); h.update(tp.flatten()[::99991].numpy().tobytes())
+    h.update(open(synth.__file__, "rb").read())
+    return f"/tmp/gvl_{tag}_feats_{h.hexdigest()[:16]}.pt"
+
+
 def _g_llama_e2e(ns, tag, n_segs, n_forced, row_step):
     """BASELINE configs[3] at REAL size, end to end through the reference's own modules on CPU in fp32: LLaVA-Next-Llama3-8B base,
     96 frames / 12 segments -> CLIP 24 L x 12 key frames, InternVideo2 40 blocks x 12 segments (S = 2049), 3x3 pooling + projectors +
@@ -608,8 +619,9 @@ def _g_llama_e2e(ns, tag, n_segs, n_forced, row_step):
     sp = synth.exact_tensor(tag + ".sp", (1, n_segs, 3, 336, 336))
     tp = synth.exact_tensor(tag + ".tp", (1, 8 * n_segs, 3, 224, 224))
     t0 = time.time()
-    if os.path.exists(f"/tmp/{tag}_feats.pt"):
-        feats = torch.load(f"/tmp/{tag}_feats.pt")
+    feats_cache = _feats_cache_name(tag, n_segs, ("c3.clip", "c3.iv2", "c3.proj"), sp, tp)
+    if os.path.exists(feats_cache):
+        feats = torch.load(feats_cache)
     else:
         feats = sk.encode_images({"spatial_pixel_values": sp, "temporal_pixel_values": tp})
     t_enc = time.time() - t0
@@ -626,8 +638,8 @@ def _g_llama_e2e(ns, tag, n_segs, n_forced, row_step):
     cfg.attention_dropout = 0.0
     cfg.mlp_bias = False
     cfg._attn_implementation = "eager"
-    feats_cache = f"/tmp/{tag}_feats.pt"                     # (the 32-segment vision pass takes 20 minutes on 8 cores)
-    torch.save(feats, feats_cache)
+    torch.save(feats, feats_cache)                           # (the 32-segment vision pass takes 20 minutes on 8 cores; the name carries a hash of
+                                                             #  the weight seeds, the geometry and the pixel streams: a stale cache is never reused)
     specs = synth.llm_weight_specs("llama", 4096, 14336, 32, 32, 8, 128558, True)
     ids = c3_ids()
     forced = c3_forced_tokens(n_forced)
@@ -768,9 +780,85 @@ def g_c1(ns):
          feats=feats[:, ::7, ::12], logits_rows=lg[:, ::4], logits_rows_bf16ref=lb[:, ::4], top1=t2.values[:, 0], top2=t2.values[:, 1])
 
 
+def g_free(ns, tag):
+    """Free-running greedy ids for the full-size configs beyond C0: the reference's own encode_images + prepare_multimodal_inputs
+    (as in g_c1 / g_c3) give the fp32 prefix; the continuation is the ORACLE's KV-cached greedy (oracle/gvl_oracle.py, pinned at this depth against
+    the reference's O(n^2) greedy by tests/test_oracle_c0_slow.py) -- twelve 5-minute reference forwards replaced by one prefix pass + 9 cached
+    steps.  Fixture: tests/golden/<tag>_free.json = prompt ids, 10 greedy ids, the top-1 / top-2 margin of every step and the logit scale."""
+    import copy
+    import json
+    import time
+    import gvl_oracle as O
+    L = ns.llava
+    n_free = 10
+
+    class Skel(L.LLAVA_NEXT_VIDEO):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+
+        def get_input_embeddings(self):
+            return self.embed
+
+    phi = tag == "c1"
+    hid = 3072 if phi else 4096
+    wseed = "c0" if phi else "c3"
+    sk = Skel()
+    sk.llm, sk.dtype = ("phi3.5" if phi else "llama3"), torch.float32
+    c = copy.deepcopy(L.CLIP_VIT_LARGE_PATCH14_336_CONFIG)
+    c._attn_implementation = "eager"
+    sp = synth.exact_tensor(tag + ".sp", (1, 12, 3, 336, 336))
+    tp = synth.exact_tensor(tag + ".tp", (1, 96, 3, 224, 224))
+    Wp = synth.projector_weights("phi3.5" if phi else "llama3", hid, 1024, 1408, seed=wseed + ".proj", exact=True)
+    cache = _feats_cache_name(tag, 12, (wseed + ".clip", wseed + ".iv2", wseed + ".proj"), sp, tp)
+    t0 = time.time()
+    if os.path.exists(cache):
+        feats = torch.load(cache)
+    else:
+        sk.vision_tower = _stream_load(ns.clip.CLIPVisionModel(c), lambda: synth.clip_weights(seed=wseed + ".clip", exact=True))
+        sk.video_encoder = _stream_load(_iv2(ns, 1408, 40, 16, 48 / 11, 224, 8), lambda: synth.iv2_weights(seed=wseed + ".iv2", exact=True))
+        sk.video_projecter = load_into(L.Video_Projecter(1408, hid), {k[len("video_projecter."):]: v for k, v in Wp.items() if k.startswith("video_projecter.")})
+        if phi:
+            sk.multi_modal_projector = load_into(L.Phi3_5_Projecter(), {k[len("multi_modal_projector."):]: v for k, v in Wp.items() if k.startswith("multi_modal_projector.")})
+            sk.glb_GN, sk.sub_GN = Wp["glb_GN"], Wp["sub_GN"]
+        else:
+            from transformers import LlavaConfig, CLIPVisionConfig, LlamaConfig
+            lc = LlavaConfig(vision_config=CLIPVisionConfig(hidden_size=1024, num_attention_heads=16),
+                             text_config=LlamaConfig(hidden_size=hid, num_hidden_layers=1, intermediate_size=64, num_attention_heads=4, vocab_size=32),
+                             projector_hidden_act="gelu", vision_feature_layer=-2)
+            sk.multi_modal_projector = load_into(L.LlavaMultiModalProjector(lc), {k[len("multi_modal_projector."):]: v for k, v in Wp.items() if k.startswith("multi_modal_projector.")})
+            sk.image_newline = Wp["image_newline"]
+        sk.config = type("C", (), {"hidden_size": hid})()
+        feats = sk.encode_images({"spatial_pixel_values": sp, "temporal_pixel_values": tp})
+        torch.save(feats, cache)
+        del sk.vision_tower, sk.video_encoder
+    print(f"[{tag} free] encode_images {time.time() - t0:.0f}s", flush=True)
+    if phi:
+        Wl = synth.llm_weights("phi3", seed="c0.llm", exact=True)
+        ocfg = O.LLMConfig("phi3", 3072, 8192, 32, 32, 32, 32366, 1e-5, 10000.0, 131072, 4096, *synth.longrope_factors(96))
+        ids = c0_ids()
+    else:
+        Wl = synth.llm_weights("llama", 4096, 14336, 32, 32, 8, 128558, True, seed="c3.llm", exact=True)
+        ocfg = O.LLMConfig("llama", 4096, 14336, 32, 32, 8, 128558, 1e-5, 500000.0, 8192, 0, None, None)
+        ids = c3_ids()
+    sk.embed = torch.nn.Embedding.from_pretrained(Wl["model.embed_tokens.weight"])
+    tid = torch.tensor([ids])
+    emb, _, mask = sk.prepare_multimodal_inputs(tid, tid.clone(), torch.ones_like(tid), feats, ["vid"])       # the reference's own splice
+    S = emb.shape[1]
+    t0 = time.time()
+    with torch.no_grad():
+        free_ids, margins = O.greedy_generate(ocfg, Wl, emb[0], n_free, None, use_cache=True, return_margins=True)
+        # the logit scale of the first step (units of the margins)
+        scale = float(O.llm_forward(ocfg, Wl, emb[0], last_only=True)[-1].abs().max())
+    print(f"[{tag} free] oracle greedy {time.time() - t0:.0f}s: ids {free_ids} margins/scale {[round(m / scale, 4) for m in margins]}", flush=True)
+    with open(os.path.join(OUT, tag + "_free.json"), "w") as f:
+        json.dump({"tag": tag, "ids": ids, "S": S, "free_ids": free_ids, "margins": margins, "scale": scale,
+                   "seeds": dict(clip=wseed + ".clip", iv2=wseed + ".iv2", proj=wseed + ".proj", llm=wseed + ".llm", sp=tag + ".sp", tp=tag + ".tp")}, f)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["int", "clip", "iv2", "phi3", "llama", "glue", "pre", "train"]
     ns = ref_shims.load_reference() if any(w != "pre" for w in which) else None
     for w in which:
         {"int": g_int, "clip": g_clip, "iv2": g_iv2, "phi3": g_phi3, "llama": g_llama, "glue": g_glue, "pre": g_pre, "train": g_train, "c0": g_c0,
-         "llama_full": g_llama_full, "c3": g_c3, "c4": g_c4, "c1": g_c1}[w](ns)
+         "llama_full": g_llama_full, "c3": g_c3, "c4": g_c4, "c1": g_c1,
+         "free_c1": lambda n: g_free(n, "c1"), "free_c3": lambda n: g_free(n, "c3")}[w](ns)

@@ -52,7 +52,7 @@ def test_bench_main_end_to_end_on_cpu(world, mode_args):
         assert [p["rank"] for p in d["per_rank_stage_ms"]] == list(range(world))
         assert all(set(p) >= {"vision_ms", "exchange_ms", "prefill_ms", "decode_ms"} for p in d["per_rank_stage_ms"])
         assert d["n_ranks_seen_by_rccl"] is None                 # the stub has no RCCL communicator; a real engine reports ncclCommCount
-    assert "launches_per_clip_serial" in d["roofline"] and not any(k.endswith("_per_step") for k in d["stages"])
+    assert "clips_in_profiled_pass" in d["roofline"] and not any(k.endswith("_per_step") for k in d["stages"])
 
 
 def test_bench_watchdog_names_the_hung_stage():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-N profiling passes on the GPU box (run through gpurun): kernel traces of the default and the serial bench, the two PMC
 # traffic passes, MFMA-utilisation counters per GEMM shape.  Outputs under gpurun_out/prof_$1/ ; summaries are copied to profiles/ by hand.
-R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r02}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r03}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 WHAT=${2:-all}
 db() { find "$1" -name "*.db" | head -1; }
@@ -10,11 +10,15 @@ if [[ $WHAT == all || $WHAT == trace ]]; then
   python $R/tools/rocpd_stats.py "$(db $OUT/default)" $OUT/${TAG}_bench_kernel_stats.txt > /dev/null
   rocprofv3 --kernel-trace -d $OUT/serial -- python $R/bench.py --plain --mode serial --steps 6 --warmup 1 > $OUT/serial.log 2>&1
   python $R/tools/rocpd_stats.py "$(db $OUT/serial)" $OUT/${TAG}_bench_kernel_stats_serial.txt > /dev/null
+  # the launches of the TIMED step (8 clips: batched CLIP / InternVideo2 / ragged prefill / decode) serialised on one stream: 3 steps = 24 clips.
+  # `roofline.gemm_ms_per_clip` of the bench line must equal (sum of the gemm_* rows) / 24 of this table.
+  rocprofv3 --kernel-trace -d $OUT/serial_step -- python $R/bench.py --plain --mode serial_step --steps 2 --warmup 1 > $OUT/serial_step.log 2>&1
+  python $R/tools/rocpd_stats.py "$(db $OUT/serial_step)" $OUT/${TAG}_bench_kernel_stats_serial_step.txt > /dev/null
 fi
 if [[ $WHAT == all || $WHAT == pmc ]]; then
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- python $R/bench.py --plain --mode serial --steps 3 --warmup 1 > $OUT/fetch.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- python $R/bench.py --plain --mode serial --steps 3 --warmup 1 > $OUT/write.log 2>&1
-  python $R/tools/pmc_traffic.py "$(db $OUT/fetch)" "$(db $OUT/write)" $OUT/${TAG}_pmc_traffic.json 4 > /dev/null
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- python $R/bench.py --plain --mode serial_step --steps 1 --warmup 1 > $OUT/fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- python $R/bench.py --plain --mode serial_step --steps 1 --warmup 1 > $OUT/write.log 2>&1
+  python $R/tools/pmc_traffic.py "$(db $OUT/fetch)" "$(db $OUT/write)" $OUT/${TAG}_pmc_traffic.json 16 > /dev/null
 fi
 if [[ $WHAT == all || $WHAT == mfma ]]; then
   : > $OUT/${TAG}_gemm_mfma_util.txt
@@ -38,4 +42,7 @@ phi.down 3519 3072 8192 resid
 sq8192 8192 8192 8192 plain
 SHAPES
 fi
+# the rocprofv3 databases are hundreds of MB: only the summaries travel back (gpurun_out/ is capped at 64 MiB)
+find $OUT -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
+rm -f $OUT/*.log.big
 ls -la $OUT/*.txt $OUT/*.json 2>/dev/null

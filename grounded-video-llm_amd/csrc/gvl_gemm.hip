@@ -617,6 +617,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
     u32x4_t rv[G::KI];
     u32x2_t ebv, egv;
     char* bgw = smem + PP_BG_OFF + wave * TN * 8;   // bias / gamma scratch of this wave (above the ring and the staging slices)
+#ifdef GVL_PP_ENERGY_LAB
+    bf16x8_t wf[NB], af[MB];
+#endif
     for (int t = 0; t < nk; ++t) {
       const char* sb = smem + (t & 1) * STAGE_BYTES;
       const bool more = t + 1 < nk;
@@ -626,13 +629,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
           if (ph == 0 && t == 0 && (G::has_bias || G::has_gamma)) stg_request_bias<NB, EPI_G>(a, n0 + wn * TN, lane, ebv, egv);
           if (ph == 0 && !more && PRE_RES) stg_request_resid<MB, NB, EPI_G>(a, m0 + wm * TM, n0 + wn * TN, lane, 0, rv);
         }
+#ifndef GVL_PP_ENERGY_LAB
         bf16x8_t wf[NB], af[MB];
+#endif
         const int coff = ((ph * 2 + h) ^ swz) << 4;
+#ifdef GVL_PP_ENERGY_LAB          // LAB (wrong results, timing only): bit 0 = fragment reads in phase 0 only (1/4 of the LDS reads), bit 1 = no DMA after the first tile
+        if (!(GVL_PP_ENERGY_LAB & 1) || ph == 0) {
+#endif
 #pragma unroll
         for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
 #pragma unroll
         for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
+#ifdef GVL_PP_ENERGY_LAB
+        }
+        if (!(GVL_PP_ENERGY_LAB & 2))
+#endif
+#ifdef GVL_PP_ENERGY_LAB          // bit 2: the DMA always re-reads k-tile (t & 3): same instruction stream and L2 -> LDS bytes, but every line is an L1 / L2 hit
+        if (ph < 2 && more) stage_half((t + 1) & 1, ((GVL_PP_ENERGY_LAB & 4) ? ((t + 1) & 3) : (t + 1)) * BK, ph);
+#else
         if (ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
+#endif
         if (ph == 3 && (more || !STAGED)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last k-tile: no DMA pending, residual stays in flight
         if constexpr (STAGED) {
           if (ph == 3 && t == 0 && (G::has_bias || G::has_gamma)) stg_store_bias<NB, EPI_G>(bgw, lane, ebv, egv);

@@ -164,6 +164,12 @@ def make_pixels(D: Dev, seed: int, n_segs=12, fps=8, hw=(336, 224)):
     return sp, tp
 
 
+def make_inputs(dev, rank, n_segs=12, fps=8, n_text=100):
+    """One clip's pixels and a prompt of n_text ids (tests/test_gpu_fullsize.py): (spatial [n,3,336,336], temporal [n,3,fps,224,224], ids)."""
+    sp, tp = make_pixels(Dev(torch.device(dev)), 42 + rank, n_segs, fps)
+    return sp, tp, make_prompt(42, n_text)
+
+
 class Stepper:
     """The stages of the hot path on one rank, over a resident POOL of distinct inputs.
     world == 1: pool entry i = clip i (12 segments) and its prompt.  world > 1: pool entry i = the 12 segment blocks this rank encodes in

@@ -174,3 +174,28 @@ def test_c4_full_depth_long_context_vs_reference_golden(llama):
     at real size on one device (tests/golden/c4_full.npz, oracle/make_golden.py c4: 32-segment encode_images, one fp32 forward over
     the prefix plus 63 teacher-forced tokens, every 4th row stored)."""
     _full_depth_vs_reference_golden(llama, "c4_full")
+
+
+def test_c3_free_running_greedy_vs_oracle_continuation(llama):
+    """The same for BASELINE configs[3] (Llama-3-8B, 96 frames): tests/golden/c3_free.json = fp32 reference prefix + the oracle's KV-cached greedy."""
+    import json, os
+    from conftest import GOLDEN
+    eng, geo = llama
+    path = os.path.join(GOLDEN, "c3_free.json")
+    if not os.path.exists(path):
+        pytest.skip("c3_free.json not generated (oracle/make_golden.py free_c3: ~25 min and 40 GB on the build container)")
+    fr = json.load(open(path))
+    sd = fr["seeds"]
+    sp = synth.exact_tensor(sd["sp"], (1, 12, 3, 336, 336), device=DEV)[0]
+    tp = synth.exact_tensor(sd["tp"], (1, 96, 3, 224, 224), device=DEV)
+    tseg = tp.reshape(1, 12, 8, 3, 224, 224).permute(0, 1, 3, 2, 4, 5).flatten(0, 1).contiguous()
+    ms = geo.max_segs
+    vis = torch.cat([eng.encode_segments(sp[i:i + ms], tseg[i:i + ms]) for i in range(0, 12, ms)], 0)
+    emb = eng.splice(fr["ids"], vis)
+    assert emb.shape[0] == fr["S"]
+    got = eng.generate_ids(emb, len(fr["free_ids"]), None)
+    rel = [m / fr["scale"] for m in fr["margins"]]
+    n_same = next((i for i, (a, b) in enumerate(zip(got, fr["free_ids"])) if a != b), len(got))
+    print(f"[parity] C3 free-running greedy: {n_same} of {len(got)} ids equal the fp32 continuation; ids {got} vs {fr['free_ids']}; margins/scale {[round(r, 4) for r in rel]}")
+    if n_same < len(got):
+        assert rel[n_same] < 2 * 2.7e-2, f"greedy id differs at step {n_same} although the margin is {rel[n_same]:.3e} of the logit scale"

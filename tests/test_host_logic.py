@@ -507,9 +507,10 @@ def test_reset_embeddings_grows_a_base_language_model():
 
 
 def test_committed_bench_line_meets_the_driver_contract():
-    """The one JSON line bench.py prints (committed copy of a default run: profiles/r02_bench_1gpu.json) carries every field the driver
+    """The one JSON line bench.py prints (committed copy of a default run: profiles/rNN_bench_1gpu.json, newest round) carries every field the driver
     and the tier's measurement rules ask for, with consistent values."""
-    path = os.path.join(ROOT, "profiles", "r02_bench_1gpu.json")
+    import glob
+    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench_1gpu.json")))[-1]       # the newest round's committed line
     d = json.loads(open(path).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
@@ -525,6 +526,12 @@ def test_committed_bench_line_meets_the_driver_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["oracle_ids_equal_reference_golden"] is True
+    if "r03" in path or "r04" in path or "r05" in path:
+        # round 3: the north-star sharded single-clip latency, honest key names, the profiled pass = the timed step's launches
+        assert d["single_clip_latency_ms_sharded"] > 0 and d["ids_match_serial"] is True
+        assert r["clips_in_profiled_pass"] == cps and "one_clip_serial" in r and not any(k.endswith("_per_step") for k in d["stages"])
+        assert abs(d["stages"]["gemm_ms_per_clip"] - r["gemm_ms_per_clip"]) < 1e-6
+        assert "ragged" in d["config"]["workload"] and d["config"]["distinct_clips_resident"] >= 2 * cps
 
 
 def test_generate_kwargs_map_to_hf_token_selection_semantics():

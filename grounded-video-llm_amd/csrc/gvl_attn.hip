@@ -76,9 +76,10 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   const int hkv = head / (a.H / a.KV);
   const int q0 = qb * (NWAVES * 32);
   const int qw = q0 + wave * 32;
-  const int n_tiles_all = (a.S + 63) >> 6;
+  const int Sk = a.Sk > 0 ? a.Sk : a.S, qpos0 = a.qpos0;    // keys of the context; absolute position of query 0 (extend-prefill: the cached prefix comes first)
+  const int n_tiles_all = (Sk + 63) >> 6;
   int last_q = q0 + NWAVES * 32 - 1; if (last_q > a.S - 1) last_q = a.S - 1;
-  const int n_tiles = a.causal ? (last_q >> 6) + 1 : n_tiles_all;
+  const int n_tiles = a.causal ? ((qpos0 + last_q) >> 6) + 1 : n_tiles_all;
 
   // ---- DMA source offsets inside a page (elements), loop invariant --------------------------------
   unsigned koff[NIK], voff[NIK];              // BYTE offsets (32-bit): the page base stays in SGPRs, no 64-bit VALU adds per piece
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     if (t + NS - 1 < n_tiles) { int nb = cur + NS - 1; if (nb >= NS) nb -= NS; stage(nb, t + NS - 1); }
     const int tb = cur;
     cur = cur + 1 == NS ? 0 : cur + 1;
-    if (a.causal && t * 64 > qw + 31) continue;   // wave-uniform: every key of this tile is in the future
+    if (a.causal && t * 64 > qpos0 + qw + 31) continue;   // wave-uniform: every key of this tile is in the future
     const char* kb_ = smem + tb * STAGE_BYTES;
     const char* vb_ = kb_ + TILE_BYTES;
 
@@ -172,14 +173,14 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
       }
     }
     // ---- online softmax (lane-local; raw-score max, scale folded into the exp2 argument) ---------------
-    const bool need_mask = (t == n_tiles_all - 1 && (a.S & 63)) || (a.causal && t * 64 + 63 > qw);
+    const bool need_mask = (t == n_tiles_all - 1 && (Sk & 63)) || (a.causal && t * 64 + 63 > qpos0 + qw);
     if (need_mask) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = t * 64 + kb * 32 + (r >> 3) * 16 + 8 * h + (r & 7);
-          const bool dead = key >= a.S || (a.causal && key > my_q);
+          const bool dead = key >= Sk || (a.causal && key > qpos0 + my_q);
           s[kb][r] = dead ? -1e30f : s[kb][r];
         }
     }
@@ -290,15 +291,17 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
 
 double gvl_attn_flops(const AttnArgs& a) {
   // algorithmic: 4*S^2*d*H non-causal, half that causal, d = real head dim
-  const double f = 4.0 * (double)a.S * a.S * a.Dout * a.H * a.B;
-  return a.causal ? 0.5 * f : f;
+  const double Sk = a.Sk > 0 ? a.Sk : a.S;
+  const double f = 4.0 * (double)a.S * Sk * a.Dout * a.H * a.B;
+  return a.causal ? f * (a.qpos0 + 0.5 * a.S) / Sk : f;      // causal: query i sees qpos0 + i + 1 keys
 }
 
 int gvl_launch_attention(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
   static const float lazy = [] { const char* e = gvl_lab_env("GVL_ATTN_LAZY"); return e ? (float)atof(e) : 8.f; }();      // A/B: 0 = move the reference whenever a max grows
   a.lazy = lazy >= 0.f && lazy <= 64.f ? lazy : 8.f;
-  if (a.B <= 0 || a.S <= 0 || a.S > 256 * 64 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 7) || ((uintptr_t)a.O & 15)) return -1;   // 16-byte O stores
+  if (a.Sk < 0 || a.qpos0 < 0 || (a.Sk > 0 && (a.Sk < a.S + a.qpos0 || !a.block_table)) || (a.Sk == 0 && a.qpos0 != 0)) return -1;   // a context longer than the queries lives in pages of a block table
+  if (a.B <= 0 || a.S <= 0 || a.S > 256 * 64 || a.Sk > 256 * 64 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 7) || ((uintptr_t)a.O & 15)) return -1;   // 16-byte O stores
   switch (a.D) {
     // ring depth 2: 48 KB (D=96) -> 3 blocks / CU at 151 VGPRs (measured 427 us vs 461 us for the 73 KB depth-3 ring, which
     // caps residency at 2 blocks / CU; DMA latency is not the limiter -- PMC shows the kernel is VALU-issue-bound)

@@ -66,6 +66,7 @@ struct gvl_ctx {
   char* arena_l = nullptr; size_t arena_l_bytes = 0, arena_l_off = 0;    // LLM prefill (own arena: may overlap vision on another stream)
   // KV pool
   bf16_t *kpool = nullptr, *vpool = nullptr; size_t layer_stride = 0; std::vector<int> free_pages;
+  std::vector<int> page_ref;             // sequences holding each page: full pages of a shared prefix are referenced, never copied (gvl_seq_fork)
   std::vector<Seq> seqs;
   static constexpr int kMaxSeqs = 256;   // live sequences (slots of the device-side tables); the KV pool is the real limit
   int* d_seq_tables = nullptr; int* d_seq_pos = nullptr; int seq_table_cap = 0;   // [kMaxSeqs][seq_table_cap], [kMaxSeqs]

@@ -142,7 +142,8 @@ struct AttnArgs {
   bf16_t* O;            // [B][S][H*Dout]
   const int* block_table;  // [B][max_pages] page ids, or null: page(b,t) = b*n_tiles + t
   int max_pages;
-  int B, H, KV, S, D, Dout;   // S = number of queries == number of keys (self attention), q_pos0 = 0
+  int B, H, KV, S, D, Dout;   // S = number of queries; keys: Sk (0 = S, plain self attention)
+  int Sk, qpos0;              // extend-prefill (gvl_prefill_extend): query i sits at position qpos0 + i of a context of Sk = qpos0 + S keys (causal: key <= qpos0 + i)
   float scale;
   int causal;
   int ones_row;         // D > Dout only: V^T pad row Dout holds 1.0 for every key (QkvPostArgs.ones_row), so the P.V MFMAs deliver the

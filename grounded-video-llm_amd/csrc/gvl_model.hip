@@ -81,6 +81,7 @@ int alloc_kv_pool(gvl_ctx* ctx, int pages) {
   if (hipMemset(ctx->kpool, 0, pool) != hipSuccess || hipMemset(ctx->vpool, 0, pool) != hipSuccess) return fail(ctx, GVL_ERR_HIP, "hipMemset(kv pool) failed");
   ctx->free_pages.clear();
   for (int p = pages - 1; p >= 0; --p) ctx->free_pages.push_back(p);
+  ctx->page_ref.assign(pages, 0);
   ctx->kv_total_pages = pages;
   return 0;
 }
@@ -256,11 +257,14 @@ int pick_tokens(gvl_ctx* ctx, ArgmaxArgs& am, Seq* const* sqs, hipStream_t st) {
 // (packed back to back, no padding); RoPE / KV append / causal attention run per sequence on its own pages -- as ONE launch with a
 // batch dimension when the lengths are equal, as nb launches otherwise.  Every kernel is batch-invariant, so each sequence's
 // result is bit-identical to a prefill on its own.
-int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embeds, const int* lens, hipStream_t st, const LossReq* loss = nullptr) {
+// pos0 > 0 (one sequence only): EXTEND -- the sequence already holds pos0 tokens (a multiple of 64: whole pages, possibly shared with other
+// sequences); the new rows take positions pos0 .. pos0 + len - 1 and attend to the cached prefix plus themselves.
+int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embeds, const int* lens, hipStream_t st, const LossReq* loss = nullptr, int pos0 = 0) {
   const gvl_config& f = ctx->cfg;
   const int Hd = f.hidden, H = f.heads, KV = f.kv_heads, Dr = ctx->l_Dr, D = ctx->l_D, I = f.inter;
   const int qkvw = (H + 2 * KV) * Dr;
   if (nb < 1 || nb > GVL_MAX_PREFILL_BATCH || nb == 3) return fail(ctx, GVL_ERR_ARG, "llm_prefill: batch must be 1, 2 or 4 sequences");
+  if (pos0 != 0 && (nb != 1 || (pos0 & 63) || loss)) return fail(ctx, GVL_ERR_ARG, "llm_prefill: extend takes one sequence whose cached prefix is whole pages");
   int off[GVL_MAX_PREFILL_BATCH + 1]; off[0] = 0;
   bool uniform = true;
   for (int b = 0; b < nb; ++b) { off[b + 1] = off[b] + lens[b]; uniform = uniform && lens[b] == lens[0]; }
@@ -291,13 +295,14 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
       const int* tbl = n_att == 1 ? table : sqs[u]->d_block_table;
       const int tstride = n_att == 1 ? table_stride : sqs[u]->n_pages;
       // LongRoPE: short factors up to the original context, long factors past it (modeling_phi3.py:381-385), per sequence
-      const bool use_long = f.rope_orig_max_pos > 0 && S > f.rope_orig_max_pos && ctx->cos_l;
+      const bool use_long = f.rope_orig_max_pos > 0 && pos0 + S > f.rope_orig_max_pos && ctx->cos_l;
       bf16_t* Qu = Q + (size_t)off[u] * H * D;
       { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv + (size_t)off[u] * qkvw; q.ld = qkvw; q.Q = Qu; q.Kt = Kt; q.Vt = Vt; q.block_table = tbl; q.max_pages = tstride;
-        q.B = B; q.S = S; q.H = H; q.KV = KV; q.Dr = Dr; q.D = D; q.mode = 2; q.cos = use_long ? ctx->cos_l : ctx->cos_s; q.sin = use_long ? ctx->sin_l : ctx->sin_s; q.pos0 = 0;
+        q.B = B; q.S = S; q.H = H; q.KV = KV; q.Dr = Dr; q.D = D; q.mode = 2; q.cos = use_long ? ctx->cos_l : ctx->cos_s; q.sin = use_long ? ctx->sin_l : ctx->sin_s; q.pos0 = pos0;
         RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
       { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Qu; a.Kt = Kt; a.Vt = Vt; a.O = att + (size_t)off[u] * H * Dr; a.block_table = tbl; a.max_pages = tstride;
         a.B = B; a.H = H; a.KV = KV; a.S = S; a.D = D; a.Dout = Dr; a.scale = 1.0f / sqrtf((float)Dr); a.causal = 1;
+        if (pos0) { a.Sk = pos0 + S; a.qpos0 = pos0; }
         RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
     }
     { GemmArgs g = gemm(att, H * Dr, w.ow, x, Hd, M, Hd, H * Dr); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
@@ -339,8 +344,8 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
     for (int b = 0; b < nb; ++b) sqs[b]->rng_stream = ctx->sample.next_stream++;     // a fresh random stream per prefilled sequence
     RUN(GVL_PROF_OTHER, 0, pick_tokens(ctx, am, sqs, st)); }
   for (int b = 0; b < nb; ++b) {
-    RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sqs[b]->d_pos, lens[b], st));
-    sqs[b]->pos = lens[b]; sqs[b]->n_gen = 1;
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sqs[b]->d_pos, pos0 + lens[b], st));
+    sqs[b]->pos = pos0 + lens[b]; sqs[b]->n_gen = 1;
   }
   return 0;
 }
@@ -851,7 +856,7 @@ int gvl_seq_alloc(gvl_ctx* ctx, int max_tokens, int* seq_id) {
   }
   Seq& s = ctx->seqs[id];
   s.used = true; s.max_tokens = max_tokens; s.n_pages = np; s.pos = 0; s.n_gen = 0; s.pages.clear();
-  for (int i = 0; i < np; ++i) { s.pages.push_back(ctx->free_pages.back()); ctx->free_pages.pop_back(); }
+  for (int i = 0; i < np; ++i) { s.pages.push_back(ctx->free_pages.back()); ctx->free_pages.pop_back(); ctx->page_ref[s.pages.back()] = 1; }
   // preallocated slot: no hipMalloc / hipFree / device-wide sync per clip.  Work that uses the slot is stream ordered;
   // a freed slot or page may be handed out again only for work enqueued later on the same stream (one stream per ctx
   // for the LLM path -- the reference is single-stream too).
@@ -868,8 +873,36 @@ int gvl_seq_alloc(gvl_ctx* ctx, int max_tokens, int* seq_id) {
 int gvl_seq_free(gvl_ctx* ctx, int seq_id) {
   if (!ctx || seq_id < 0 || seq_id >= (int)ctx->seqs.size() || !ctx->seqs[seq_id].used) return fail(ctx, GVL_ERR_ARG, "gvl_seq_free: bad seq");
   Seq& s = ctx->seqs[seq_id];
-  for (int p : s.pages) ctx->free_pages.push_back(p);
+  for (int p : s.pages) if (--ctx->page_ref[p] == 0) ctx->free_pages.push_back(p);     // a page shared with a fork lives on until its last holder is freed
   s = Seq();
+  return 0;
+}
+int gvl_seq_fork(gvl_ctx* ctx, int src_seq, int n_tokens, int max_tokens, int* dst_seq) {
+  REQUIRE_READY(ctx->has_llm, "gvl_seq_fork");
+  if (!dst_seq || src_seq < 0 || src_seq >= (int)ctx->seqs.size() || !ctx->seqs[src_seq].used) return fail(ctx, GVL_ERR_ARG, "gvl_seq_fork: bad arguments");
+  if (n_tokens <= 0 || (n_tokens & 63) || n_tokens > ctx->seqs[src_seq].pos) return fail(ctx, GVL_ERR_ARG, "gvl_seq_fork: n_tokens must be a positive multiple of 64 within the source's tokens");
+  if (max_tokens <= n_tokens || max_tokens > ctx->cfg.max_seq) return fail(ctx, GVL_ERR_ARG, "gvl_seq_fork: max_tokens must exceed n_tokens and fit cfg.max_seq");
+  const int shared = n_tokens >> 6, np = (max_tokens + 63) / 64;
+  if ((int)ctx->free_pages.size() < np - shared) return fail(ctx, GVL_ERR_OOM, "gvl_seq_fork: KV pages exhausted");
+  int id = -1;
+  for (size_t i = 0; i < ctx->seqs.size(); ++i) if (!ctx->seqs[i].used) { id = (int)i; break; }
+  if (id < 0) {
+    if ((int)ctx->seqs.size() >= gvl_ctx::kMaxSeqs) return fail(ctx, GVL_ERR_OOM, "gvl_seq_fork: too many live sequences");
+    ctx->seqs.emplace_back(); id = (int)ctx->seqs.size() - 1;
+  }
+  const std::vector<int> src_pages(ctx->seqs[src_seq].pages.begin(), ctx->seqs[src_seq].pages.begin() + shared);   // (emplace_back may have moved the source)
+  Seq& s = ctx->seqs[id];
+  s.used = true; s.max_tokens = max_tokens; s.n_pages = np; s.pos = n_tokens; s.n_gen = 0; s.pages = src_pages;
+  for (int p : s.pages) ++ctx->page_ref[p];          // whole pages of the prefix: immutable from now on for both holders (appends go to later pages)
+  for (int i = shared; i < np; ++i) { s.pages.push_back(ctx->free_pages.back()); ctx->free_pages.pop_back(); ctx->page_ref[s.pages.back()] = 1; }
+  s.d_block_table = ctx->d_seq_tables + (size_t)id * ctx->seq_table_cap;
+  s.d_pos = ctx->d_seq_pos + id;
+  s.d_tok = ctx->d_seq_tok + id;
+  s.d_out = ctx->d_seq_out + (size_t)id * ctx->outlist_cap;
+  s.d_ngen = ctx->d_seq_ngen + id;
+  s.d_eos = ctx->d_eos_flags + id; s.h_eos = ctx->h_eos_flags + id;
+  HIPCHK(ctx, hipMemcpy(s.d_block_table, s.pages.data(), (size_t)np * 4, hipMemcpyHostToDevice));
+  *dst_seq = id;
   return 0;
 }
 
@@ -882,6 +915,20 @@ int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int S, float* 
   hipStream_t st = (hipStream_t)stream;
   Seq* one[1] = {&sq}; const bf16_t* e1[1] = {embeds};
   int rc = llm_prefill(ctx, one, 1, e1, &S, st);
+  if (rc) return rc;
+  if (last_logits) HIPCHK(ctx, hipMemcpyAsync(last_logits, ctx->d_logits, (size_t)ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int gvl_prefill_extend(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int n_new, float* last_logits, void* stream) {
+  REQUIRE_READY(ctx->has_llm, "gvl_prefill_extend");
+  if (seq_id < 0 || seq_id >= (int)ctx->seqs.size() || !ctx->seqs[seq_id].used) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_extend: bad seq");
+  Seq& sq = ctx->seqs[seq_id];
+  if (sq.pos <= 0 || (sq.pos & 63)) return fail(ctx, GVL_ERR_STATE, "gvl_prefill_extend: the sequence must hold a prefix of whole pages (gvl_seq_fork)");
+  if (!embeds || n_new <= 0 || sq.pos + n_new > sq.max_tokens || n_new > ctx->cfg.max_prefill) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_extend: bad length");
+  hipStream_t st = (hipStream_t)stream;
+  Seq* one[1] = {&sq}; const bf16_t* e1[1] = {embeds};
+  int rc = llm_prefill(ctx, one, 1, e1, &n_new, st, nullptr, sq.pos);
   if (rc) return rc;
   if (last_logits) HIPCHK(ctx, hipMemcpyAsync(last_logits, ctx->d_logits, (size_t)ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
   return 0;

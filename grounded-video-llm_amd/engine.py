@@ -283,6 +283,20 @@ class Engine:
     def seq_free(self, seq: int):
         self._chk(self.lib.gvl_seq_free(self.ctx, int(seq)), "gvl_seq_free")
 
+    def seq_fork(self, src: int, n_tokens: int, max_tokens: int) -> int:
+        """A new sequence that SHARES the first n_tokens (multiple of 64) of `src` -- whole KV pages, referenced not copied (gvl_seq_fork)."""
+        sid = C.c_int(-1)
+        self._chk(self.lib.gvl_seq_fork(self.ctx, int(src), int(n_tokens), int(max_tokens), C.byref(sid)), "gvl_seq_fork")
+        return sid.value
+
+    def prefill_extend(self, seq: int, embeds_new: torch.Tensor, want_logits: bool = False) -> Optional[torch.Tensor]:
+        """Prefill of the rows that FOLLOW a forked prefix (gvl_prefill_extend): positions prefix .. prefix + n - 1, attention over prefix + new rows."""
+        embeds_new = embeds_new.contiguous()
+        assert embeds_new.dtype == bf and embeds_new.dim() == 2
+        lg = torch.empty((self.geo.vocab,), dtype=torch.float32, device=self.device) if want_logits else None
+        self._chk(self.lib.gvl_prefill_extend(self.ctx, int(seq), _ptr(embeds_new), embeds_new.shape[0], _ptr(lg), self.stream), "gvl_prefill_extend")
+        return lg
+
     def prefill(self, seq: int, embeds: torch.Tensor, want_logits: bool = False) -> Optional[torch.Tensor]:
         embeds = embeds.contiguous()
         logits = torch.empty((self.geo.vocab,), dtype=torch.float32, device=self.device) if want_logits else None

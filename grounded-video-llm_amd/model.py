@@ -281,9 +281,50 @@ class LLAVA_NEXT_VIDEO:
         ids = [self.tokenizer_image_token(t) for t in prompts]
         pad_id = getattr(self.tokenizer, "pad_token_id", 0) or 0
         ids_arr, mask = P.left_pad_truncate(ids, pad_id, self.max_txt_len)
-        feats = self.encode_images(samples).expand(len(prompts), -1, -1)
-        out_ids = self.generate_ids(ids_arr, mask, feats, max_new)
+        feats = self.encode_images(samples)
+        rows = [[int(t) for t, m in zip(ids_arr[i], mask[i]) if m] for i in range(len(prompts))]
+        out_ids = self._generate_shared_prefix(rows, feats[0], max_new)
+        if out_ids is None:                              # nothing worth sharing (one prompt, or the prompts part ways before 128 tokens)
+            out_ids = self.generate_ids(ids_arr, mask, feats.expand(len(prompts), -1, -1), max_new)
         return [t.strip() for t in self.tokenizer.batch_decode(out_ids, skip_special_tokens=True)]
+
+    def _generate_shared_prefix(self, rows: List[List[int]], vis: torch.Tensor, max_new: int) -> Optional[List[List[int]]]:
+        """Prompts about one video share the system prompt and the visual tokens: the common prefix (rounded down to 128 tokens = whole KV pages AND
+        whole query blocks, so that every later row is computed exactly as in a full prefill) is prefilled ONCE; every prompt forks it
+        (gvl_seq_fork: pages referenced, not copied) and prefills only its own tail (gvl_prefill_extend); the answers are decoded together.
+        Ids are bit-identical to one full prefill per prompt."""
+        eng = self.engine
+        self.last_shared_prefix = 0                      # tokens prefilled once for all prompts in the last generate_shared call (0 = not shared)
+        if len(rows) < 2:
+            return None
+        embs = [eng.splice(r, vis) for r in rows]
+        # common prefix in EMBEDDING rows: ids before the image slot must agree, then the visual rows, then the ids after it
+        k = rows[0].index(P.IMAGE_TOKEN_INDEX)
+        if any(r[:k + 1] != rows[0][:k + 1] for r in rows):
+            return None
+        n_vis = vis.shape[0]
+        tail = 0
+        while all(k + 1 + tail < len(r) for r in rows) and len({r[k + 1 + tail] for r in rows}) == 1:
+            tail += 1
+        shared = min(k + n_vis + tail, min(e.shape[0] for e in embs) - 1)     # every prompt keeps at least one row of its own (its last row feeds the first token)
+        prefix = shared // 128 * 128
+        if prefix < 128:
+            return None
+        self.last_shared_prefix = prefix
+        eos = getattr(self.tokenizer, "eos_token_id", None)
+        base, seqs = None, []
+        try:
+            base = eng.seq_alloc(prefix)
+            eng.prefill(base, embs[0][:prefix])
+            for e in embs:
+                seqs.append(eng.seq_fork(base, prefix, min(e.shape[0] + max_new, self.geo.max_seq)))
+                eng.prefill_extend(seqs[-1], e[prefix:])
+            return eng.decode_greedy_batch(seqs, max_new, eos)
+        finally:
+            for s_ in seqs:
+                eng.seq_free(s_)
+            if base is not None:
+                eng.seq_free(base)
 
     # training forward (SURVEY.md §8 f4) --------------------------------------------------------------------------
     @torch.inference_mode()

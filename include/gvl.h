@@ -126,6 +126,15 @@ int gvl_seq_free(gvl_ctx* ctx, int seq_id);
  * layers.  cfg.kv_pages > 0 fixes the pool size at gvl_create; cfg.kv_pages <= 0 sizes it in gvl_finalize_weights from the HBM
  * that is free once the weights are resident (env GVL_KV_FRACTION, default 0.85 of it, minus 4 GiB) -- on a 288 GB MI355X about
  * 670 k Phi-3.5 tokens.  Any out pointer may be NULL. */
+/* Prefix sharing (the reference asks three questions about ONE video, inference.py:178-182: the prompts share the system prompt and the
+ * 3 420 visual tokens).  gvl_seq_fork makes a new sequence whose first n_tokens (a multiple of 64 = whole KV pages, <= the source's
+ * tokens) ARE the source's pages -- referenced, not copied; a page returns to the pool when its last holder is freed -- and reserves
+ * fresh pages up to max_tokens.  gvl_prefill_extend then runs the decoder over the remaining n_new prompt rows only: they take
+ * positions prefix .. prefix + n_new - 1 and attend to the cached prefix plus themselves; last_logits / first token as gvl_prefill.
+ * With a prefix that is a multiple of 128 tokens the result is BIT-IDENTICAL to a gvl_prefill of the whole prompt (same query blocks,
+ * same page tiles, same k order); any multiple of 64 is within bf16 rounding of it. */
+int gvl_seq_fork(gvl_ctx* ctx, int src_seq, int n_tokens, int max_tokens, int* dst_seq);
+int gvl_prefill_extend(gvl_ctx* ctx, int seq_id, const uint16_t* embeds_new, int n_new, float* last_logits, void* stream);
 int gvl_kv_info(const gvl_ctx* ctx, int* total_pages, int* free_pages, int64_t* pool_bytes, int* max_live_seqs);
 int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int seq_len, float* last_logits,
                 void* stream);

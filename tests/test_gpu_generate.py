@@ -84,6 +84,7 @@ def test_generate_matches_oracle(llm):
     one = {"spatial_pixel_values": sp3[1:2], "temporal_pixel_values": tp3[1:2], "video_ids": ["x"]}
     shared = model.generate_shared(one, prompts, do_sample=False, num_beams=1, max_new_tokens=10)
     assert shared == [model.generate({**one, "prompts": [p]}, do_sample=False, num_beams=1, max_new_tokens=10)[0] for p in prompts]
+    assert model.last_shared_prefix >= 256 and model.last_shared_prefix % 128 == 0      # the system prompt + visual tokens were prefilled ONCE (gvl_seq_fork / gvl_prefill_extend)
     model.engine.close()
     # start from ONE packed weight file (tools/pack_checkpoint.py's output format) instead of state dicts: same answers
     import os, tempfile

@@ -765,3 +765,60 @@ def test_finished_members_do_not_truncate_the_group():
     eos = singles[1][8]                                                               # member 1 stops at its 9th token (or earlier), others where they must
     assert run(True, eos) == run(False, eos)
     eng.close()
+
+
+def test_prefix_sharing_fork_and_extend_prefill():
+    """gvl_seq_fork + gvl_prefill_extend (three prompts about ONE video share the system prompt and the visual prefix, inference.py:178-182):
+    a sequence forked at a multiple of 128 tokens and extended with the remaining rows gives BIT-identical logits, first token and greedy
+    continuation to a full prefill of the whole prompt (same query blocks, same page tiles); a fork at an odd multiple of 64 stays within
+    bf16 rounding; the shared pages are referenced, not copied -- the source may be freed first, and the pool is whole again at the end."""
+    c = dict(hidden=256, inter=512, layers=2, heads=4, kv_heads=4, vocab=400)
+    geo = _phi_geo(c, max_seq=1024, max_prefill=768, kv_pages=48)
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.fork", device=DEV)
+    eng = llm_engine(geo, W)
+    free0 = eng.kv_info()["free_pages"]
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    common = (torch.randn((300, c["hidden"]), device=DEV, generator=g) * 0.5).to(bf)
+    tails = [(torch.randn((n, c["hidden"]), device=DEV, generator=g) * 0.5).to(bf) for n in (37, 1, 140)]
+    full = [torch.cat([common, t], 0) for t in tails]
+    new = 9
+
+    def reference(e):
+        s = eng.seq_alloc(e.shape[0] + new + 1)
+        lg = eng.prefill(s, e, want_logits=True).clone()
+        ids = eng.decode_greedy(s, new, None)
+        eng.seq_free(s)
+        return lg, ids
+
+    refs = [reference(e) for e in full]
+    for prefix, exact in ((256, True), (128, True), (192, False), (64, False)):
+        base = eng.seq_alloc(prefix)
+        eng.prefill(base, common[:prefix])
+        forks, lgs = [], []
+        for e in full:
+            s = eng.seq_fork(base, prefix, e.shape[0] + new + 1)
+            lgs.append(eng.prefill_extend(s, e[prefix:], want_logits=True).clone())
+            forks.append(s)
+        eng.seq_free(base)                                  # the forks keep the shared pages alive
+        ids = eng.decode_greedy_batch(forks, new, None)
+        for s in forks:
+            eng.seq_free(s)
+        for i, (lg, idl) in enumerate(zip(lgs, ids)):
+            if exact:
+                assert torch.equal(lg, refs[i][0]), f"prefix {prefix}, prompt {i}: extend-prefill logits differ from the full prefill"
+                assert idl == refs[i][1], f"prefix {prefix}, prompt {i}: greedy ids differ"
+            else:
+                check(lg, refs[i][0], 1e-2, f"extend-prefill at prefix {prefix} (not a query-block boundary), prompt {i}, vs full prefill")
+        assert eng.kv_info()["free_pages"] == free0, "pages leaked or double-freed"
+    # argument checks: not a multiple of 64, beyond the source, extend without a prefix
+    base = eng.seq_alloc(300)
+    eng.prefill(base, common)
+    for bad in (100, 320):
+        with pytest.raises(RuntimeError):
+            eng.seq_fork(base, bad, 512)
+    s = eng.seq_alloc(64)
+    with pytest.raises(RuntimeError):
+        eng.prefill_extend(s, tails[0])
+    eng.seq_free(s); eng.seq_free(base)
+    assert eng.kv_info()["free_pages"] == free0
+    eng.close()

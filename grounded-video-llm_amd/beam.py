@@ -1,0 +1,109 @@
+"""Beam search as the reference gets it from HF `generate(num_beams=k, do_sample=False)` (inference.py:46,170-176 ->
+models/llava_next_video.py:655-661 -> transformers 4.40.1 GenerationMixin._beam_search + BeamSearchScorer / BeamHypotheses [ext],
+the version requirements.txt pins): host-side bookkeeping only -- the log-softmax / top-2k of every step and the KV cache
+live with the caller (`step`).  Restated, not imported: the installed transformers (5.x) no longer ships BeamSearchScorer; the
+CPU test drives this function and the installed `generate()` with the same tiny HF model and compares the sequences.
+
+Semantics kept from 4.40.1 (batch of one, one beam group):
+  * beam_scores start as [0, -1e9, ...]; per step the log-softmax of every running beam plus its score is flattened, the best
+    2k (token, beam) pairs are visited in order: an eos candidate of rank < k closes a hypothesis (score = sum of log-probs /
+    generated_len ** length_penalty, generated_len counting the eos), of rank >= k is skipped; the first k non-eos candidates are the
+    next running beams;
+  * the search is done when k hypotheses exist and (early_stopping, or the worst of them is at least the best running
+    sum-log-prob / cur_len ** length_penalty); at max_new_tokens the running beams are added as hypotheses;
+  * the answer is the best hypothesis, with eos appended when it ended by eos.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+
+class _Hyps:
+    """BeamHypotheses of transformers 4.40.1 (generation/beam_search.py) for one batch item."""
+
+    def __init__(self, num_beams: int, length_penalty: float, early_stopping):
+        self.k, self.lp, self.early = num_beams, length_penalty, early_stopping
+        self.beams: List[Tuple[float, List[int], bool]] = []
+        self.worst = 1e9
+
+    def add(self, toks: Sequence[int], sum_logprobs: float, generated_len: int, by_eos: bool):
+        score = sum_logprobs / (generated_len ** self.lp)
+        if len(self.beams) < self.k or score > self.worst:
+            self.beams.append((score, list(toks), by_eos))
+            if len(self.beams) > self.k:
+                order = sorted((s, i) for i, (s, _, _) in enumerate(self.beams))
+                del self.beams[order[0][1]]
+                self.worst = order[1][0]
+            else:
+                self.worst = min(score, self.worst)
+
+    def is_done(self, best_sum_logprobs: float, cur_len: int) -> bool:
+        if len(self.beams) < self.k:
+            return False
+        if self.early is True:
+            return True
+        if self.early is False:
+            return self.worst >= best_sum_logprobs / (cur_len ** self.lp)
+        # "never": a heuristic-free upper bound on what a running beam can still reach
+        if self.lp > 0.0:
+            raise ValueError("early_stopping='never' with length_penalty > 0 needs max_length; not used by the reference")
+        return self.worst >= best_sum_logprobs / (cur_len ** self.lp)
+
+
+def beam_search(step: Callable[[List[int], List[int]], torch.Tensor], first_logits: torch.Tensor, num_beams: int, max_new_tokens: int,
+                eos_id: Optional[int], length_penalty: float = 1.0, early_stopping=False) -> List[int]:
+    """first_logits [vocab]: logits after the prompt.  step(parents, tokens) -> logits [k, vocab] of the k new running beams, where new beam j
+    continues old beam parents[j] with tokens[j] (the caller reorders its KV cache accordingly; at the first call every parent is 0 = the
+    prompt).  Returns the NEW ids of the best hypothesis (eos included when it ended by eos), as HF does for inputs_embeds prompts."""
+    k = int(num_beams)
+    if k < 2:
+        raise ValueError("beam_search needs num_beams >= 2")
+    V = first_logits.shape[-1]
+    if V < 2 * k:
+        raise ValueError("vocabulary smaller than 2 x num_beams")
+    seqs: List[List[int]] = [[] for _ in range(k)]
+    scores = torch.full((k,), -1e9, dtype=torch.float32, device=first_logits.device)
+    scores[0] = 0.0
+    logits = first_logits.float().unsqueeze(0).expand(k, V)
+    hyps = _Hyps(k, length_penalty, early_stopping)
+    done = False
+    while True:
+        lp = torch.log_softmax(logits.float(), dim=-1) + scores[:, None]
+        top = torch.topk(lp.reshape(-1), 2 * k, largest=True, sorted=True)
+        vals, idxs = top.values.tolist(), top.indices.tolist()
+        cur_len = len(seqs[0]) + 1
+        nxt: List[Tuple[float, int, int]] = []
+        for rank, (v, ix) in enumerate(zip(vals, idxs)):
+            b, tok = ix // V, ix % V
+            if eos_id is not None and tok == eos_id:
+                if rank >= k:
+                    continue
+                hyps.add(seqs[b], v, cur_len, True)
+            else:
+                nxt.append((v, tok, b))
+            if len(nxt) == k:
+                break
+        if len(nxt) < k:
+            raise ValueError("fewer than num_beams non-eos candidates among the top 2 x num_beams")
+        done = done or hyps.is_done(max(vals), cur_len)
+        parents, toks = [b for _, _, b in nxt], [t for _, t, _ in nxt]
+        seqs = [seqs[b] + [t] for _, t, b in nxt]
+        scores = torch.tensor([v for v, _, _ in nxt], dtype=torch.float32, device=first_logits.device)
+        if done or len(seqs[0]) >= max_new_tokens:
+            break
+        logits = step(parents, toks)
+    if not done:
+        for j in range(k):                                   # finalize(): the open beams become hypotheses
+            hyps.add(seqs[j], float(scores[j]), len(seqs[j]), False)
+    best = max(hyps.beams, key=lambda x: x[0]) if hyps.beams else (0.0, seqs[0], False)
+    # python's sort is stable and HF takes sorted(...)[-1]: among equal scores the LAST added wins
+    top_score = best[0]
+    for h in hyps.beams:
+        if h[0] == top_score:
+            best = h
+    out = list(best[1])
+    if best[2] and eos_id is not None and len(out) < max_new_tokens:
+        out.append(eos_id)
+    return out

@@ -948,6 +948,18 @@ int gvl_launch_ce_rows(const bf16_t* logits, int ld, const int* targets, float* 
   hipLaunchKernelGGL(ce_rows_kernel, dim3(n), dim3(256), 0, st, logits, ld, targets, nll, V);
   return CHECK_LAUNCH();
 }
+// one KV page (all layers, K and V^T pools) copied to another page: grid (layers, 2), 16-byte pieces.  The partial last page of a cloned sequence.
+__global__ __launch_bounds__(256) void kv_page_copy_kernel(bf16_t* kpool, bf16_t* vpool, size_t layer_stride, size_t page_elems, int src_page, int dst_page) {
+  bf16_t* pool = blockIdx.y == 0 ? kpool : vpool;
+  const u32x4_t* s = (const u32x4_t*)(pool + (size_t)blockIdx.x * layer_stride + (size_t)src_page * page_elems);
+  u32x4_t* d = (u32x4_t*)(pool + (size_t)blockIdx.x * layer_stride + (size_t)dst_page * page_elems);
+  for (size_t i = threadIdx.x; i < page_elems / 8; i += 256) d[i] = s[i];
+}
+int gvl_launch_kv_page_copy(bf16_t* kpool, bf16_t* vpool, size_t layer_stride, size_t page_elems, int layers, int src_page, int dst_page, hipStream_t st) {
+  if (layers < 1 || (page_elems & 7) || src_page == dst_page) return -1;
+  hipLaunchKernelGGL(kv_page_copy_kernel, dim3(layers, 2), dim3(256), 0, st, kpool, vpool, layer_stride, page_elems, src_page, dst_page);
+  return CHECK_LAUNCH();
+}
 __global__ void inc_many_kernel(const IntPtrs ptrs) { if (threadIdx.x < ptrs.n) (*ptrs.p[threadIdx.x])++; }
 int gvl_launch_inc_many(const IntPtrs& ptrs, hipStream_t st) {
   if (ptrs.n < 1 || ptrs.n > GVL_MAX_DECODE_BATCH) return -1;

@@ -273,6 +273,7 @@ int gvl_launch_norm_tiled(bf16_t* x, bf16_t* xn, const bf16_t* w, int batch, int
 struct IntPtrs { int* p[GVL_MAX_DECODE_BATCH]; int n; };
 int gvl_launch_inc_many(const IntPtrs& ptrs, hipStream_t st);
 int gvl_launch_inc(int* p, hipStream_t st);
+int gvl_launch_kv_page_copy(bf16_t* kpool, bf16_t* vpool, size_t layer_stride, size_t page_elems, int layers, int src_page, int dst_page, hipStream_t st);
 int gvl_launch_set_int(int* p, int v, hipStream_t st);
 
 // ---- frame pre-processing (gvl_pre.hip) -------------------------------------------------------------------------

@@ -920,6 +920,45 @@ int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int S, float* 
   return 0;
 }
 
+int gvl_seq_clone(gvl_ctx* ctx, int src_seq, int max_tokens, int* dst_seq, void* stream) {
+  REQUIRE_READY(ctx->has_llm, "gvl_seq_clone");
+  if (!dst_seq || src_seq < 0 || src_seq >= (int)ctx->seqs.size() || !ctx->seqs[src_seq].used) return fail(ctx, GVL_ERR_ARG, "gvl_seq_clone: bad arguments");
+  const int pos = ctx->seqs[src_seq].pos;
+  if (pos <= 0 || max_tokens <= pos || max_tokens > ctx->cfg.max_seq) return fail(ctx, GVL_ERR_ARG, "gvl_seq_clone: the source must hold tokens and max_tokens must exceed them (and fit cfg.max_seq)");
+  const int shared = pos >> 6, np = (max_tokens + 63) / 64;
+  if ((int)ctx->free_pages.size() < np - shared) return fail(ctx, GVL_ERR_OOM, "gvl_seq_clone: KV pages exhausted");
+  int id = -1;
+  for (size_t i = 0; i < ctx->seqs.size(); ++i) if (!ctx->seqs[i].used) { id = (int)i; break; }
+  if (id < 0) {
+    if ((int)ctx->seqs.size() >= gvl_ctx::kMaxSeqs) return fail(ctx, GVL_ERR_OOM, "gvl_seq_clone: too many live sequences");
+    ctx->seqs.emplace_back(); id = (int)ctx->seqs.size() - 1;
+  }
+  const std::vector<int> src_pages = ctx->seqs[src_seq].pages;
+  const int src_ngen = ctx->seqs[src_seq].n_gen;
+  Seq& s = ctx->seqs[id];
+  s.used = true; s.max_tokens = max_tokens; s.n_pages = np; s.pos = pos; s.n_gen = src_ngen;
+  s.pages.assign(src_pages.begin(), src_pages.begin() + shared);
+  for (int p : s.pages) ++ctx->page_ref[p];
+  for (int i = shared; i < np; ++i) { s.pages.push_back(ctx->free_pages.back()); ctx->free_pages.pop_back(); ctx->page_ref[s.pages.back()] = 1; }
+  s.d_block_table = ctx->d_seq_tables + (size_t)id * ctx->seq_table_cap;
+  s.d_pos = ctx->d_seq_pos + id;
+  s.d_tok = ctx->d_seq_tok + id;
+  s.d_out = ctx->d_seq_out + (size_t)id * ctx->outlist_cap;
+  s.d_ngen = ctx->d_seq_ngen + id;
+  s.d_eos = ctx->d_eos_flags + id; s.h_eos = ctx->h_eos_flags + id;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(ctx, hipMemcpyAsync(s.d_block_table, s.pages.data(), (size_t)np * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));            // s.pages (host) must outlive the copy; also orders the clone behind the source's pending steps on this stream
+  if (pos & 63)                                       // the partial last page is private: copy the source's (all layers, K and V^T)
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_kv_page_copy(ctx->kpool, ctx->vpool, ctx->layer_stride, (size_t)ctx->cfg.kv_heads * 64 * ctx->l_D, ctx->cfg.layers,
+                                                   src_pages[shared], s.pages[shared], st));
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(s.d_pos, pos, st));
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(s.d_ngen, 0, st));
+  s.n_gen = 0;
+  *dst_seq = id;
+  return 0;
+}
+
 int gvl_prefill_extend(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int n_new, float* last_logits, void* stream) {
   REQUIRE_READY(ctx->has_llm, "gvl_prefill_extend");
   if (seq_id < 0 || seq_id >= (int)ctx->seqs.size() || !ctx->seqs[seq_id].used) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_extend: bad seq");

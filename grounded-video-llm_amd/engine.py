@@ -289,6 +289,12 @@ class Engine:
         self._chk(self.lib.gvl_seq_fork(self.ctx, int(src), int(n_tokens), int(max_tokens), C.byref(sid)), "gvl_seq_fork")
         return sid.value
 
+    def seq_clone(self, src: int, max_tokens: int) -> int:
+        """A copy of `src` at its current length: whole pages shared by reference, the partial last page copied (gvl_seq_clone; beam search)."""
+        sid = C.c_int(-1)
+        self._chk(self.lib.gvl_seq_clone(self.ctx, int(src), int(max_tokens), C.byref(sid), self.stream), "gvl_seq_clone")
+        return sid.value
+
     def prefill_extend(self, seq: int, embeds_new: torch.Tensor, want_logits: bool = False) -> Optional[torch.Tensor]:
         """Prefill of the rows that FOLLOW a forked prefix (gvl_prefill_extend): positions prefix .. prefix + n - 1, attention over prefix + new rows."""
         embeds_new = embeds_new.contiguous()

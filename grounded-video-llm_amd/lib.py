@@ -57,6 +57,7 @@ _SIGS = {
     "gvl_seq_alloc": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "gvl_seq_free": (C.c_int, [C.c_void_p, C.c_int]),
     "gvl_seq_fork": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "gvl_seq_clone": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "gvl_prefill_extend": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gvl_prefill": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gvl_decode_greedy": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.c_void_p]),

@@ -235,8 +235,8 @@ class LLAVA_NEXT_VIDEO:
         """HF generate's token selection for the kwargs the reference forwards (inference.py:170-176 -> llava_next_video.py:655-661):
         greedy, or temperature -> top-k (HF default 50) -> top-p sampling on the device; `seed` (extra) makes a run reproducible,
         otherwise every call draws a fresh seed from torch's CPU generator (so torch.manual_seed governs it, as it does HF's)."""
-        if kw.get("num_beams", 1) not in (1, None):
-            raise NotImplementedError("beam search (num_beams > 1) is not built; use num_beams=1")
+        if kw.get("num_beams", 1) not in (1, None) and kw.get("do_sample", False):
+            raise NotImplementedError("beam-sample (num_beams > 1 with do_sample=True) is not built; use do_sample=False for beam search or num_beams=1")
         if not kw.get("do_sample", False):
             self.engine.set_sampling(False)
             return
@@ -265,9 +265,51 @@ class LLAVA_NEXT_VIDEO:
         pad_id = getattr(self.tokenizer, "pad_token_id", 0) or 0
         ids_arr, mask = P.left_pad_truncate(ids, pad_id, self.max_txt_len)
         feats = self.encode_images(samples)
-        out_ids = self.generate_ids(ids_arr, mask, feats, max_new)
+        k = generate_kwargs.get("num_beams", 1) or 1
+        if k > 1:                                         # HF beam search (do_sample=False), one sample at a time
+            out_ids = [self.beam_generate_ids([int(t) for t, m in zip(ids_arr[b], mask[b]) if m], feats[b], k, max_new,
+                                              float(generate_kwargs.get("length_penalty", 1.0)), generate_kwargs.get("early_stopping", False))
+                       for b in range(ids_arr.shape[0])]
+        else:
+            out_ids = self.generate_ids(ids_arr, mask, feats, max_new)
         texts = self.tokenizer.batch_decode(out_ids, skip_special_tokens=True)
         return [t.strip() for t in texts]
+
+    def beam_generate_ids(self, row: List[int], vis: torch.Tensor, num_beams: int, max_new: int, length_penalty: float = 1.0, early_stopping=False) -> List[int]:
+        """generate(num_beams = k, do_sample = False): HF beam search (beam.py restates transformers 4.40.1's scorer) on the paged KV cache.  The k running
+        beams are k sequences; HF's per-step cache reorder becomes gvl_seq_clone -- a beam that continues another one shares its whole KV pages by
+        reference and copies only the partial last page; the first child of a parent simply keeps the parent's sequence.  Every beam advances by ONE
+        teacher-forced decode step per token (gvl_decode_step_logits); log-softmax / top-2k of the step run on the device (torch), the bookkeeping on
+        the host."""
+        from . import beam as B
+        eng = self.engine
+        eos = getattr(self.tokenizer, "eos_token_id", None)
+        emb = eng.splice(row, vis)
+        cap = min(emb.shape[0] + max_new + 1, self.geo.max_seq)
+        beams: List[int] = [eng.seq_alloc(cap)]
+        try:
+            first = eng.prefill(beams[0], emb, want_logits=True)
+
+            def step(parents: List[int], toks: List[int]) -> torch.Tensor:
+                keep, new = {}, [None] * len(parents)
+                for j, p_ in enumerate(parents):             # clones first: every parent is still at the length the children continue from
+                    if p_ in keep:
+                        new[j] = eng.seq_clone(beams[p_], cap)
+                    else:
+                        keep[p_] = j
+                for p_, j in keep.items():
+                    new[j] = beams[p_]
+                for p_, s_ in enumerate(beams):
+                    if p_ not in keep:
+                        eng.seq_free(s_)
+                beams[:] = new
+                return torch.stack([eng.decode_step_logits(s_, t) for s_, t in zip(beams, toks)])
+
+            return B.beam_search(step, first, num_beams, max_new, eos, length_penalty, early_stopping)
+        finally:
+            for s_ in beams:
+                if s_ is not None:
+                    eng.seq_free(s_)
 
     @torch.inference_mode()
     def generate_shared(self, samples, prompts: Sequence[str], **generate_kwargs) -> List[str]:

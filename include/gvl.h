@@ -135,6 +135,9 @@ int gvl_seq_free(gvl_ctx* ctx, int seq_id);
  * same page tiles, same k order); any multiple of 64 is within bf16 rounding of it. */
 int gvl_seq_fork(gvl_ctx* ctx, int src_seq, int n_tokens, int max_tokens, int* dst_seq);
 int gvl_prefill_extend(gvl_ctx* ctx, int seq_id, const uint16_t* embeds_new, int n_new, float* last_logits, void* stream);
+/* A copy of a sequence AT ITS CURRENT LENGTH (beam search: HF's cache reorder, transformers GenerationMixin._reorder_cache [ext]): whole pages
+ * are shared by reference, the partial last page is copied on `stream` (one launch over all layers); the clone then appends to its own pages. */
+int gvl_seq_clone(gvl_ctx* ctx, int src_seq, int max_tokens, int* dst_seq, void* stream);
 int gvl_kv_info(const gvl_ctx* ctx, int* total_pages, int* free_pages, int64_t* pool_bytes, int* max_live_seqs);
 int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int seq_len, float* last_logits,
                 void* stream);
@@ -149,7 +152,8 @@ int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t
  * this call, generation step, logits): reproducible, and independent of how sequences are grouped into decode batches.  (A call
  * that repeats the current seed while sequences are live continues the numbering instead, so newcomers never share a stream with
  * a running sequence; callers that make several generate() calls per request pass a different seed per call.)
- * torch.multinomial's random stream is not reproduced (parity = same kept set + same distribution).  num_beams > 1 is not built. */
+ * torch.multinomial's random stream is not reproduced (parity = same kept set + same distribution).  Beam search (num_beams > 1, do_sample = 0) is host
+ * bookkeeping over gvl_seq_clone + gvl_decode_step_logits (grounded_video_llm_amd/beam.py); beam-sample is not built. */
 int gvl_set_sampling(gvl_ctx* ctx, int do_sample, float temperature, int top_k, float top_p, uint64_t seed);
 /* Prefill of n_seqs sequences together, seq_lens[i] tokens each (ragged: prompts differ in length; the reference left-pads and
  * masks, llava_next_video.py:622-647 -- here the rows are packed back to back, no padding).  Groups of 4 / 2 / 1 sequences whose

@@ -572,3 +572,39 @@ def test_generate_kwargs_map_to_hf_token_selection_semantics():
             sel(**bad)
     with pytest.raises(NotImplementedError):
         sel(do_sample=False, num_beams=4)
+
+
+def test_beam_search_bookkeeping_equals_hf_generate():
+    """grounded_video_llm_amd/beam.py restates transformers 4.40.1's BeamSearchScorer / BeamHypotheses (the version the reference pins; the installed 5.x
+    has no such class any more).  Pin: the SAME tiny LlamaForCausalLM drives this function (logits by full re-forward per beam) and the installed
+    transformers' own generate(inputs_embeds=..., num_beams=k, do_sample=False) -- the sequences must be equal for k = 2, 3, 4, with and without an eos
+    id, length_penalty 1 and 2."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from grounded_video_llm_amd.beam import beam_search
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=50, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4, max_position_embeddings=256)
+    m = LlamaForCausalLM(cfg).eval()
+    E = m.get_input_embeddings().weight
+    n_eos_hits = 0
+    for seed in range(6):
+        emb = torch.randn((1, 7, 32), generator=torch.Generator().manual_seed(seed)) * 2.0
+        with torch.no_grad():                                            # an eos id the model really produces: the third token of the eos-free 3-beam answer
+            free = m.generate(inputs_embeds=emb, num_beams=3, do_sample=False, max_new_tokens=8, eos_token_id=None, pad_token_id=0)[0].tolist()
+        for k, eos, mx, lp in ((3, free[2], 9, 1.0), (4, None, 6, 1.0), (2, free[2], 12, 1.0), (3, free[1], 10, 2.0), (4, free[3], 10, 0.5)):
+            with torch.no_grad():
+                ref = m.generate(inputs_embeds=emb, num_beams=k, do_sample=False, max_new_tokens=mx, eos_token_id=eos, pad_token_id=0, length_penalty=lp, early_stopping=False)[0].tolist()
+
+            def fwd(x):
+                with torch.no_grad():
+                    return m(inputs_embeds=x).logits[0, -1]
+            beams = [[] for _ in range(k)]
+
+            def step(parents, toks):
+                beams[:] = [beams[p_] + [t] for p_, t in zip(parents, toks)]
+                return torch.stack([fwd(torch.cat([emb, E[torch.tensor(b)][None]], 1)) for b in beams])
+            got = beam_search(step, fwd(emb), k, mx, eos, lp, False)
+            while ref and ref[-1] == 0 and len(ref) > len(got):          # HF pads the batch row to the longest hypothesis
+                ref = ref[:-1]
+            assert got == ref, (seed, k, eos, mx, lp, got, ref)
+            n_eos_hits += int(eos is not None and eos in got)
+    assert n_eos_hits >= 1, "no case ended by eos: the hypothesis bookkeeping was not exercised"

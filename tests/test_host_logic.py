@@ -570,8 +570,10 @@ def test_generate_kwargs_map_to_hf_token_selection_semantics():
                 dict(do_sample=True, top_p=1.5)):
         with pytest.raises(ValueError):
             sel(**bad)
+    sel(do_sample=False, num_beams=4)                   # beam search: greedy token selection inside the steps, the beams live in generate()
+    assert d.engine.calls[-1] == ((False,), {})
     with pytest.raises(NotImplementedError):
-        sel(do_sample=False, num_beams=4)
+        sel(do_sample=True, num_beams=4)                # beam-sample is not built
 
 
 def test_beam_search_bookkeeping_equals_hf_generate():

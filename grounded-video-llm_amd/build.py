@@ -32,6 +32,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(CSRC, "build" + ("_" + TAG if TAG else ""))
     flags = FLAGS + os.environ.get("GVL_BUILD_DEFS", "").split()
+    if os.environ.get("GVL_BUILD_NO_VGPR_FORM"):          # LAB: MFMA accumulators in AGPRs (hipcc's default) for the listed sources, e.g. "gvl_attn.hip"
+        no_vf = os.environ["GVL_BUILD_NO_VGPR_FORM"].split(",")
+    else:
+        no_vf = []
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
@@ -41,7 +45,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
-            cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+            f_ = [x for x in flags if x not in ("-mllvm", "-amdgpu-mfma-vgpr-form")] if s in no_vf else flags
+            cmd = [hipcc] + f_ + ["-c", src, "-o", obj]
             if verbose:
                 print("[gvl build]", " ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

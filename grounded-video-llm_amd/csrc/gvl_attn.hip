@@ -150,6 +150,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef GVL_ATTN_LAB                  // LAB (wrong results, timing only): bit 0 no K/V DMA after the first tile, 1 exp2 -> one FMA, 2 no S^T MFMAs / reads, 3 no P.V MFMAs / reads
+    if (!(GVL_ATTN_LAB & 1))
+#endif
     if (t + NS - 1 < n_tiles) { int nb = cur + NS - 1; if (nb >= NS) nb -= NS; stage(nb, t + NS - 1); }
     const int tb = cur;
     cur = cur + 1 == NS ? 0 : cur + 1;
@@ -163,6 +166,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+#ifdef GVL_ATTN_LAB
+    if (GVL_ATTN_LAB & 4) { s[0][0] = (float)t; s[1][3] = qf[0][0]; } else
+#endif
 #pragma unroll
     for (int kk = 0; kk < DK; ++kk) {            // kk outer: the two accumulators alternate, no back-to-back dependent MFMAs
 #pragma unroll
@@ -212,12 +218,19 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#ifdef GVL_ATTN_LAB
+        const float p = (GVL_ATTN_LAB & 2) ? fmaf(s[kb][r], sc, nm) : ((GVL_ATTN_LAB & 16) ? __builtin_amdgcn_exp2f(s[kb][r]) : __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, nm)));   // bit 4: exp2 without the scale / shift FMA
+#else
         const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, nm));
+#endif
         s[kb][r] = p;
         if constexpr (!ONES) psum += p;
       }
     if constexpr (!ONES) l_run = l_run * alpha + psum;
     // ---- O^T += V^T . P^T ---------------------------------------------------------------------------
+#ifdef GVL_ATTN_LAB
+    if (GVL_ATTN_LAB & 8) { o[0][0] += s[0][1] + s[1][2]; } else
+#endif
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const int kb = st >> 1, r0 = (st & 1) * 8;

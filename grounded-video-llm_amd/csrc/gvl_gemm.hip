@@ -619,6 +619,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
     char* bgw = smem + PP_BG_OFF + wave * TN * 8;   // bias / gamma scratch of this wave (above the ring and the staging slices)
 #ifdef GVL_PP_ENERGY_LAB
     bf16x8_t wf[NB], af[MB];
+    u32x4_t lab_dmy[8];
+#pragma unroll
+    for (int q_ = 0; q_ < 8; ++q_) lab_dmy[q_] = u32x4_t{0u, 0u, 0u, 0u};
 #endif
     for (int t = 0; t < nk; ++t) {
       const char* sb = smem + (t & 1) * STAGE_BYTES;
@@ -645,7 +648,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         if (!(GVL_PP_ENERGY_LAB & 2))
 #endif
 #ifdef GVL_PP_ENERGY_LAB          // bit 2: the DMA always re-reads k-tile (t & 3): same instruction stream and L2 -> LDS bytes, but every line is an L1 / L2 hit
+        if ((GVL_PP_ENERGY_LAB & 8) && ph < 2 && more) {   // bit 3: the same bytes from L2, but into VGPRs (discarded) instead of LDS: the L2 -> CU transfer without the LDS write
+          const bf16_t* sbl = (ph == 0 ? a.W : a.A) + (t + 1) * BK;
+#pragma unroll
+          for (int q_ = 0; q_ < 4; ++q_)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(lab_dmy[ph * 4 + q_]) : "v"(voff[ph * 4 + q_]), "s"(sbl) : "memory");
+        } else
         if (ph < 2 && more) stage_half((t + 1) & 1, ((GVL_PP_ENERGY_LAB & 4) ? ((t + 1) & 3) : (t + 1)) * BK, ph);
+        if ((GVL_PP_ENERGY_LAB & 8) && ph == 3) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int q_ = 0; q_ < 8; ++q_) asm volatile("" :: "v"(lab_dmy[q_]));
+        }
 #else
         if (ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
 #endif

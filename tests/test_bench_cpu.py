@@ -69,3 +69,23 @@ def test_bench_watchdog_names_the_hung_stage():
     assert len(d["per_rank_stage_ms"]) == 2                      # the diagnostics gathered BEFORE the timed region survive the hang
     assert "WATCHDOG rank 0/2 stuck in stage" in e0
     assert outs[1][0] == 3 and "WATCHDOG rank 1/2" in outs[1][2]
+
+
+def test_bench_under_the_drivers_own_launcher():
+    """The driver's N > 1 command line verbatim (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P <script> --gpus N --steps K --warmup W), with the stub engine on gloo: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come
+    from the launcher itself, not from this test."""
+    if __import__("torch").cuda.is_available():
+        pytest.skip("plumbing test is for the GPU-less container")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GVL_BENCH_SAME_DEVICE")}
+    env.update(GVL_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tests", "bench_stub.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--new-tokens", "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["ids_match_serial"] is True
+    assert [q["rank"] for q in d["per_rank_stage_ms"]] == [0, 1]

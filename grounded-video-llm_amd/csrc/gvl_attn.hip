@@ -37,6 +37,31 @@ template <> struct KSwz<128> {  // 256-byte rows: phys = chunk ^ (row&15)
   static __device__ __forceinline__ int logical(int row, int pc) { return pc ^ (row & 15); }
 };
 
+// Row-major V image [64 keys][D] (VROW: the vision towers read V straight out of the fused-qkv GEMM output, no V^T pass): the P.V A operand
+// (lane (d, h) holds 8 consecutive KEYS of column d) is gathered by two ds_read_b64_tr_b16 -- each 16-lane group reads a [4 keys][16 d] block,
+// 4 contiguous d per lane, and receives it transposed (cdna_hip_programming.md T10).  One LDS cycle serves a 32-lane half: 4 key rows x 64
+// bytes, which must cover all 64 banks -> per-D chunk swizzle (involutions; invariant under row += 4, so a lane's base address is reused
+// with immediates for every 16-key step):  D = 96 (192-byte rows) needs none: rows 4j..4j+3 start at 0, 192, 128, 64 (mod 256).
+template <int D> struct VSwz;
+template <> struct VSwz<64> { static __device__ __forceinline__ int phys(int row, int c) { return c ^ (((row >> 1) & 1) << 2); } };
+template <> struct VSwz<96> { static __device__ __forceinline__ int phys(int, int c) { return c; } };
+template <> struct VSwz<128> { static __device__ __forceinline__ int phys(int row, int c) { return c ^ ((row & 3) << 2); } };
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+__device__ __forceinline__ bf16x8_t lds_tr8(const char* p0, const char* p1) {
+  typedef __attribute__((address_space(3))) s16x4_t* lp;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)p0), hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)p1);
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+// one DMA piece from a wave-uniform base + per-lane 32-bit byte offset (callers may predicate it per lane: inactive lanes leave their
+// 16 bytes of the lane-linear LDS image untouched)
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 // row i of the S^T MFMA reads key kperm(i) of the 32-key block, so that accumulator register r of
 // lane (q, h) holds key (r>>3)*16 + 8*h + (r&7).
 __device__ __forceinline__ int kperm(int i) {
@@ -47,7 +72,10 @@ __device__ __forceinline__ int kperm(int i) {
 // ONES: the V^T pad row Dout is all ones (D = 96, Dout = 88: InternVideo2), so O^T[Dout] accumulates the softmax row sum inside the
 // P.V MFMAs the kernel issues anyway -- the 32 VALU adds per key tile of the VALU-bound loop are dropped (the sum then runs over the
 // bf16-rounded probabilities the P.V product uses, in fp32).
-template <int D, int NWAVES, int NS, int ONES = 0>
+// VROW = 2: Q and K are token rows too (a.Qrows / a.Krows; needs D == Dout and no per-token transform of q / k: CLIP) -- no qkv_post pass at all.
+// VROW: V comes as token rows of a row-major matrix (a.Vrows, row stride a.v_ld, head h at column h * Dout) instead of V^T pages; the pad
+// columns Dout..D-1 of the LDS image are written once by the kernel (1.0 in column Dout when ONES) and skipped by the DMA.
+template <int D, int NWAVES, int NS, int ONES = 0, int VROW = 0>
 __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int NT = NWAVES * 64;
   constexpr int DK = D / 16;          // k-steps of the QK^T contraction
@@ -87,15 +115,20 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   for (int i = 0; i < NIK; ++i) {
     const int pos = i * NT + tid;
     const int kr = pos / CPR, kpc = pos - kr * CPR;
-    koff[i] = (unsigned)(kr * D + KSwz<D>::logical(kr, kpc) * 8) * 2;
-    const int vr = pos >> 3, vpc = pos & 7;
-    voff[i] = (unsigned)(vr * 64 + (vpc ^ ((vr >> 1) & 7)) * 8) * 2;
+    koff[i] = VROW == 2 ? (unsigned)(kr * a.k_ld + KSwz<D>::logical(kr, kpc) * 8) * 2 : (unsigned)(kr * D + KSwz<D>::logical(kr, kpc) * 8) * 2;
+    if constexpr (VROW) {
+      const int vr = pos / CPR, lc = VSwz<D>::phys(vr, pos - vr * CPR);
+      voff[i] = lc * 8 < a.Dout ? (unsigned)(vr * a.v_ld + lc * 8) * 2 : 0xffffffffu;      // pad chunk: no DMA
+    } else {
+      const int vr = pos >> 3, vpc = pos & 7;
+      voff[i] = (unsigned)(vr * 64 + (vpc ^ ((vr >> 1) & 7)) * 8) * 2;
+    }
   }
   // ---- Q fragments (MFMA B operand): lane (q = qw + l31, h) holds d = kk*16 + 8h + 0..7 ----------
   bf16x8_t qf[DK];
   {
     int qi = qw + l31; if (qi > a.S - 1) qi = a.S - 1;
-    const bf16_t* qp = a.Q + (((size_t)b * a.H + head) * a.S + qi) * D + 8 * h;
+    const bf16_t* qp = VROW == 2 ? a.Qrows + ((size_t)b * a.S + qi) * a.q_ld + head * D + 8 * h : a.Q + (((size_t)b * a.H + head) * a.S + qi) * D + 8 * h;
 #pragma unroll
     for (int kk = 0; kk < DK; ++kk) qf[kk] = *(const bf16x8_t*)(qp + kk * 16);
     // make hipcc retire these loads HERE: otherwise its scoreboard keeps them pending around the loop back-edge and
@@ -108,6 +141,15 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   // make hipcc wait vmcnt(0) (draining the DMA ring) every tile
   int* pages_s = (int*)(smem + NS * STAGE_BYTES);
   for (int i = tid; i < n_tiles; i += NT) pages_s[i] = a.block_table ? a.block_table[b * a.max_pages + i] : b * n_tiles_all + i;
+  if constexpr (VROW) {                              // pad columns of the V image, both ring slots, once
+    const int npc = CPR - (a.Dout >> 3);
+    for (int i = tid; i < NS * 64 * npc; i += NT) {
+      const int slot = i / (64 * npc), r = (i / npc) & 63, lc = (a.Dout >> 3) + i % npc;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (ONES && lc * 8 == a.Dout) v[0] = 0x3F80u;  // bf16 1.0 in column Dout: O^T[Dout] = sum_k P[k]
+      *(u32x4_t*)(smem + slot * STAGE_BYTES + TILE_BYTES + (r * CPR + VSwz<D>::phys(r, lc)) * 16) = v;
+    }
+  }
   __syncthreads();
   const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   auto stage = [&](int buf, int t) {
@@ -116,7 +158,40 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     const bf16_t* kp = a.Kt + pb;
     const bf16_t* vp = a.Vt + pb;
     const unsigned base = smem_base + buf * STAGE_BYTES + wave * 1024;
-    if constexpr (NIK == 2 || NIK == 3) {
+    if constexpr (VROW) {
+      const int rows_left = a.S - t * 64;            // wave-uniform; < 64 only in the last tile: rows past the end re-read the last real key row (P = 0 there)
+      if constexpr (VROW == 2) {
+        const bf16_t* kr_ = a.Krows + ((size_t)b * a.S + (size_t)t * 64) * a.k_ld + hkv * D;
+        if (rows_left >= 64) {
+          if constexpr (NIK == 2 || NIK == 3) glds16xn<NIK>(kr_, koff, base, NT * 16);
+          else {
+#pragma unroll
+            for (int i = 0; i < NIK; ++i) glds16s(kr_, koff[i], base + i * NT * 16);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NIK; ++i) {
+            const int r = (i * NT + tid) / CPR;
+            glds16s(kr_, r >= rows_left ? koff[i] - (unsigned)((r - rows_left + 1) * a.k_ld * 2) : koff[i], base + i * NT * 16);
+          }
+        }
+      } else {
+        glds16xn<NIK>(kp, koff, base, NT * 16);
+      }
+      const bf16_t* vr_ = a.Vrows + ((size_t)b * a.S + (size_t)t * 64) * a.v_ld + hkv * a.Dout;
+      if (rows_left >= 64) {                         // wave-uniform
+#pragma unroll
+        for (int i = 0; i < NIK; ++i)
+          if (voff[i] != 0xffffffffu) glds16s(vr_, voff[i], base + TILE_BYTES + i * NT * 16);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NIK; ++i) {
+          const int r = (i * NT + tid) / CPR;
+          const unsigned off = r >= rows_left ? voff[i] - (unsigned)((r - rows_left + 1) * a.v_ld * 2) : voff[i];
+          if (voff[i] != 0xffffffffu) glds16s(vr_, off, base + TILE_BYTES + i * NT * 16);
+        }
+      }
+    } else if constexpr (NIK == 2 || NIK == 3) {
       glds16xn<NIK>(kp, koff, base, NT * 16);
       glds16xn<NIK>(vp, voff, base + TILE_BYTES, NT * 16);
     } else {
@@ -139,6 +214,12 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   const int krow0 = kperm(l31);
   const int vswz = (l31 >> 1) & 7;
   const int my_q = qw + l31;
+  unsigned vtr[DB];                                    // VROW: byte offset of this lane's 4-element run in the V image, per 32-column block
+  if constexpr (VROW) {
+    const int i16 = lane & 15, g4 = (lane >> 4) & 1, r0 = 8 * h + (i16 >> 2);
+#pragma unroll
+    for (int db = 0; db < DB; ++db) vtr[db] = (unsigned)(r0 * (D * 2) + VSwz<D>::phys(r0, db * 4 + 2 * g4 + ((i16 & 3) >> 1)) * 16 + (i16 & 1) * 8);
+  }
 
   // NS-deep LDS ring: tile t+NS-1 is requested while tile t is consumed, so a DMA has NS-1 iterations to land.
   // Counted vmcnt (never 0 in steady state) + raw s_barrier: __syncthreads() would drain the DMA queue (guide §5).
@@ -240,7 +321,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
       const int coff = ((st * 2 + h) ^ vswz) << 4;
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        const bf16x8_t vf = *(const bf16x8_t*)(vb_ + (db * 32 + l31) * 128 + coff);
+        bf16x8_t vf;
+        if constexpr (VROW) { const char* p = vb_ + vtr[db] + st * (16 * D * 2); vf = lds_tr8(p, p + 4 * D * 2); }
+        else vf = *(const bf16x8_t*)(vb_ + (db * 32 + l31) * 128 + coff);
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o[db], 0, 0, 0);
       }
     }
@@ -287,11 +370,11 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
 // (A software-pipelined variant -- S^T of tile t + 1 issued under the softmax of tile t, third ring slot, second score tile, two waves per
 //  SIMD -- was built in round 2, passed every test and measured 16 % SLOWER (19.6 vs 16.9 ms of attention per clip): removed in round 3,
 //  DESIGN.md §3.2 keeps the numbers.)
-template <int D, int NWAVES, int NS, int ONES = 0>
+template <int D, int NWAVES, int NS, int ONES = 0, int VROW = 0>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
   constexpr int LDS = NS * 2 * 64 * D * 2 + 1024;   // ring + page-id table (256 pages)
   static bool attr_set = false;
-  auto kern = attn_fwd_kernel<D, NWAVES, NS, ONES>;
+  auto kern = attn_fwd_kernel<D, NWAVES, NS, ONES, VROW>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
     attr_set = true;
@@ -314,20 +397,24 @@ int gvl_launch_attention(const AttnArgs& a_in, hipStream_t st) {
   static const float lazy = [] { const char* e = gvl_lab_env("GVL_ATTN_LAZY"); return e ? (float)atof(e) : 8.f; }();      // A/B: 0 = move the reference whenever a max grows
   a.lazy = lazy >= 0.f && lazy <= 64.f ? lazy : 8.f;
   if (a.Sk < 0 || a.qpos0 < 0 || (a.Sk > 0 && (a.Sk < a.S + a.qpos0 || !a.block_table)) || (a.Sk == 0 && a.qpos0 != 0)) return -1;   // a context longer than the queries lives in pages of a block table
+  if (a.Vrows && (a.block_table || a.Sk || a.v_ld < a.KV * a.Dout || (a.v_ld & 7) || ((uintptr_t)a.Vrows & 15) || (size_t)64 * a.v_ld * 2 >= 0xffffffffull)) return -1;
+  if ((a.Krows != nullptr) != (a.Qrows != nullptr) || (a.Krows && (!a.Vrows || a.D != 64 || a.Dout != a.D || a.k_ld < a.KV * a.D || a.q_ld < a.H * a.D || ((a.k_ld | a.q_ld) & 7) ||
+                                                              (((uintptr_t)a.Krows | (uintptr_t)a.Qrows) & 15) || (size_t)64 * a.k_ld * 2 >= 0xffffffffull))) return -1;
   if (a.B <= 0 || a.S <= 0 || a.S > 256 * 64 || a.Sk > 256 * 64 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 7) || ((uintptr_t)a.O & 15)) return -1;   // 16-byte O stores
   switch (a.D) {
     // ring depth 2: 48 KB (D=96) -> 3 blocks / CU at 151 VGPRs (measured 427 us vs 461 us for the 73 KB depth-3 ring, which
     // caps residency at 2 blocks / CU; DMA latency is not the limiter -- PMC shows the kernel is VALU-issue-bound)
-    case 64: return launch_attn<64, 4, 2>(a, st);
+    case 64: return a.Krows ? launch_attn<64, 4, 2, 0, 2>(a, st) : a.Vrows ? launch_attn<64, 4, 2, 0, 1>(a, st) : launch_attn<64, 4, 2>(a, st);
     case 96: {
       static const bool no_ones = gvl_lab_env("GVL_ATTN_NO_ONES") != nullptr;                       // A/B
       // (192-query blocks of 6 waves -- 3 % instead of 5.9 % tail waste at S = 2049, K/V tiles shared by more waves -- measured 24.6 ms
       //  of attention per clip against 18.0: two 98 KB blocks per CU hide less latency than three 49 KB ones.  Round 2, dropped.)
       const int lr = a.Dout - 64;
       const bool ones = a.ones_row && !no_ones && a.Dout < 96 && lr >= 0 && (lr & 7) < 4 && !a.causal;
+      if (a.Vrows) return ones ? launch_attn<96, 4, 2, 1, 1>(a, st) : launch_attn<96, 4, 2, 0, 1>(a, st);
       return ones ? launch_attn<96, 4, 2, 1>(a, st) : launch_attn<96, 4, 2>(a, st);
     }
-    case 128: return launch_attn<128, 4, 2>(a, st);
+    case 128: return a.Vrows ? -1 : launch_attn<128, 4, 2>(a, st);     // row-major V is the vision towers' mode (head dims 64 and 88)
     default: return -1;
   }
 }

@@ -398,7 +398,7 @@ int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st) {
   } else {
     hipLaunchKernelGGL(qkv_post_kernel<1>, dim3((rows + 3) / 4), dim3(256), 0, st, a);
   }
-  if (!a.pos_ptr) {
+  if (!a.pos_ptr && a.Vt) {                          // Vt == null: the attention kernel reads V in place (AttnArgs.Vrows)
     const int n_tiles = (a.S + 63) >> 6;
     hipLaunchKernelGGL(v_transpose_kernel, dim3(n_tiles, a.KV, a.B), dim3(256), 0, st, a);
   }

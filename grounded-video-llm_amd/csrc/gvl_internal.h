@@ -139,6 +139,10 @@ struct AttnArgs {
   const bf16_t* Q;      // [B][H][S][D] bf16 (D = padded head dim: 64, 96 or 128)
   const bf16_t* Kt;     // key pages  [page][KV][64][D]
   const bf16_t* Vt;     // value pages [page][KV][D][64]  (transposed inside the page)
+  const bf16_t* Vrows;  // null, or V as token rows: V[b][s][kv head][0..Dout) = Vrows[(b*S + s)*v_ld + head*Dout + d] (the fused-qkv GEMM output of a
+  int v_ld;             //   vision tower, read in place: no V^T pass); then Vt is unused and block_table must be null
+  const bf16_t* Qrows; const bf16_t* Krows;   // both null, or (with Vrows; D == Dout == 64) q and k as token rows too: Qrows[(b*S + s)*q_ld + head*D + d], Krows likewise
+  int q_ld, k_ld;       //   -- a tower whose q / k need no per-token transform (CLIP) runs no qkv_post pass; then Q / Kt are unused
   bf16_t* O;            // [B][S][H*Dout]
   const int* block_table;  // [B][max_pages] page ids, or null: page(b,t) = b*n_tiles + t
   int max_pages;

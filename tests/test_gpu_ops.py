@@ -151,6 +151,22 @@ def test_attention_random_shapes(eng):
         test_attention(eng, B, S, H, KV, Dr, causal)
 
 
+def test_attention_in_place_operands_are_bit_identical_to_the_paged_path(eng):
+    """Non-causal attention reads V (and Q, K at head dim 64) straight from the fused-qkv matrix -- row-major V tiles gathered by
+    ds_read_b64_tr_b16 -- instead of going through Q / K pages and a V^T transpose pass (gvl_debug_set vision_in_place = 0): same MFMAs on
+    the same values in the same order, so not one output bit may differ; lengths around the 64-key tile boundary, padded head dims, GQA."""
+    for B, S, H, KV, Dr in ((1, 577, 16, 16, 64), (2, 2049, 4, 4, 88), (3, 63, 2, 1, 32), (2, 129, 4, 2, 88), (1, 257, 2, 2, 16), (2, 64, 4, 4, 64), (1, 65, 8, 2, 64), (1, 1, 2, 2, 64),
+                            (2, 130, 4, 4, 96), (1, 700, 2, 1, 80)):
+        qkv = _rand(f"inpl{B}{S}{H}{Dr}", (B * S, (H + 2 * KV) * Dr), 1.0).to(bf)
+        got = eng.op_attention(qkv, B, S, H, KV, Dr, Dr ** -0.5, 0)
+        eng.debug_set("vision_in_place", 0)
+        try:
+            ref = eng.op_attention(qkv, B, S, H, KV, Dr, Dr ** -0.5, 0)
+        finally:
+            eng.debug_set("vision_in_place", 1)
+        assert torch.equal(got, ref), (B, S, H, KV, Dr, float((got.float() - ref.float()).abs().max()))
+
+
 def test_attention_spike_forces_rescale(eng):
     # one key dominates late in the sequence: the online-softmax rescale branch must fire (guide §5.4 rule 26)
     B, S, H, Dr = 1, 300, 2, 64

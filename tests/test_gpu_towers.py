@@ -36,6 +36,8 @@ def test_clip(name, tol_g, tol_o):
     check(got[:, ::st[0], ::st[1]], g["penultimate"], tol_g, f"{name} vs reference golden (fp32)")
     ref = O.clip_penultimate(px, W, c["layers"], c["heads"], emu=True)
     check(got, ref, tol_o, f"{name} vs oracle (bf16 emulation)")
+    eng.debug_set("vision_in_place", 0)         # the round-2 operand path (Q / K pages + V^T transpose pass): bit-identical
+    assert torch.equal(eng.clip_encode(px.to(DEV)), got)
     eng.close()
 
 
@@ -60,6 +62,8 @@ def test_iv2(name, tol_g, tol_o):
     check(got[:, ::st[0], ::st[1]], g["out"], tol_g, f"{name} vs reference golden (fp32)")
     ref = O.iv2_encode(px, W, c["depth"], c["heads"], emu=True)
     check(got, ref, tol_o, f"{name} vs oracle (bf16 emulation)")
+    eng.debug_set("vision_in_place", 0)         # V^T pages with the ones row written by the transpose pass: bit-identical
+    assert torch.equal(eng.iv2_encode(px.to(DEV)), got)
     eng.close()
 
 

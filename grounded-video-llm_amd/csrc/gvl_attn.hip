@@ -72,6 +72,7 @@ __device__ __forceinline__ int kperm(int i) {
 // ONES: the V^T pad row Dout is all ones (D = 96, Dout = 88: InternVideo2), so O^T[Dout] accumulates the softmax row sum inside the
 // P.V MFMAs the kernel issues anyway -- the 32 VALU adds per key tile of the VALU-bound loop are dropped (the sum then runs over the
 // bf16-rounded probabilities the P.V product uses, in fp32).
+// VROW = 3: V rows + q rows normalised in the prologue (a.q_rs / a.q_nw: InternVideo2), K pages.
 // VROW = 2: Q and K are token rows too (a.Qrows / a.Krows; needs D == Dout and no per-token transform of q / k: CLIP) -- no qkv_post pass at all.
 // VROW: V comes as token rows of a row-major matrix (a.Vrows, row stride a.v_ld, head h at column h * Dout) instead of V^T pages; the pad
 // columns Dout..D-1 of the LDS image are written once by the kernel (1.0 in column Dout when ONES) and skipped by the DMA.
@@ -125,16 +126,28 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     }
   }
   // ---- Q fragments (MFMA B operand): lane (q = qw + l31, h) holds d = kk*16 + 8h + 0..7 ----------
+  // The loads are only ISSUED here; they are consumed after the first K / V tile has been requested below, so the block pays one memory
+  // latency for both instead of two in a row.
   bf16x8_t qf[DK];
+  u32x4_t qraw[DK], qw_[VROW == 3 ? DK : 1];
+  float q_rs = 1.f;
   {
     int qi = qw + l31; if (qi > a.S - 1) qi = a.S - 1;
-    const bf16_t* qp = VROW == 2 ? a.Qrows + ((size_t)b * a.S + qi) * a.q_ld + head * D + 8 * h : a.Q + (((size_t)b * a.H + head) * a.S + qi) * D + 8 * h;
+    if constexpr (VROW == 3) {                        // q in place + InternVideo2's full-width RMSNorm (qkv_post_kernel::norm_chunk, same rounding points)
+      const bf16_t* qp = a.Qrows + ((size_t)b * a.S + qi) * a.q_ld + head * a.Dout + 8 * h;
+      const bf16_t* wp = a.q_nw + head * a.Dout + 8 * h;
+      q_rs = a.q_rs[(size_t)b * a.S + qi];
 #pragma unroll
-    for (int kk = 0; kk < DK; ++kk) qf[kk] = *(const bf16x8_t*)(qp + kk * 16);
-    // make hipcc retire these loads HERE: otherwise its scoreboard keeps them pending around the loop back-edge and
-    // emits vmcnt(5..0) waits inside every iteration, which (in hardware) also drain our un-counted DMA ring
+      for (int kk = 0; kk < DK; ++kk) {
+        const bool real = kk * 16 + 8 * h < a.Dout;   // Dout is a multiple of 8: a chunk is all real or all padding
+        qraw[kk] = real ? *(const u32x4_t*)(qp + kk * 16) : u32x4_t{0u, 0u, 0u, 0u};
+        qw_[kk] = real ? *(const u32x4_t*)(wp + kk * 16) : u32x4_t{0u, 0u, 0u, 0u};
+      }
+    } else {
+      const bf16_t* qp = VROW == 2 ? a.Qrows + ((size_t)b * a.S + qi) * a.q_ld + head * D + 8 * h : a.Q + (((size_t)b * a.H + head) * a.S + qi) * D + 8 * h;
 #pragma unroll
-    for (int kk = 0; kk < DK; ++kk) asm volatile("" ::"v"(qf[kk]));
+      for (int kk = 0; kk < DK; ++kk) qraw[kk] = *(const u32x4_t*)(qp + kk * 16);
+    }
   }
 
   // page ids of this (b) row of the block table, staged in LDS once: a per-iteration global load of the table would
@@ -225,6 +238,21 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   // Counted vmcnt (never 0 in steady state) + raw s_barrier: __syncthreads() would drain the DMA queue (guide §5).
   stage(0, 0);
   if (NS == 3 && n_tiles > 1) stage(1, 1);
+#pragma unroll
+  for (int kk = 0; kk < DK; ++kk) {
+    if constexpr (VROW == 3) {
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack2bf(lo_bf(qw_[kk][e]) * rbf(lo_bf(qraw[kk][e]) * q_rs), hi_bf(qw_[kk][e]) * rbf(hi_bf(qraw[kk][e]) * q_rs));
+      qf[kk] = __builtin_bit_cast(bf16x8_t, o);
+    } else {
+      qf[kk] = __builtin_bit_cast(bf16x8_t, qraw[kk]);
+    }
+  }
+  // make hipcc retire the q loads HERE: otherwise its scoreboard keeps them pending around the loop back-edge and emits vmcnt(5..0)
+  // waits inside every iteration, which (in hardware) also drain our un-counted DMA ring
+#pragma unroll
+  for (int kk = 0; kk < DK; ++kk) asm volatile("" ::"v"(qf[kk]));
   int cur = 0;
   for (int t = 0; t < n_tiles; ++t) {
     if (NS == 3 && t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIK) : "memory");
@@ -398,7 +426,8 @@ int gvl_launch_attention(const AttnArgs& a_in, hipStream_t st) {
   a.lazy = lazy >= 0.f && lazy <= 64.f ? lazy : 8.f;
   if (a.Sk < 0 || a.qpos0 < 0 || (a.Sk > 0 && (a.Sk < a.S + a.qpos0 || !a.block_table)) || (a.Sk == 0 && a.qpos0 != 0)) return -1;   // a context longer than the queries lives in pages of a block table
   if (a.Vrows && (a.block_table || a.Sk || a.v_ld < a.KV * a.Dout || (a.v_ld & 7) || ((uintptr_t)a.Vrows & 15) || (size_t)64 * a.v_ld * 2 >= 0xffffffffull)) return -1;
-  if ((a.Krows != nullptr) != (a.Qrows != nullptr) || (a.Krows && (!a.Vrows || a.D != 64 || a.Dout != a.D || a.k_ld < a.KV * a.D || a.q_ld < a.H * a.D || ((a.k_ld | a.q_ld) & 7) ||
+  if ((a.q_rs != nullptr) != (a.q_nw != nullptr) || (a.q_rs && (!a.Qrows || a.Krows || !a.Vrows || a.D != 96 || a.q_ld < a.H * a.Dout || (a.q_ld & 7) || (((uintptr_t)a.Qrows | (uintptr_t)a.q_nw) & 15)))) return -1;
+  if ((!a.q_rs && (a.Krows != nullptr) != (a.Qrows != nullptr)) || (a.Krows && (!a.Vrows || a.D != 64 || a.Dout != a.D || a.k_ld < a.KV * a.D || a.q_ld < a.H * a.D || ((a.k_ld | a.q_ld) & 7) ||
                                                               (((uintptr_t)a.Krows | (uintptr_t)a.Qrows) & 15) || (size_t)64 * a.k_ld * 2 >= 0xffffffffull))) return -1;
   if (a.B <= 0 || a.S <= 0 || a.S > 256 * 64 || a.Sk > 256 * 64 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 7) || ((uintptr_t)a.O & 15)) return -1;   // 16-byte O stores
   switch (a.D) {
@@ -411,6 +440,7 @@ int gvl_launch_attention(const AttnArgs& a_in, hipStream_t st) {
       //  of attention per clip against 18.0: two 98 KB blocks per CU hide less latency than three 49 KB ones.  Round 2, dropped.)
       const int lr = a.Dout - 64;
       const bool ones = a.ones_row && !no_ones && a.Dout < 96 && lr >= 0 && (lr & 7) < 4 && !a.causal;
+      if (a.Vrows && a.q_rs) return ones ? launch_attn<96, 4, 2, 1, 3>(a, st) : launch_attn<96, 4, 2, 0, 3>(a, st);
       if (a.Vrows) return ones ? launch_attn<96, 4, 2, 1, 1>(a, st) : launch_attn<96, 4, 2, 0, 1>(a, st);
       return ones ? launch_attn<96, 4, 2, 1>(a, st) : launch_attn<96, 4, 2>(a, st);
     }

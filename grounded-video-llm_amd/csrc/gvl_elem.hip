@@ -274,6 +274,7 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
     }
     q_rs = rsqrtf(wave_sum(sq) / (a.H * a.Dr) + a.eps);
     k_rs = rsqrtf(wave_sum(sk) / (a.KV * a.Dr) + a.eps);
+    if (a.q_rs && lt == 0) a.q_rs[row] = q_rs;
   }
   int pos = a.pos0 + s_in;                          // token position (RoPE, cache slot)
   if (a.pos_ptr) pos = *a.pos_ptr;
@@ -327,11 +328,11 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
 #pragma unroll
     for (int i = 0; i < RC; ++i) {
       const int c = lane + 64 * i;
-      if (c < nq) { const int hd = c / cpr, dc = c - hd * cpr; *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + dc * 8) = norm_chunk(qreg[i], c, q_rs, a.qn); }
+      if (c < nq && !a.q_rs) { const int hd = c / cpr, dc = c - hd * cpr; *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + dc * 8) = norm_chunk(qreg[i], c, q_rs, a.qn); }
       if (c < nk) { const int hd = c / cpr, dc = c - hd * cpr; *(u32x4_t*)(Kb + (size_t)hd * (64 * a.D) + dc * 8) = norm_chunk(kreg[i], c, k_rs, a.kn); }
     }
   } else {
-    for (int c = lt; c < nq; c += TEAM) {
+    if (!a.q_rs) for (int c = lt; c < nq; c += TEAM) {
       const int hd = c / cpr, dc = c - hd * cpr;
       *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + dc * 8) = xform(qr, c, q_rs, a.qn);
     }
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
   }
   if (cpd > cpr) {                                   // zero the head-dim padding (88 -> 96)
     const int np = cpd - cpr;
-    for (int c = lt; c < a.H * np; c += TEAM) { const int hd = c / np; *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + (cpr + c % np) * 8) = zero; }
+    if (!a.q_rs) for (int c = lt; c < a.H * np; c += TEAM) { const int hd = c / np; *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + (cpr + c % np) * 8) = zero; }
     for (int c = lt; c < a.KV * np; c += TEAM) { const int hd = c / np; *(u32x4_t*)(Kb + (size_t)hd * (64 * a.D) + (cpr + c % np) * 8) = zero; }
   }
   // V^T column of this single row (decode).  Bulk rows go through v_transpose_kernel.
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const QkvPostArgs a) {
 int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st) {
   if ((a.Dr & 7) || (a.mode == 2 && (a.Dr & 15)) || (a.D & 7) || a.D < a.Dr || a.Dr > 128 || (a.ld & 7)) return -1;   // 16-byte chunks; rotate_half partner chunk-aligned
   const int rows = a.B * a.S;
+  if (a.q_rs && (a.mode != 1 || a.pos_ptr)) return -1;
   if (a.pos_ptr) {
     if (rows != 1 || a.mode != 2) return -1;
     hipLaunchKernelGGL(qkv_post_kernel<4>, dim3(1), dim3(256), 0, st, a);

@@ -143,6 +143,8 @@ struct AttnArgs {
   int v_ld;             //   vision tower, read in place: no V^T pass); then Vt is unused and block_table must be null
   const bf16_t* Qrows; const bf16_t* Krows;   // both null, or (with Vrows; D == Dout == 64) q and k as token rows too: Qrows[(b*S + s)*q_ld + head*D + d], Krows likewise
   int q_ld, k_ld;       //   -- a tower whose q / k need no per-token transform (CLIP) runs no qkv_post pass; then Q / Kt are unused
+  const float* q_rs; const bf16_t* q_nw;      // both null, or (Qrows set, Krows null, Vrows set): q needs the full-width RMSNorm of InternVideo2 --
+                        //   q'[d] = q_nw[head*Dout + d] * bf16(q[d] * q_rs[token]) applied to the fragments as they are loaded (K stays in pages)
   bf16_t* O;            // [B][S][H*Dout]
   const int* block_table;  // [B][max_pages] page ids, or null: page(b,t) = b*n_tiles + t
   int max_pages;
@@ -200,6 +202,8 @@ struct QkvPostArgs {
   const int* pos_ptr;              // mode 2 decode: device position of the (single) row, overrides pos0 when non-null
   const float* cos_l; const float* sin_l; int rope_switch;   // decode: long-factor tables used when pos+1 > rope_switch (>0)
   int ones_row;                    // V^T pad row Dr (needs D > Dr) is filled with 1.0 instead of 0: see AttnArgs.ones_row
+  float* q_rs;                     // mode 1, or null: [B*S] -- the q rows are NOT written; their RMS factor rsqrt(mean q^2 + eps) is, and the attention
+                                   //   kernel normalises the q fragments it loads from the qkv matrix itself (AttnArgs.q_rs / q_nw)
 };
 int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st);
 // HD 2x2 merge + sub_GN newline (Phi): f32 [n,576,C] -> bf16 [n,156,4C]

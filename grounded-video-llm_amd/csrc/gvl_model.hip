@@ -117,6 +117,7 @@ size_t iv2_bytes(const gvl_ctx* c, int n) {
   b += 2 * al256(M * C * 2) + al256(M * 3 * C * 2) + al256(M * C * 2) + al256(M * f.iv2_inter * 2);
   b += al256((size_t)n * c->v_TL * c->v_Kp * 2) + al256((size_t)n * c->v_TL * C * 2);
   b += al256((size_t)n * f.iv2_heads * c->v_S * c->v_D * 2) + 2 * al256((size_t)n * tiles * f.iv2_heads * 64 * c->v_D * 2);
+  b += al256(M * 4);                                   // per-token RMS factor of q (iv2_encode: qrs)
   return b + 4096;
 }
 size_t visual_bytes(const gvl_ctx* c, int n) {
@@ -165,7 +166,7 @@ int clip_encode(gvl_ctx* ctx, const float* px, int n, float* out, hipStream_t st
     const ClipLayerW& w = ctx->cl[l];
     RUN(GVL_PROF_OTHER, 0, gvl_launch_layernorm_f32(x, w.ln1w, w.ln1b, h, M, C, 1e-5f, st));
     { GemmArgs g = gemm(h, C, w.qkvw, qkv, 3 * C, M, 3 * C, C); g.bias = w.qkvb; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
-    const bool in_place = !vt_pages && D == Dr && D == 64;     // q, k, v read by the attention kernel straight from the fused-qkv matrix
+    const bool in_place = ctx->dbg.vision_in_place == 1 && D == Dr && D == 64;     // q, k, v read by the attention kernel straight from the fused-qkv matrix
     if (!in_place) { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv; q.ld = 3 * C; q.Q = Q; q.Kt = Kt; q.Vt = vt_pages ? Vt : nullptr; q.B = n; q.S = S; q.H = H; q.KV = H; q.Dr = Dr; q.D = D; q.mode = 0;
       RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
     { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; if (!vt_pages) { a.Vrows = qkv + 2 * C; a.v_ld = 3 * C; }
@@ -197,14 +198,16 @@ int iv2_encode(gvl_ctx* ctx, const float* px, int n, bf16_t* out, hipStream_t st
   { GemmArgs g = gemm(pA, ctx->v_Kp, ctx->v_patchw, pO, C, n * TL, C, ctx->v_Kp); g.bias = ctx->v_patchb;
     RUN(GVL_PROF_GEMM, 2.0 * n * TL * (double)C * 3 * f.iv2_patch * f.iv2_patch, gvl_launch_gemm(g, st)); }
   RUN(GVL_PROF_OTHER, 0, gvl_launch_iv2_embed(pO, ctx->v_cls, ctx->v_pos, x, n, TL, C, st));
-  const bool vt_pages = !ctx->dbg.vision_in_place;
+  const bool vt_pages = !ctx->dbg.vision_in_place, q_in_place = ctx->dbg.vision_in_place == 1 && D == 96;
+  AALLOC(qrs, float, (size_t)M);
   for (int l = 0; l < f.iv2_blocks_run; ++l) {
     const Iv2BlockW& w = ctx->vb[l];
     RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.n1, h, M, C, 1e-6f, st));
     { GemmArgs g = gemm(h, C, w.qkvw, qkv, 3 * C, M, 3 * C, C); RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
     { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv; q.ld = 3 * C; q.Q = Q; q.Kt = Kt; q.Vt = vt_pages ? Vt : nullptr; q.B = n; q.S = S; q.H = H; q.KV = H; q.Dr = Dr; q.D = D;
-      q.mode = 1; q.qn = w.qn; q.kn = w.kn; q.eps = 1e-6f; q.ones_row = D > Dr ? 1 : 0; RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
+      q.mode = 1; q.qn = w.qn; q.kn = w.kn; q.eps = 1e-6f; q.ones_row = D > Dr ? 1 : 0; q.q_rs = q_in_place ? qrs : nullptr; RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
     { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; if (!vt_pages) { a.Vrows = qkv + 2 * C; a.v_ld = 3 * C; } a.O = att; a.B = n; a.H = H; a.KV = H; a.S = S; a.D = D; a.Dout = Dr;
+      if (q_in_place) { a.Qrows = qkv; a.q_ld = 3 * C; a.q_rs = qrs; a.q_nw = w.qn; }      // q read in place, normalised by the attention prologue: no Q write pass
       a.scale = 1.0f / sqrtf((float)Dr); a.causal = 0; a.ones_row = D > Dr ? 1 : 0;   // head dim 88 padded to 96: the pad row of V^T carries the softmax row sum
       RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
     { GemmArgs g = gemm(att, C, w.projw, x, C, M, C, C); g.bias = w.projb; g.gamma = w.ls1; g.resid = x; g.ldr = C;
@@ -1134,7 +1137,7 @@ int gvl_debug_set(gvl_ctx* ctx, const char* key, int value) {
   if (k == "decode_attn_cpb") { if (value < 0 || value > 16) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: decode_attn_cpb must be 0 (default) .. 16"); ctx->dbg.decode_attn_cpb = value; }
   else if (k == "decode_attn_hpb") { if (value < 0) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: decode_attn_hpb must be >= 0"); ctx->dbg.decode_attn_hpb = value; }
   else if (k == "decode_graph") ctx->dbg.decode_graph = value != 0;
-  else if (k == "vision_in_place") ctx->dbg.vision_in_place = value != 0;
+  else if (k == "vision_in_place") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: vision_in_place must be 0, 1 or 2"); ctx->dbg.vision_in_place = value; }
   else return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: unknown key " + k);
   return 0;
 }
@@ -1228,7 +1231,7 @@ int gvl_op_attention(gvl_ctx* ctx, const uint16_t* q, const uint16_t* k, const u
   AALLOC(Q, bf16_t, (size_t)B * H * S * D); AALLOC(Kt, bf16_t, (size_t)B * tiles * KV * 64 * D); AALLOC(Vt, bf16_t, (size_t)B * tiles * KV * 64 * D);
   // non-causal (vision) attention reads v -- and, when no head-dim padding is needed, q and k -- in place, exactly as the towers do
   const int ld = (H + 2 * KV) * Dr;
-  const bool v_rows = ctx->dbg.vision_in_place && !causal && D != 128, qk_rows = v_rows && D == Dr && D == 64;
+  const bool v_rows = ctx->dbg.vision_in_place && !causal && D != 128, qk_rows = ctx->dbg.vision_in_place == 1 && v_rows && D == Dr && D == 64;
   if (!qk_rows) { QkvPostArgs p; memset(&p, 0, sizeof(p)); p.qkv = q; p.ld = ld; p.Q = Q; p.Kt = Kt; p.Vt = v_rows ? nullptr : Vt; p.B = B; p.S = S; p.H = H; p.KV = KV; p.Dr = Dr; p.D = D; p.mode = 0;
     RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(p, st)); }
   { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; a.O = out; a.B = B; a.H = H; a.KV = KV; a.S = S; a.D = D; a.Dout = Dr; a.scale = scale; a.causal = causal;

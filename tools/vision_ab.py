@@ -21,7 +21,7 @@ sp = torch.randn((NSEG, 3, geo.clip_image, geo.clip_image), device="cuda:0", gen
 runs = {"iv2": lambda: eng.iv2_encode(tp), "clip": lambda: eng.clip_encode(sp)}
 outs = {}
 for rnd in range(rounds):
-    for mode in (1, 0):
+    for mode in (1, 2, 0):
         eng.debug_set("vision_in_place", mode)
         for name, fn in runs.items():
             out = fn(); torch.cuda.synchronize()

@@ -516,6 +516,8 @@ def main(argv=None, engine_factory=None):
                     help="pipelined: 2 x cps clips in flight per GPU (vision of the next clips overlaps prefill + decode of the current ones); serial: one clip at a "
                          "time; serial_step: the launches of a pipelined step (cps clips, batched CLIP / InternVideo2 / prefill / decode) back to back on ONE stream -- "
                          "the rocprofv3 target whose per-kernel times `roofline` must agree with")
+    ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=INT",
+                    help="gvl_debug_set(KEY, INT) before the run (result-neutral launch parameters, include/gvl.h): A/B measurements in one place")
     ap.add_argument("--watchdog-s", type=float, default=float(os.environ.get("GVL_BENCH_WATCHDOG_S", "900")),
                     help="seconds one stage may last before the run is declared hung (0 = off)")
     args = ap.parse_args(argv)
@@ -553,6 +555,9 @@ def main(argv=None, engine_factory=None):
     else:
         eng, geo = build_engine(dev, max_segs=12 * cps if clip_batch else 12, new_tokens=args.new_tokens, clips_per_step=cps,
                                 kv_pages=int(os.environ.get("GVL_BENCH_KV_PAGES", "0")))
+    for kv in args.debug_set:
+        k, v = kv.split("=")
+        eng.debug_set(k, int(v))
     hw = getattr(eng, "bench_hw", (336, 224))
     st = Stepper(eng, geo, rank, world, args.new_tokens, pool=2 * cps, hw=hw)
 

@@ -266,6 +266,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     const int tb = cur;
     cur = cur + 1 == NS ? 0 : cur + 1;
     if (a.causal && t * 64 > qpos0 + qw + 31) continue;   // wave-uniform: every key of this tile is in the future
+    // (Letting the waves of the last query block that hold no real query -- 3 of 4 at S = 2049 -- skip the tile body was measured: the extra
+    //  wave-uniform branch costs 16 VGPRs (172: 2 blocks / CU; also when folded into the causal skip's own compare) or, capped at 168 by __launch_bounds__, a worse schedule: +4 % either way.)
     const char* kb_ = smem + tb * STAGE_BYTES;
     const char* vb_ = kb_ + TILE_BYTES;
 

@@ -128,7 +128,14 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   // ---- Q fragments (MFMA B operand): lane (q = qw + l31, h) holds d = kk*16 + 8h + 0..7 ----------
   // The loads are only ISSUED here; they are consumed after the first K / V tile has been requested below, so the block pays one memory
   // latency for both instead of two in a row.
-  bf16x8_t qf[DK];
+  const float sc = a.scale * 1.4426950408889634f;  // scores in log2 units
+  // FOLD (VROW = 3, Dout = D - 8: InternVideo2): the softmax shift and scale ride inside the S^T MFMAs.  q is pre-multiplied by `sc` before its
+  // one rounding to bf16; K's pad column Dout holds 1.0 (qkv_post, k_ones) and q's pad element Dout holds MINUS the row's reference point,
+  // so the accumulators come out as (score - reference) in log2 units and the probabilities are a bare v_exp_f32: the 32 FMAs per key tile
+  // of the VALU-bound loop are gone.  The reference only has to be SOME value near the running max (the division by the row sum cancels
+  // it), so keeping it bf16-representable costs nothing; it moves (rarely: `lazy`) by rewriting that one q element.
+  constexpr bool FOLD = VROW == 3;
+  u32x4_t qf[DK];                                   // kept as dwords: FOLD rewrites one of them inside the loop, and hipcc re-packs a loop-carried bf16x8 every iteration
   u32x4_t qraw[DK], qw_[VROW == 3 ? DK : 1];
   float q_rs = 1.f;
   {
@@ -221,7 +228,6 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
-  const float sc = a.scale * 1.4426950408889634f;  // scores in log2 units
 
   // K fragment rows (permuted) and their swizzled chunk offsets; V^T fragment rows
   const int krow0 = kperm(l31);
@@ -243,10 +249,10 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     if constexpr (VROW == 3) {
       u32x4_t o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = pack2bf(lo_bf(qw_[kk][e]) * rbf(lo_bf(qraw[kk][e]) * q_rs), hi_bf(qw_[kk][e]) * rbf(hi_bf(qraw[kk][e]) * q_rs));
-      qf[kk] = __builtin_bit_cast(bf16x8_t, o);
+      for (int e = 0; e < 4; ++e) o[e] = pack2bf(lo_bf(qw_[kk][e]) * rbf(lo_bf(qraw[kk][e]) * q_rs) * sc, hi_bf(qw_[kk][e]) * rbf(hi_bf(qraw[kk][e]) * q_rs) * sc);   // FOLD: scores come out in log2 units
+      qf[kk] = o;
     } else {
-      qf[kk] = __builtin_bit_cast(bf16x8_t, qraw[kk]);
+      qf[kk] = qraw[kk];
     }
   }
   // make hipcc retire the q loads HERE: otherwise its scoreboard keeps them pending around the loop back-edge and emits vmcnt(5..0)
@@ -254,6 +260,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
 #pragma unroll
   for (int kk = 0; kk < DK; ++kk) asm volatile("" ::"v"(qf[kk]));
   int cur = 0;
+  int first_tile = 1;                                      // FOLD: the first tile sets the reference to its own max (whatever its sign)
+  if constexpr (FOLD) m_run = 0.f;
   for (int t = 0; t < n_tiles; ++t) {
     if (NS == 3 && t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIK) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
       for (int kb = 0; kb < 2; ++kb) {
         const int row = kb * 32 + krow0;
         const bf16x8_t kf = *(const bf16x8_t*)(kb_ + row * (D * 2) + (KSwz<D>::phys(row, kk * 2 + h) << 4));
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qf[kk]), s[kb], 0, 0, 0);
       }
     }
     // ---- online softmax (lane-local; raw-score max, scale folded into the exp2 argument) ---------------
@@ -314,6 +322,25 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     // and after the first tile of a row almost never moves again.  (Moving it whenever any row's max grew at all skipped 12 % of the
     // rescales at S = 2049: with 32 rows per wave some row nearly always grows a little.)
     float alpha = 1.f;
+    if constexpr (FOLD) {
+      // m_run = the reference (bf16-representable, log2 units, starts at 0); mx = tile max RELATIVE to it
+      if (first_tile || !__all(mx <= a.lazy)) {
+        const float m_new = rbf(m_run + (first_tile ? mx : fmaxf(mx, 0.f)));
+        const float de = m_new - m_run;
+        alpha = __builtin_amdgcn_exp2f(-de);
+        m_run = m_new;
+        first_tile = 0;
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kb][r] -= de;      // this tile's scores were taken against the old reference
+        qf[DK - 1][0] = h ? (unsigned)f2bf(-m_run) : qf[DK - 1][0];   // element Dout of q: the h = 1 lane's last chunk, low half of dword 0 (Dout + 1 is padding: 0)
+      }
+    } else
     if (!__all((mx - m_run) * sc <= a.lazy)) {   // wave-uniform: some row's tile max is far above its reference -> move it, rescale O
       const float m_new = fmaxf(m_run, mx);
       alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
@@ -332,7 +359,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
 #ifdef GVL_ATTN_LAB
         const float p = (GVL_ATTN_LAB & 2) ? fmaf(s[kb][r], sc, nm) : ((GVL_ATTN_LAB & 16) ? __builtin_amdgcn_exp2f(s[kb][r]) : __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, nm)));   // bit 4: exp2 without the scale / shift FMA
 #else
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, nm));
+        const float p = FOLD ? __builtin_amdgcn_exp2f(s[kb][r]) : __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, nm));
 #endif
         s[kb][r] = p;
         if constexpr (!ONES) psum += p;
@@ -442,7 +469,7 @@ int gvl_launch_attention(const AttnArgs& a_in, hipStream_t st) {
       //  of attention per clip against 18.0: two 98 KB blocks per CU hide less latency than three 49 KB ones.  Round 2, dropped.)
       const int lr = a.Dout - 64;
       const bool ones = a.ones_row && !no_ones && a.Dout < 96 && lr >= 0 && (lr & 7) < 4 && !a.causal;
-      if (a.Vrows && a.q_rs) return ones ? launch_attn<96, 4, 2, 1, 3>(a, st) : launch_attn<96, 4, 2, 0, 3>(a, st);
+      if (a.Vrows && a.q_rs) { if (a.Dout != 88 || !a.k_ones) return -1; return ones ? launch_attn<96, 4, 2, 1, 3>(a, st) : launch_attn<96, 4, 2, 0, 3>(a, st); }
       if (a.Vrows) return ones ? launch_attn<96, 4, 2, 1, 1>(a, st) : launch_attn<96, 4, 2, 0, 1>(a, st);
       return ones ? launch_attn<96, 4, 2, 1>(a, st) : launch_attn<96, 4, 2>(a, st);
     }

@@ -344,7 +344,11 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
   if (cpd > cpr) {                                   // zero the head-dim padding (88 -> 96)
     const int np = cpd - cpr;
     if (!a.q_rs) for (int c = lt; c < a.H * np; c += TEAM) { const int hd = c / np; *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + (cpr + c % np) * 8) = zero; }
-    for (int c = lt; c < a.KV * np; c += TEAM) { const int hd = c / np; *(u32x4_t*)(Kb + (size_t)hd * (64 * a.D) + (cpr + c % np) * 8) = zero; }
+    for (int c = lt; c < a.KV * np; c += TEAM) {
+      const int hd = c / np;
+      u32x4_t v = zero; if (a.k_ones && c % np == 0) v[0] = 0x3F80u;      // bf16 1.0 in column Dr
+      *(u32x4_t*)(Kb + (size_t)hd * (64 * a.D) + (cpr + c % np) * 8) = v;
+    }
   }
   // V^T column of this single row (decode).  Bulk rows go through v_transpose_kernel.
   if (a.pos_ptr) {

@@ -143,6 +143,7 @@ struct AttnArgs {
   int v_ld;             //   vision tower, read in place: no V^T pass); then Vt is unused and block_table must be null
   const bf16_t* Qrows; const bf16_t* Krows;   // both null, or (with Vrows; D == Dout == 64) q and k as token rows too: Qrows[(b*S + s)*q_ld + head*D + d], Krows likewise
   int q_ld, k_ld;       //   -- a tower whose q / k need no per-token transform (CLIP) runs no qkv_post pass; then Q / Kt are unused
+  int k_ones;           // the K pages' pad column Dout holds 1.0 (QkvPostArgs.k_ones): required by the q_rs mode, which folds the softmax shift into the S^T MFMAs
   const float* q_rs; const bf16_t* q_nw;      // both null, or (Qrows set, Krows null, Vrows set): q needs the full-width RMSNorm of InternVideo2 --
                         //   q'[d] = q_nw[head*Dout + d] * bf16(q[d] * q_rs[token]) applied to the fragments as they are loaded (K stays in pages)
   bf16_t* O;            // [B][S][H*Dout]
@@ -202,6 +203,7 @@ struct QkvPostArgs {
   const int* pos_ptr;              // mode 2 decode: device position of the (single) row, overrides pos0 when non-null
   const float* cos_l; const float* sin_l; int rope_switch;   // decode: long-factor tables used when pos+1 > rope_switch (>0)
   int ones_row;                    // V^T pad row Dr (needs D > Dr) is filled with 1.0 instead of 0: see AttnArgs.ones_row
+  int k_ones;                      // K pad column Dr (needs D > Dr) is 1.0 instead of 0 (harmless while q's pad is 0; see AttnArgs.k_ones)
   float* q_rs;                     // mode 1, or null: [B*S] -- the q rows are NOT written; their RMS factor rsqrt(mean q^2 + eps) is, and the attention
                                    //   kernel normalises the q fragments it loads from the qkv matrix itself (AttnArgs.q_rs / q_nw)
 };

@@ -62,8 +62,15 @@ def test_iv2(name, tol_g, tol_o):
     check(got[:, ::st[0], ::st[1]], g["out"], tol_g, f"{name} vs reference golden (fp32)")
     ref = O.iv2_encode(px, W, c["depth"], c["heads"], emu=True)
     check(got, ref, tol_o, f"{name} vs oracle (bf16 emulation)")
-    eng.debug_set("vision_in_place", 0)         # V^T pages with the ones row written by the transpose pass: bit-identical
-    assert torch.equal(eng.iv2_encode(px.to(DEV)), got)
+    # operand paths: 0 = Q / K pages + V^T transpose pass (round 2); 2 = V read in place -- the same arithmetic, bit-identical to 0;
+    # 1 (default, `got`) = q in place too, normalised, scaled and rounded ONCE in the attention prologue with the softmax shift folded into
+    # the S^T MFMAs: a different (not larger) set of rounding points, held to the same goldens above and to path 0 within bf16 noise
+    eng.debug_set("vision_in_place", 0)
+    paged = eng.iv2_encode(px.to(DEV))
+    eng.debug_set("vision_in_place", 2)
+    assert torch.equal(eng.iv2_encode(px.to(DEV)), paged)
+    check(got, paged.float(), tol_o, f"{name}: folded in-place attention vs the paged path")
+    check(paged[:, ::st[0], ::st[1]], g["out"], tol_g, f"{name} (paged path) vs reference golden (fp32)")
     eng.close()
 
 

@@ -33,5 +33,6 @@ for rnd in range(rounds):
             eng.prof_enable(True); fn(); torch.cuda.synchronize()
             fam = {k: eng.prof_read(c)[0] for k, c in (("gemm", L.PROF_GEMM), ("attn", L.PROF_ATTN), ("other", L.PROF_OTHER))}
             eng.prof_enable(False)
-            same = outs.setdefault(name, out) is out or bool(torch.equal(outs[name], out))
+            first = outs.setdefault(name, out)
+            same = "yes" if first is out or bool(torch.equal(first, out)) else f"no (max diff {float((first.float() - out.float()).abs().max() / first.float().abs().max()):.2e} of scale)"
             print(f"[vision_ab] round {rnd} {name:4s} in_place={mode}: wall {wall:7.3f} ms  gemm {fam['gemm']:7.3f}  attn {fam['attn']:7.3f}  other {fam['other']:6.3f}  bit-identical to first: {same}", flush=True)

@@ -261,7 +261,7 @@ int pick_tokens(gvl_ctx* ctx, ArgmaxArgs& am, Seq* const* sqs, hipStream_t st) {
   return gvl_launch_sample(am, st);
 }
 
-// Prefill of nb = 1, 2 or 4 sequences together (lens[b] tokens each).  The decoder GEMMs run over the rows of all of them
+// Prefill of nb = 1 .. 8 sequences together (lens[b] tokens each).  The decoder GEMMs run over the rows of all of them
 // (packed back to back, no padding); RoPE / KV append / causal attention run per sequence on its own pages -- as ONE launch with a
 // batch dimension when the lengths are equal, as nb launches otherwise.  Every kernel is batch-invariant, so each sequence's
 // result is bit-identical to a prefill on its own.
@@ -271,7 +271,7 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
   const gvl_config& f = ctx->cfg;
   const int Hd = f.hidden, H = f.heads, KV = f.kv_heads, Dr = ctx->l_Dr, D = ctx->l_D, I = f.inter;
   const int qkvw = (H + 2 * KV) * Dr;
-  if (nb < 1 || nb > GVL_MAX_PREFILL_BATCH || nb == 3) return fail(ctx, GVL_ERR_ARG, "llm_prefill: batch must be 1, 2 or 4 sequences");
+  if (nb < 1 || nb > GVL_MAX_PREFILL_BATCH) return fail(ctx, GVL_ERR_ARG, "llm_prefill: batch must be 1 .. 8 sequences");
   if (pos0 != 0 && (nb != 1 || (pos0 & 63) || loss)) return fail(ctx, GVL_ERR_ARG, "llm_prefill: extend takes one sequence whose cached prefix is whole pages");
   int off[GVL_MAX_PREFILL_BATCH + 1]; off[0] = 0;
   bool uniform = true;
@@ -343,9 +343,13 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
     for (int b = 0; b < nb; ++b) HIPCHK(ctx, hipMemcpyAsync(h + (size_t)b * Hd, x + (size_t)(off[b + 1] - 1) * Hd, (size_t)Hd * 2, hipMemcpyDeviceToDevice, st));
     last = h; last_stride = Hd;
   }
-  { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = ctx->l_headw; g.N = f.vocab; g.K = Hd; g.x = last; g.norm_w = ctx->l_norm; g.eps = f.rms_eps;
-    g.batch = nb; g.x_stride = last_stride; g.out_stride = f.vocab;
-    g.bias = ctx->l_headb; g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, gvl_launch_gemv(g, st)); }
+  for (int b0 = 0; b0 < nb;) {             // the GEMV holds 1, 2 or 4 vectors in LDS: chunks of 4 / 2 / 1 last rows (row results do not depend on the chunking)
+    const int nbc = nb - b0 >= 4 ? 4 : (nb - b0 >= 2 ? 2 : 1);
+    GemvArgs g; memset(&g, 0, sizeof(g)); g.W = ctx->l_headw; g.N = f.vocab; g.K = Hd; g.x = last + (size_t)b0 * last_stride; g.norm_w = ctx->l_norm; g.eps = f.rms_eps;
+    g.batch = nbc; g.x_stride = last_stride; g.out_stride = f.vocab;
+    g.bias = ctx->l_headb; g.out_f32 = ctx->d_logits + (size_t)b0 * f.vocab; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, gvl_launch_gemv(g, st));
+    b0 += nbc;
+  }
   for (int b = 0; b < nb; ++b) RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sqs[b]->d_ngen, 0, st));
   { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = f.vocab; am.batch = nb;
     for (int b = 0; b < nb; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.ngen_ptrs[b] = sqs[b]->d_ngen; }   // first generated token
@@ -1020,15 +1024,15 @@ int gvl_prefill_varlen(gvl_ctx* ctx, const int* seq_ids, int n_seqs, const uint1
     for (int j = 0; j < i; ++j) if (seq_ids[j] == id) return fail(ctx, GVL_ERR_ARG, "gvl_prefill_varlen: duplicate seq");
   }
   hipStream_t st = (hipStream_t)stream;
-  // groups of 4, 2, 1 sequences in call order -- as many as the prefill workspace (cfg.max_prefill rows in total) allows
+  // groups of up to 8 sequences in call order -- as many as the prefill workspace (cfg.max_prefill rows in total) allows
   int i = 0;
   while (i < n_seqs) {
     const int left = n_seqs - i;
-    int B = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+    int B = left >= ctx->dbg.prefill_group ? ctx->dbg.prefill_group : left;
     for (;;) {
       long rows = 0; for (int b = 0; b < B; ++b) rows += seq_lens[i + b];
       if (B == 1 || rows <= ctx->cfg.max_prefill) break;
-      B >>= 1;
+      --B;
     }
     Seq* sqs[GVL_MAX_PREFILL_BATCH]; const bf16_t* es[GVL_MAX_PREFILL_BATCH];
     for (int b = 0; b < B; ++b) { sqs[b] = &ctx->seqs[seq_ids[i + b]]; es[b] = embeds[i + b]; }
@@ -1137,6 +1141,7 @@ int gvl_debug_set(gvl_ctx* ctx, const char* key, int value) {
   if (k == "decode_attn_cpb") { if (value < 0 || value > 16) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: decode_attn_cpb must be 0 (default) .. 16"); ctx->dbg.decode_attn_cpb = value; }
   else if (k == "decode_attn_hpb") { if (value < 0) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: decode_attn_hpb must be >= 0"); ctx->dbg.decode_attn_hpb = value; }
   else if (k == "decode_graph") ctx->dbg.decode_graph = value != 0;
+  else if (k == "prefill_group") { if (value < 1 || value > GVL_MAX_PREFILL_BATCH) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: prefill_group must be 1 .. 8"); ctx->dbg.prefill_group = value; }
   else if (k == "vision_in_place") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: vision_in_place must be 0, 1 or 2"); ctx->dbg.vision_in_place = value; }
   else return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: unknown key " + k);
   return 0;

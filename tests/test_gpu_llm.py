@@ -211,18 +211,18 @@ def test_prefill_batch_is_bit_identical_to_single(which):
     meta, g = load_golden(which)
     c = meta["cfg"]
     if which == "phi3_tiny":
-        geo = _phi_geo(c)
+        geo = _phi_geo(c, kv_pages=64, max_prefill=1024)
         W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
     else:
         geo = tiny_geo(llm="llama3", hidden=c["hidden"], inter=c["inter"], layers=c["layers"], heads=c["heads"], kv_heads=c["kv_heads"], vocab=c["vocab"],
-                       rope_theta=c["rope_theta"], rope_orig_max_pos=0)
+                       rope_theta=c["rope_theta"], rope_orig_max_pos=0, kv_pages=64, max_prefill=1024)
         W = synth.llm_weights("llama", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
     eng = llm_engine(geo, W)
     new = 10
     for S in (7, 64, 61):                                     # below / exactly / just under one 64-token page
-        xs = [synth.det_tensor(f"pbatch.{which}.{S}.{i}", (S, c["hidden"]), 0.5).to(DEV).to(bf) for i in range(4)]
+        xs = [synth.det_tensor(f"pbatch.{which}.{S}.{i}", (S, c["hidden"]), 0.5).to(DEV).to(bf) for i in range(8)]
         single = [eng.generate_ids(x, new, None) for x in xs]
-        for n in (2, 3, 4):
+        for n in (2, 3, 4, 5, 7, 8):                           # one pass of the decoder GEMMs for up to 8 sequences; lm_head in chunks of 4 / 2 / 1 rows
             seqs = [eng.seq_alloc(S + new) for _ in range(n)]
             eng.prefill_batch(seqs, xs[:n])
             got = eng.decode_greedy_batch(seqs, new, None)
@@ -240,18 +240,18 @@ def test_prefill_varlen_is_bit_identical_to_single(which):
     meta, g = load_golden(which)
     c = meta["cfg"]
     if which == "phi3_tiny":
-        geo = _phi_geo(c)
+        geo = _phi_geo(c, kv_pages=64, max_prefill=1024)
         W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
     else:
         geo = tiny_geo(llm="llama3", hidden=c["hidden"], inter=c["inter"], layers=c["layers"], heads=c["heads"], kv_heads=c["kv_heads"], vocab=c["vocab"],
-                       rope_theta=c["rope_theta"], rope_orig_max_pos=0)
+                       rope_theta=c["rope_theta"], rope_orig_max_pos=0, kv_pages=64, max_prefill=1024)
         W = synth.llm_weights("llama", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
     eng = llm_engine(geo, W)
     new = 10
-    for lens in ((7, 64, 61, 65), (1, 130, 2, 129), (33, 33, 40, 33)):   # page boundaries, single-token prompts, a near-uniform batch
+    for lens in ((7, 64, 61, 65, 3, 128, 66, 63), (1, 130, 2, 129, 1, 64, 5, 200), (33, 33, 40, 33, 33, 33, 33, 34)):   # page boundaries, single-token prompts, a near-uniform batch
         xs = [synth.det_tensor(f"pvar.{which}.{S}.{i}", (S, c["hidden"]), 0.5).to(DEV).to(bf) for i, S in enumerate(lens)]
         single = [eng.generate_ids(x, new, None) for x in xs]
-        for n in (2, 3, 4):
+        for n in (2, 3, 4, 5, 6, 8):
             seqs = [eng.seq_alloc(lens[i] + new) for i in range(n)]
             eng.prefill_batch(seqs, xs[:n])
             got = eng.decode_greedy_batch(seqs, new, None)

@@ -13,6 +13,8 @@ SHAPES = [("clip.qkv", 27696, 3072, 1024, "bias"), ("clip.out", 27696, 1024, 102
           ("iv2.qkv", 24588, 4224, 1408, "plain"), ("iv2.proj", 24588, 1408, 1408, "bias_gamma_resid"), ("iv2.fc1", 24588, 6144, 1408, "bias_gelu"), ("iv2.fc2", 24588, 1408, 6144, "bias_gamma_resid"),
           ("phi.qkv", 3519, 9216, 3072, "plain"), ("phi.o", 3519, 3072, 3072, "resid"), ("phi.gu", 3519, 16384, 3072, "silu"), ("phi.down", 3519, 3072, 8192, "resid"),
           ("sq8192", 8192, 8192, 8192, "plain")]
+if os.environ.get("GVL_LAB_PHI_M"):       # the decoder GEMMs at other prefill-group sizes: GVL_LAB_PHI_M=1790,3580,7160,14320
+    SHAPES = [(f"{n}@{m}", m, N, K, mode) for m in map(int, os.environ["GVL_LAB_PHI_M"].split(",")) for n, _, N, K, mode in SHAPES if n.startswith("phi.")]
 VARS = []
 for item in (sys.argv[1] if len(sys.argv) > 1 else "base=").split(";"):
     name, envs = item.split("=", 1)

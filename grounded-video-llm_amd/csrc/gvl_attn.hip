@@ -99,7 +99,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   // (With grouped-query attention the unit is the (batch, KV head) GROUP: its H/KV query heads share the pages too.)
   const int nq = (a.S + NWAVES * 32 - 1) / (NWAVES * 32), rep = a.H / a.KV;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int qb = j % nq, t_ = j / nq, member = t_ % rep, grp = (t_ / rep) * 8 + xcd;
+  const int qb_ = j % nq, t_ = j / nq, member = t_ % rep, grp = (t_ / rep) * 8 + xcd;
+  const int qb = a.causal ? nq - 1 - qb_ : qb_;     // causal: the late query blocks see the most keys -- dispatch them FIRST, the short ones fill the tail
   if (grp >= a.KV * a.B) return;                     // grid is padded to a multiple of 8 groups; uniform per block
   const int b = grp / a.KV, head = (grp - b * a.KV) * rep + member;
   const int hkv = head / (a.H / a.KV);
@@ -459,6 +460,7 @@ int gvl_launch_attention(const AttnArgs& a_in, hipStream_t st) {
   if ((!a.q_rs && (a.Krows != nullptr) != (a.Qrows != nullptr)) || (a.Krows && (!a.Vrows || a.D != 64 || a.Dout != a.D || a.k_ld < a.KV * a.D || a.q_ld < a.H * a.D || ((a.k_ld | a.q_ld) & 7) ||
                                                               (((uintptr_t)a.Krows | (uintptr_t)a.Qrows) & 15) || (size_t)64 * a.k_ld * 2 >= 0xffffffffull))) return -1;
   if (a.B <= 0 || a.S <= 0 || a.S > 256 * 64 || a.Sk > 256 * 64 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 7) || ((uintptr_t)a.O & 15)) return -1;   // 16-byte O stores
+  const int ring = a.ring == 3 && !a.Vrows ? 3 : 2;
   switch (a.D) {
     // ring depth 2: 48 KB (D=96) -> 3 blocks / CU at 151 VGPRs (measured 427 us vs 461 us for the 73 KB depth-3 ring, which
     // caps residency at 2 blocks / CU; DMA latency is not the limiter -- PMC shows the kernel is VALU-issue-bound)
@@ -471,9 +473,10 @@ int gvl_launch_attention(const AttnArgs& a_in, hipStream_t st) {
       const bool ones = a.ones_row && !no_ones && a.Dout < 96 && lr >= 0 && (lr & 7) < 4 && !a.causal;
       if (a.Vrows && a.q_rs) { if (a.Dout != 88 || !a.k_ones) return -1; return ones ? launch_attn<96, 4, 2, 1, 3>(a, st) : launch_attn<96, 4, 2, 0, 3>(a, st); }
       if (a.Vrows) return ones ? launch_attn<96, 4, 2, 1, 1>(a, st) : launch_attn<96, 4, 2, 0, 1>(a, st);
+      if (!ones && ring == 3) return launch_attn<96, 4, 3>(a, st);
       return ones ? launch_attn<96, 4, 2, 1>(a, st) : launch_attn<96, 4, 2>(a, st);
     }
-    case 128: return a.Vrows ? -1 : launch_attn<128, 4, 2>(a, st);     // row-major V is the vision towers' mode (head dims 64 and 88)
+    case 128: return a.Vrows ? -1 : (ring == 3 ? launch_attn<128, 4, 3>(a, st) : launch_attn<128, 4, 2>(a, st));     // row-major V is the vision towers' mode (head dims 64 and 88)
     default: return -1;
   }
 }

@@ -311,6 +311,7 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
       { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Qu; a.Kt = Kt; a.Vt = Vt; a.O = att + (size_t)off[u] * H * Dr; a.block_table = tbl; a.max_pages = tstride;
         a.B = B; a.H = H; a.KV = KV; a.S = S; a.D = D; a.Dout = Dr; a.scale = 1.0f / sqrtf((float)Dr); a.causal = 1;
         if (pos0) { a.Sk = pos0 + S; a.qpos0 = pos0; }
+        a.ring = ctx->dbg.attn_ring;
         RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
     }
     { GemmArgs g = gemm(att, H * Dr, w.ow, x, Hd, M, Hd, H * Dr); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
@@ -1141,6 +1142,7 @@ int gvl_debug_set(gvl_ctx* ctx, const char* key, int value) {
   if (k == "decode_attn_cpb") { if (value < 0 || value > 16) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: decode_attn_cpb must be 0 (default) .. 16"); ctx->dbg.decode_attn_cpb = value; }
   else if (k == "decode_attn_hpb") { if (value < 0) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: decode_attn_hpb must be >= 0"); ctx->dbg.decode_attn_hpb = value; }
   else if (k == "decode_graph") ctx->dbg.decode_graph = value != 0;
+  else if (k == "attn_ring") { if (value != 0 && value != 2 && value != 3) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: attn_ring must be 0, 2 or 3"); ctx->dbg.attn_ring = value; }
   else if (k == "prefill_group") { if (value < 1 || value > GVL_MAX_PREFILL_BATCH) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: prefill_group must be 1 .. 8"); ctx->dbg.prefill_group = value; }
   else if (k == "vision_in_place") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: vision_in_place must be 0, 1 or 2"); ctx->dbg.vision_in_place = value; }
   else return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: unknown key " + k);
@@ -1239,7 +1241,7 @@ int gvl_op_attention(gvl_ctx* ctx, const uint16_t* q, const uint16_t* k, const u
   const bool v_rows = ctx->dbg.vision_in_place && !causal && D != 128, qk_rows = ctx->dbg.vision_in_place == 1 && v_rows && D == Dr && D == 64;
   if (!qk_rows) { QkvPostArgs p; memset(&p, 0, sizeof(p)); p.qkv = q; p.ld = ld; p.Q = Q; p.Kt = Kt; p.Vt = v_rows ? nullptr : Vt; p.B = B; p.S = S; p.H = H; p.KV = KV; p.Dr = Dr; p.D = D; p.mode = 0;
     RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(p, st)); }
-  { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; a.O = out; a.B = B; a.H = H; a.KV = KV; a.S = S; a.D = D; a.Dout = Dr; a.scale = scale; a.causal = causal;
+  { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; a.O = out; a.B = B; a.H = H; a.KV = KV; a.S = S; a.D = D; a.Dout = Dr; a.scale = scale; a.causal = causal; a.ring = ctx->dbg.attn_ring;
     if (v_rows) { a.Vrows = v; a.v_ld = ld; }
     if (qk_rows) { a.Qrows = q; a.Krows = k; a.q_ld = a.k_ld = ld; }
     RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }

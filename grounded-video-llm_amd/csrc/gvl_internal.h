@@ -25,8 +25,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 constexpr int GVL_MAX_DECODE_BATCH = 16;  // sequences decoded together: the weight stream is read ONCE for all of them;
                                           // = the 16 columns of the MFMA B operand of the skinny decode GEMM (gvl_decode.hip)
 constexpr int GVL_MAX_VALU_BATCH = 4;     // the round-1 VALU GEMV (fallback for K % 256 != 0 geometries) holds B vectors in LDS: 1, 2 or 4
-constexpr int GVL_MAX_PREFILL_BATCH = 8;  // sequences whose rows share one pass of the prefill GEMMs (8 x ~1.8 k rows: the 12-tile-wide o / down
-                                          // projections fill 2.6 rounds of the 256 CUs instead of 1.3 -- measured -4.7 % of the decoder GEMM time against groups of 4)
+constexpr int GVL_MAX_PREFILL_BATCH = 8;  // most sequences whose rows share one pass of the prefill GEMMs (gvl_debug_set prefill_group picks 1 .. 8; default 4)
 
 // ---- device helpers ---------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;

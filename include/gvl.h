@@ -235,7 +235,9 @@ int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launche
  *   "decode_attn_cpb"  consecutive context splits one decode-attention block works through (0 = launcher's choice, 1..16)
  *   "decode_attn_hpb"  query heads of a KV head served by one block of the grouped-query decode kernel (0 = launcher's choice)
  *   "decode_graph"     1 (default): a decode group's step is captured once and replayed as a hipGraph for the following tokens; 0: eager
- *   "prefill_group"    sequences whose rows share one pass of the prefill GEMMs in gvl_prefill_varlen / _batch (default 8 = the maximum)
+ *   "prefill_group"    sequences whose rows share one pass of the prefill GEMMs in gvl_prefill_varlen / _batch (1 .. 8, default 4: at the bench's 3.5 k-row prompts
+ *                      8 measured neutral on clips/s and 0.7 % slower on the GEMM family -- 0.9 GB of activations per projection fall out of the
+ *                      Infinity Cache; shorter prompts gain up to 4.7 % from 8, profiles/r03_gemm_prefill_group.txt)
  *   "vision_in_place"  1 (default): non-causal attention (vision towers, gvl_op_attention) reads V -- and Q, K when the head dim needs no padding
  *                      or transform; with InternVideo2's q RMSNorm applied in the kernel prologue -- straight from the fused-qkv matrix;
  *                      2: V only; 0: the round-2 path through Q / K pages and a V^T transpose pass

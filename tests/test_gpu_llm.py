@@ -218,6 +218,7 @@ def test_prefill_batch_is_bit_identical_to_single(which):
                        rope_theta=c["rope_theta"], rope_orig_max_pos=0, kv_pages=64, max_prefill=1024)
         W = synth.llm_weights("llama", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
     eng = llm_engine(geo, W)
+    eng.debug_set("prefill_group", 8)
     new = 10
     for S in (7, 64, 61):                                     # below / exactly / just under one 64-token page
         xs = [synth.det_tensor(f"pbatch.{which}.{S}.{i}", (S, c["hidden"]), 0.5).to(DEV).to(bf) for i in range(8)]
@@ -247,6 +248,7 @@ def test_prefill_varlen_is_bit_identical_to_single(which):
                        rope_theta=c["rope_theta"], rope_orig_max_pos=0, kv_pages=64, max_prefill=1024)
         W = synth.llm_weights("llama", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
     eng = llm_engine(geo, W)
+    eng.debug_set("prefill_group", 8)
     new = 10
     for lens in ((7, 64, 61, 65, 3, 128, 66, 63), (1, 130, 2, 129, 1, 64, 5, 200), (33, 33, 40, 33, 33, 33, 33, 34)):   # page boundaries, single-token prompts, a near-uniform batch
         xs = [synth.det_tensor(f"pvar.{which}.{S}.{i}", (S, c["hidden"]), 0.5).to(DEV).to(bf) for i, S in enumerate(lens)]

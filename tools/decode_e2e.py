@@ -28,6 +28,8 @@ torch.cuda.empty_cache()
 eng.finalize()
 graph = int(os.environ.get("GVL_E2E_GRAPH", "1"))     # 1 (library default): a group's decode step is captured once and replayed
 eng.debug_set("decode_graph", graph)
+for kv in [x for x in os.environ.get("GVL_LAB_SET", "").split(",") if x]:      # gvl_debug_set KEY=INT pairs (A/B of result-neutral launch parameters)
+    k_, v_ = kv.split("="); eng.debug_set(k_, int(v_))
 print("kv pool", eng.kv_info(), "graph", graph, "fp8", geo.decode_fp8, flush=True)
 g = torch.Generator(device=dev); g.manual_seed(1)
 new = 33

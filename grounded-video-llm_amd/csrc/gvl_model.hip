@@ -1136,6 +1136,27 @@ int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, voi
   return 0;
 }
 
+int gvl_decode_step_logits_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, const int32_t* toks, float* logits, void* stream) {
+  REQUIRE_READY(ctx->has_llm, "gvl_decode_step_logits_batch");
+  if (!seq_ids || !toks || n_seqs < 1 || n_seqs > decode_group_size(ctx, GVL_MAX_DECODE_BATCH) || (!ctx->decode_mfma && n_seqs == 3))
+    return fail(ctx, GVL_ERR_ARG, "gvl_decode_step_logits_batch: 1 .. 16 sequences (VALU fallback geometries: 1, 2 or 4)");
+  Seq* sqs[GVL_MAX_DECODE_BATCH];
+  for (int i = 0; i < n_seqs; ++i) {
+    const int id = seq_ids[i];
+    if (id < 0 || id >= (int)ctx->seqs.size() || !ctx->seqs[id].used) return fail(ctx, GVL_ERR_ARG, "gvl_decode_step_logits_batch: bad seq");
+    Seq& sq = ctx->seqs[id];
+    if (toks[i] < 0 || toks[i] >= ctx->cfg.vocab || sq.pos >= sq.max_tokens || sq.pos == 0) return fail(ctx, GVL_ERR_ARG, "gvl_decode_step_logits_batch: bad token / sequence full / not prefilled");
+    for (int j = 0; j < i; ++j) if (seq_ids[j] == id) return fail(ctx, GVL_ERR_ARG, "gvl_decode_step_logits_batch: duplicate seq");
+    sqs[i] = &sq;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < n_seqs; ++i) RUN(GVL_PROF_OTHER, 0, gvl_launch_set_int(sqs[i]->d_tok, toks[i], st));
+  const int rc = decode_step(ctx, sqs, n_seqs, st);       // ONE weight stream for all of them; row i depends on sequence i only (batch-invariant kernels)
+  if (rc) return rc;
+  if (logits) HIPCHK(ctx, hipMemcpyAsync(logits, ctx->d_logits, (size_t)n_seqs * ctx->cfg.vocab * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
 int gvl_debug_set(gvl_ctx* ctx, const char* key, int value) {
   if (!ctx || !key) return GVL_ERR_ARG;
   const std::string k = key;

@@ -367,6 +367,14 @@ class Engine:
         self._chk(self.lib.gvl_decode_step_logits(self.ctx, seq, int(tok), _ptr(logits), self.stream), "gvl_decode_step_logits")
         return logits
 
+    def decode_step_logits_batch(self, seqs: Sequence[int], toks: Sequence[int]) -> torch.Tensor:
+        """One teacher-forced decode step for several sequences together (one stream of the weights): [n, vocab] fp32 logits."""
+        n = len(seqs)
+        logits = torch.empty((n, self.geo.vocab), dtype=torch.float32, device=self.device)
+        ids = (C.c_int * n)(*[int(s) for s in seqs]); tk = (C.c_int32 * n)(*[int(t) for t in toks])
+        self._chk(self.lib.gvl_decode_step_logits_batch(self.ctx, ids, n, tk, _ptr(logits), self.stream), "gvl_decode_step_logits_batch")
+        return logits
+
     def generate_ids(self, embeds: torch.Tensor, max_new_tokens: int, eos_id: Optional[int]) -> List[int]:
         """language_model.generate(inputs_embeds=..., greedy): returns only the NEW ids (eos included)."""
         S = embeds.shape[0]

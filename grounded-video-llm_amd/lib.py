@@ -69,6 +69,7 @@ _SIGS = {
     "gvl_prefill_varlen": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p]),
     "gvl_decode_greedy_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.c_void_p]),
     "gvl_decode_step_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "gvl_decode_step_logits_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "gvl_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "gvl_prof_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "gvl_op_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -278,11 +278,13 @@ class LLAVA_NEXT_VIDEO:
     def beam_generate_ids(self, row: List[int], vis: torch.Tensor, num_beams: int, max_new: int, length_penalty: float = 1.0, early_stopping=False) -> List[int]:
         """generate(num_beams = k, do_sample = False): HF beam search (beam.py restates transformers 4.40.1's scorer) on the paged KV cache.  The k running
         beams are k sequences; HF's per-step cache reorder becomes gvl_seq_clone -- a beam that continues another one shares its whole KV pages by
-        reference and copies only the partial last page; the first child of a parent simply keeps the parent's sequence.  Every beam advances by ONE
-        teacher-forced decode step per token (gvl_decode_step_logits); log-softmax / top-2k of the step run on the device (torch), the bookkeeping on
+        reference and copies only the partial last page; the first child of a parent simply keeps the parent's sequence.  All beams advance by ONE
+        teacher-forced batched decode step per token (gvl_decode_step_logits_batch: one stream of the weights for the k beams); log-softmax / top-2k of the step run on the device (torch), the bookkeeping on
         the host."""
         from . import beam as B
         eng = self.engine
+        g_ = self.geo                                    # the skinny-MFMA decode path (groups of any size up to 16) needs every K to be a multiple of 256
+        self._decode_mfma = all(k % 256 == 0 for k in (g_.hidden, g_.inter)) and g_.hidden <= 4096 and (g_.hidden // g_.heads) % 2 == 0   # csrc/gvl_model.hip: ctx->decode_mfma
         eos = getattr(self.tokenizer, "eos_token_id", None)
         emb = eng.splice(row, vis)
         cap = min(emb.shape[0] + max_new + 1, self.geo.max_seq)
@@ -303,6 +305,8 @@ class LLAVA_NEXT_VIDEO:
                     if p_ not in keep:
                         eng.seq_free(s_)
                 beams[:] = new
+                if len(beams) <= 16 and (self._decode_mfma or len(beams) in (1, 2, 4)):
+                    return eng.decode_step_logits_batch(beams, toks)        # the k beams share ONE stream of the weights
                 return torch.stack([eng.decode_step_logits(s_, t) for s_, t in zip(beams, toks)])
 
             return B.beam_search(step, first, num_beams, max_new, eos, length_penalty, early_stopping)

@@ -153,7 +153,7 @@ int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t
  * that repeats the current seed while sequences are live continues the numbering instead, so newcomers never share a stream with
  * a running sequence; callers that make several generate() calls per request pass a different seed per call.)
  * torch.multinomial's random stream is not reproduced (parity = same kept set + same distribution).  Beam search (num_beams > 1, do_sample = 0) is host
- * bookkeeping over gvl_seq_clone + gvl_decode_step_logits (grounded_video_llm_amd/beam.py); beam-sample is not built. */
+ * bookkeeping over gvl_seq_clone + gvl_decode_step_logits_batch (grounded_video_llm_amd/beam.py); beam-sample is not built. */
 int gvl_set_sampling(gvl_ctx* ctx, int do_sample, float temperature, int top_k, float top_p, uint64_t seed);
 /* Prefill of n_seqs sequences together, seq_lens[i] tokens each (ragged: prompts differ in length; the reference left-pads and
  * masks, llava_next_video.py:622-647 -- here the rows are packed back to back, no padding).  Groups of 4 / 2 / 1 sequences whose
@@ -183,6 +183,9 @@ int gvl_decode_steps(gvl_ctx* ctx, const int* seq_ids, int n_seqs, int n_steps, 
 int gvl_seq_read(gvl_ctx* ctx, int seq_id, int first, int32_t* out_ids_host, int cap, int* n_gen, void* stream);
 /* teacher-forced single step (parity tests): appends token `tok`, returns logits f32 [vocab]. */
 int gvl_decode_step_logits(gvl_ctx* ctx, int seq_id, int tok, float* logits, void* stream);
+/* The same for up to 16 sequences in ONE step (one stream of the weights): sequence i takes toks[i]; logits (may be null) receives
+ * [n_seqs][vocab] fp32.  Row i is bit-identical to gvl_decode_step_logits on sequence i alone.  Beam search advances its k beams with it. */
+int gvl_decode_step_logits_batch(gvl_ctx* ctx, const int* seq_ids, int n_seqs, const int32_t* toks, float* logits, void* stream);
 
 /* ---- multi-GPU exchange (SURVEY.md §8 e) -------------------------------------------------------------------------------------
  * The reference's inference is single-GPU (inference.py:17); sharding the frame batch over the GPUs of a node is this build's

@@ -448,14 +448,26 @@ def test_decode_groups_up_to_16_are_bit_identical_to_single_at_full_width():
         lg = eng.decode_step_logits(s, 7).clone()
         single.append((ids, lg))
         eng.seq_free(s)
-    seqs = [eng.seq_alloc(e.shape[0] + new + 1) for e in embs]
+    seqs = [eng.seq_alloc(e.shape[0] + new + 4) for e in embs]
     for s, e in zip(seqs, embs):
         eng.prefill(s, e)
     got = eng.decode_greedy_batch(seqs, new, None)
     assert got == [ids for ids, _ in single], "ids of the 11-sequence group differ from the one-at-a-time runs"
     assert len({tuple(ids) for ids in got}) > 1
-    for s, (_, lg) in zip(seqs, single):
-        assert torch.equal(eng.decode_step_logits(s, 7), lg)
+    # the batched teacher-forced step (beam search's per-token step): ONE weight stream, row i == the single-sequence call bit for bit
+    toks = [7] * len(seqs)
+    lgb = eng.decode_step_logits_batch(seqs, toks)
+    for i, (_, lg) in enumerate(single):
+        assert torch.equal(lgb[i], lg), i
+    toks2 = [(3 * i + 1) % c["vocab"] for i in range(len(seqs))]          # a second step with different tokens per sequence, against per-sequence calls on clones
+    clones = [eng.seq_clone(s, lens[i] + new + 4) for i, s in enumerate(seqs)]
+    lgb2 = eng.decode_step_logits_batch(seqs, toks2)
+    for i, cl in enumerate(clones):
+        assert torch.equal(eng.decode_step_logits(cl, toks2[i]), lgb2[i]), i
+        eng.seq_free(cl)
+    with pytest.raises(Exception):
+        eng.decode_step_logits_batch([seqs[0], seqs[0]], [1, 2])           # duplicate sequence
+    for s in seqs:
         eng.seq_free(s)
     eng.close()
 

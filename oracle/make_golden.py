@@ -802,15 +802,25 @@ def g_free(ns, tag):
     phi = tag == "c1"
     hid = 3072 if phi else 4096
     wseed = "c0" if phi else "c3"
+    n_segs = 32 if tag == "c4" else 12                    # c4: 256 frames, S = 6276 (the long-context config)
     sk = Skel()
     sk.llm, sk.dtype = ("phi3.5" if phi else "llama3"), torch.float32
     c = copy.deepcopy(L.CLIP_VIT_LARGE_PATCH14_336_CONFIG)
     c._attn_implementation = "eager"
-    sp = synth.exact_tensor(tag + ".sp", (1, 12, 3, 336, 336))
-    tp = synth.exact_tensor(tag + ".tp", (1, 96, 3, 224, 224))
+    sp = synth.exact_tensor(tag + ".sp", (1, n_segs, 3, 336, 336))
+    tp = synth.exact_tensor(tag + ".tp", (1, 8 * n_segs, 3, 224, 224))
     Wp = synth.projector_weights("phi3.5" if phi else "llama3", hid, 1024, 1408, seed=wseed + ".proj", exact=True)
-    cache = _feats_cache_name(tag, 12, (wseed + ".clip", wseed + ".iv2", wseed + ".proj"), sp, tp)
+    cache = _feats_cache_name(tag, n_segs, (wseed + ".clip", wseed + ".iv2", wseed + ".proj"), sp, tp)
     t0 = time.time()
+    legacy = os.environ.get("GVL_FEATS_FROM")          # a feats file from an earlier run of the SAME generator: accepted only if it reproduces the committed golden's sample bit for bit
+    if not os.path.exists(cache) and legacy and os.path.exists(legacy):
+        import numpy as np
+        cand = torch.load(legacy)
+        gz = np.load(os.path.join(OUT, tag + "_full.npz"))
+        gold, fs = gz["feats"], json.loads(str(gz["meta"]))["stride"]["feats"]
+        if list(cand.shape) == [1, n_segs * (285 if phi else 193), hid] and np.array_equal(cand[:, ::fs[0], ::fs[1]].numpy(), gold):
+            torch.save(cand, cache)
+            print(f"[{tag} free] {legacy} reproduces {tag}_full.npz's feats sample bit for bit: reused", flush=True)
     if os.path.exists(cache):
         feats = torch.load(cache)
     else:
@@ -861,4 +871,4 @@ if __name__ == "__main__":
     for w in which:
         {"int": g_int, "clip": g_clip, "iv2": g_iv2, "phi3": g_phi3, "llama": g_llama, "glue": g_glue, "pre": g_pre, "train": g_train, "c0": g_c0,
          "llama_full": g_llama_full, "c3": g_c3, "c4": g_c4, "c1": g_c1,
-         "free_c1": lambda n: g_free(n, "c1"), "free_c3": lambda n: g_free(n, "c3")}[w](ns)
+         "free_c1": lambda n: g_free(n, "c1"), "free_c3": lambda n: g_free(n, "c3"), "free_c4": lambda n: g_free(n, "c4")}[w](ns)

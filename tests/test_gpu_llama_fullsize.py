@@ -176,26 +176,30 @@ def test_c4_full_depth_long_context_vs_reference_golden(llama):
     _full_depth_vs_reference_golden(llama, "c4_full")
 
 
-def test_c3_free_running_greedy_vs_oracle_continuation(llama):
-    """The same for BASELINE configs[3] (Llama-3-8B, 96 frames): tests/golden/c3_free.json = fp32 reference prefix + the oracle's KV-cached greedy."""
+@pytest.mark.parametrize("tag,n_segs", [("c3", 12), ("c4", 32)])
+def test_free_running_greedy_vs_oracle_continuation(llama, tag, n_segs):
+    """Free-running greedy ids for BASELINE configs[3] (Llama-3-8B, 96 frames, S = 2416) and configs[4] (256 frames, S = 6276 long-context
+    prefill): tests/golden/<tag>_free.json = the reference's own fp32 prefix (encode_images + prepare_multimodal_inputs) + the oracle's
+    KV-cached greedy continuation (pinned against the reference's O(n^2) greedy at C0 depth by tests/test_oracle_c0_slow.py).  Ids must be
+    equal up to the first step whose top-1 / top-2 margin is inside two bf16 evaluations' distance."""
     import json, os
     from conftest import GOLDEN
     eng, geo = llama
-    path = os.path.join(GOLDEN, "c3_free.json")
+    path = os.path.join(GOLDEN, tag + "_free.json")
     if not os.path.exists(path):
-        pytest.skip("c3_free.json not generated (oracle/make_golden.py free_c3: ~25 min and 40 GB on the build container)")
+        pytest.skip(f"{tag}_free.json not generated (oracle/make_golden.py free_{tag}: 10-25 min and 40 GB on the build container)")
     fr = json.load(open(path))
     sd = fr["seeds"]
-    sp = synth.exact_tensor(sd["sp"], (1, 12, 3, 336, 336), device=DEV)[0]
-    tp = synth.exact_tensor(sd["tp"], (1, 96, 3, 224, 224), device=DEV)
-    tseg = tp.reshape(1, 12, 8, 3, 224, 224).permute(0, 1, 3, 2, 4, 5).flatten(0, 1).contiguous()
+    sp = synth.exact_tensor(sd["sp"], (1, n_segs, 3, 336, 336), device=DEV)[0]
+    tp = synth.exact_tensor(sd["tp"], (1, 8 * n_segs, 3, 224, 224), device=DEV)
+    tseg = tp.reshape(1, n_segs, 8, 3, 224, 224).permute(0, 1, 3, 2, 4, 5).flatten(0, 1).contiguous()
     ms = geo.max_segs
-    vis = torch.cat([eng.encode_segments(sp[i:i + ms], tseg[i:i + ms]) for i in range(0, 12, ms)], 0)
+    vis = torch.cat([eng.encode_segments(sp[i:i + ms], tseg[i:i + ms]) for i in range(0, n_segs, ms)], 0)
     emb = eng.splice(fr["ids"], vis)
     assert emb.shape[0] == fr["S"]
     got = eng.generate_ids(emb, len(fr["free_ids"]), None)
     rel = [m / fr["scale"] for m in fr["margins"]]
     n_same = next((i for i, (a, b) in enumerate(zip(got, fr["free_ids"])) if a != b), len(got))
-    print(f"[parity] C3 free-running greedy: {n_same} of {len(got)} ids equal the fp32 continuation; ids {got} vs {fr['free_ids']}; margins/scale {[round(r, 4) for r in rel]}")
+    print(f"[parity] {tag.upper()} free-running greedy: {n_same} of {len(got)} ids equal the fp32 continuation; ids {got} vs {fr['free_ids']}; margins/scale {[round(r, 4) for r in rel]}")
     if n_same < len(got):
         assert rel[n_same] < 2 * 2.7e-2, f"greedy id differs at step {n_same} although the margin is {rel[n_same]:.3e} of the logit scale"

@@ -370,3 +370,42 @@ def test_gelu_epilogue_is_correctly_rounded_on_every_bf16_input(eng, cfg):
     print(f"[parity] erf-GELU epilogue cfg {cfg}: {n_bad} of {int(finite.sum())} bf16 inputs differ from the correctly rounded double-precision value" +
           (f" (by at most {int(ulp.max())} bf16 ulp: x = {A[rows, 0].float().tolist()[:8]})" if n_bad else ""))
     assert n_bad <= 8 and (n_bad == 0 or int(ulp.max()) <= 1), f"cfg {cfg}: {n_bad} inputs differ, max {int(ulp.max()) if n_bad else 0} ulp"
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "silu_mul"])
+def test_sigmoid_epilogues_on_every_bf16_input(eng, act):
+    """CLIP's QuickGELU (x * sigmoid(1.702 x), transformers ACT2FN, modeling_clip.py:340-342) and the SwiGLU product of the decoders
+    (up * silu(gate), modeling_phi3.py:246-252 / modeling_llama.py:238) are epilogues of the GEMM kernels built on rcp(1 + exp(-x)) with the
+    hardware's fast exp / rcp.  ALL normal bf16 values go through them (accumulator = x exactly, as in the erf-GELU test) and must equal the
+    reference's bf16 op sequence -- every op evaluated in DOUBLE and rounded to bf16 where torch rounds -- up to one bf16 ulp on the few
+    inputs whose intermediate sits within the fast functions' ~1e-6 of a rounding boundary."""
+    bits = torch.arange(65536, dtype=torch.int32)
+    x = bits.to(torch.int16).view(bf)
+    xf = x.float()
+    ok = torch.isfinite(xf) & (((xf.abs() >= 2.0 ** -125) & (xf.abs() <= 2.0 ** 60)) | (xf == 0))
+    K = 1024
+    A = torch.zeros((65536, K), dtype=bf)
+    A[:, 0] = torch.where(ok, x, torch.zeros_like(x))
+    xd = A[:, 0].double()
+    rb = lambda t: t.float().to(bf).double()                             # round a double through fp32 to bf16 (the fp32 step is exact for these magnitudes' purposes)
+    if act == "quick_gelu":
+        N = 256
+        W = torch.zeros((N, K), dtype=bf); W[:, 0] = 1.0
+        got = eng.op_gemm(A.to(DEV), W.to(DEV), act=L.ACT_QUICK_GELU).cpu()
+        t1 = rb(torch.tensor(1.702, dtype=torch.float32).double() * xd)   # 1.702f * x in fp32, rounded to bf16
+        want = rb(xd * rb(torch.sigmoid(t1))).float().to(bf)
+    else:
+        N = 512                                                          # interleaved (gate_j, up_j) rows -> 256 outputs; gate = x, up = 1
+        A[:, 1] = 1.0
+        W = torch.zeros((N, K), dtype=bf); W[0::2, 0] = 1.0; W[1::2, 1] = 1.0
+        got = eng.op_gemm(A.to(DEV), W.to(DEV), act=L.ACT_SILU_MUL).cpu()
+        want = rb(xd * torch.sigmoid(xd)).float().to(bf)                 # F.silu on a bf16 tensor: one rounding; times up = 1
+    assert (got == got[:, :1]).all() or torch.equal(got.view(torch.int16), got[:, :1].view(torch.int16).expand_as(got)), "columns of one row disagree"
+    g0 = got[:, 0]
+    near = (g0.float() - want.float()).abs() <= 2.0 ** -100              # |x| huge negative: exp overflows to inf -> the kernel returns -0 / 0 like the reference
+    bad = ok & (g0.float() != want.float()) & ~near
+    n_bad = int(bad.sum())
+    ulp = (g0[bad].view(torch.int16).int() - want[bad].view(torch.int16).int()).abs()
+    print(f"[parity] {act} epilogue: {n_bad} of {int(ok.sum())} bf16 inputs differ from the double-precision op sequence" +
+          (f" (by at most {int(ulp.max())} bf16 ulp; first x = {A[bad, 0].float().tolist()[:6]})" if n_bad else ""))
+    assert n_bad <= 8 and (n_bad == 0 or int(ulp.max()) <= 1), f"{act}: {n_bad} inputs differ, max {int(ulp.max()) if n_bad else 0} ulp"

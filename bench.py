@@ -637,13 +637,6 @@ def main(argv=None, engine_factory=None):
         barrier("sharded clip")
     sharded_ms = 1e3 * (time.perf_counter() - ts) / 2
     prog.partial["single_clip_latency_ms_sharded"] = round(sharded_ms, 2)
-    if world > 1:                                        # libgvl's own communicator over all ranks: how many ranks RCCL itself reports, and its all-gather
-        prog.enter("gvl_comm_init / ncclCommCount / gvl_allgather_visual")
-        try:
-            ranks_seen, gvl_gather_ok = rccl_ranks_seen(eng, rank, world, dev, backend)
-        except Exception as e:                           # a diagnostic must not cost the measurement
-            print(f"bench: rank {rank}: libgvl communicator check failed: {e}", file=sys.stderr, flush=True)
-        prog.partial["n_ranks_seen_by_rccl"] = ranks_seen
     # ---- untimed extras: PCIe-inclusive rate, single-clip latency, decode-only rate, per-kernel-family profile, CPU baseline -----
     # The boundary takes DEVICE pixel tensors (`value` above); here every clip's 74 MB of f32 pixels is first copied from pinned
     # host memory on the vision stream, as a caller holding CPU-preprocessed frames would (inference.py:119-120 of the reference).
@@ -766,6 +759,31 @@ def main(argv=None, engine_factory=None):
     for k, p in prof1.items():
         stages[k + "_ms_per_clip_serial"] = round(p["ms"], 3)           # one clip alone
 
+    diag_stuck = False
+    if world > 1:
+        # libgvl's OWN communicator over all ranks (how many ranks RCCL itself reports, and its all-gather) -- the last collective work of
+        # the run, in a helper thread with its own 120 s bound: a diagnostic that hangs or fails must not cost the line (everything else
+        # is measured by now); on a time-out the line says so and the process leaves without tearing the process group down
+        prog.enter("gvl_comm_init / ncclCommCount / gvl_allgather_visual (bounded diagnostic)")
+        res = {}
+
+        def _diag():
+            try:
+                res["v"] = rccl_ranks_seen(eng, rank, world, dev, backend)
+            except Exception as e:
+                res["err"] = str(e)
+        th = threading.Thread(target=_diag, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("GVL_BENCH_DIAG_S", "120")))
+        if th.is_alive():
+            diag_stuck, ranks_seen = True, "timed out"
+            print(f"bench: rank {rank}: libgvl communicator check still running after its bound: skipped", file=sys.stderr, flush=True)
+        elif "err" in res:
+            ranks_seen = "failed: " + res["err"][:200]
+            print(f"bench: rank {rank}: libgvl communicator check failed: {res['err']}", file=sys.stderr, flush=True)
+        else:
+            ranks_seen, gvl_gather_ok = res["v"]
+
     if rank == 0:
         out = {"metric": "clips/sec + grounding tokens/sec, 96-frame Phi3.5-3.8B @1/2/4/8 MI355X", "value": round(clips_per_s, 4), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True,
@@ -799,6 +817,9 @@ def main(argv=None, engine_factory=None):
             out["cpu_baseline"] = cpu_baseline(dev, args.new_tokens)
         print(json.dumps(out), flush=True)
     prog.finish()
+    if diag_stuck:
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)                                      # a thread is parked inside a collective: no orderly teardown possible, and none needed
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -26,6 +26,9 @@ class StubEngine:
         self.calls = 0
         self.hang_rank = int(os.environ.get("GVL_STUB_HANG_RANK", "-1"))
         self.rank = int(os.environ.get("RANK", "0"))
+        if os.environ.get("GVL_STUB_COMM_HANG"):        # a libgvl communicator whose bootstrap never returns (bench's bounded end-of-run diagnostic)
+            self.comm_unique_id = lambda: b"stub-unique-id"
+            self.comm_init = lambda uid, rank, world: time.sleep(3600)
 
     # ---- vision: one row block per segment whose value encodes the segment's pixels ------------------------------------------------
     def _seg_code(self, sp, tp):

@@ -45,7 +45,8 @@ def test_bench_main_end_to_end_on_cpu(world, mode_args):
     d = json.loads(lines[0])
     cps = 1 if ("--mode" in mode_args or "1" in mode_args) else 8
     assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["unit"] == "clips/s" and d["scaling"] == "weak"
-    assert abs(d["value"] - world * 3 * cps / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-2      # whole-job clips / max-over-ranks time
+    # whole-job clips / max-over-ranks time (ms_per_step is printed with two decimals: a sub-millisecond stub step needs the slack)
+    assert abs(d["value"] - world * 3 * cps / (d["ms_per_step"] * 3e-3)) / d["value"] < max(1e-2, 0.011 / d["ms_per_step"])
     assert d["ids_match_serial"] is True                         # the last timed clip, alone and un-batched, gives the same ids: pixels, prompt and exchange all landed
     assert d["single_clip_latency_ms_sharded"] > 0 and d["config"]["clips_per_step"] == cps
     if world > 1:
@@ -89,3 +90,17 @@ def test_bench_under_the_drivers_own_launcher():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["ids_match_serial"] is True
     assert [q["rank"] for q in d["per_rank_stage_ms"]] == [0, 1]
+
+
+def test_a_hung_libgvl_communicator_check_does_not_cost_the_line():
+    """The ncclCommCount / gvl_allgather_visual check of libgvl's own communicator runs last, in a thread with its own bound: if its bootstrap
+    hangs, rank 0 still prints the complete line (value, roofline, per-rank stages; n_ranks_seen_by_rccl = "timed out") and every rank exits 0."""
+    if __import__("torch").cuda.is_available():
+        pytest.skip("plumbing test is for the GPU-less container")
+    outs = _run(2, ("--steps", "2", "--warmup", "1", "--new-tokens", "4"), {"GVL_STUB_COMM_HANG": "1", "GVL_BENCH_DIAG_S": "3"}, timeout=180)
+    for rc, o, e in outs:
+        assert rc == 0, e[-1500:]
+    lines = [l for l in outs[0][1].splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["n_ranks_seen_by_rccl"] == "timed out" and "hang" not in d and len(d["per_rank_stage_ms"]) == 2 and "roofline" in d

@@ -161,7 +161,7 @@ int clip_encode(gvl_ctx* ctx, const float* px, int n, float* out, hipStream_t st
     // algorithmic flops use the real K = 3*p*p, not the padded one
     RUN(GVL_PROF_GEMM, 2.0 * n * P * (double)C * 3 * f.clip_patch * f.clip_patch, gvl_launch_gemm(g, st)); }
   RUN(GVL_PROF_OTHER, 0, gvl_launch_clip_embed_ln(pO, ctx->c_cls, ctx->c_pos, ctx->c_prelnw, ctx->c_prelnb, x, n, P, C, 1e-5f, st));
-  const bool vt_pages = !ctx->dbg.vision_in_place;     // gvl_debug_set: the round-2 path (V^T pages written by a transpose pass), bit-identical
+  const bool vt_pages = !ctx->dbg.vision_in_place || D == 128;     // gvl_debug_set: the round-2 path (V^T pages written by a transpose pass), bit-identical; head dims 97..128 always take it
   for (int l = 0; l < f.clip_layers_run; ++l) {
     const ClipLayerW& w = ctx->cl[l];
     RUN(GVL_PROF_OTHER, 0, gvl_launch_layernorm_f32(x, w.ln1w, w.ln1b, h, M, C, 1e-5f, st));
@@ -198,7 +198,7 @@ int iv2_encode(gvl_ctx* ctx, const float* px, int n, bf16_t* out, hipStream_t st
   { GemmArgs g = gemm(pA, ctx->v_Kp, ctx->v_patchw, pO, C, n * TL, C, ctx->v_Kp); g.bias = ctx->v_patchb;
     RUN(GVL_PROF_GEMM, 2.0 * n * TL * (double)C * 3 * f.iv2_patch * f.iv2_patch, gvl_launch_gemm(g, st)); }
   RUN(GVL_PROF_OTHER, 0, gvl_launch_iv2_embed(pO, ctx->v_cls, ctx->v_pos, x, n, TL, C, st));
-  const bool vt_pages = !ctx->dbg.vision_in_place, q_in_place = ctx->dbg.vision_in_place == 1 && D == 96 && Dr == 88;
+  const bool vt_pages = !ctx->dbg.vision_in_place || D == 128, q_in_place = ctx->dbg.vision_in_place == 1 && D == 96 && Dr == 88;
   AALLOC(qrs, float, (size_t)M);
   for (int l = 0; l < f.iv2_blocks_run; ++l) {
     const Iv2BlockW& w = ctx->vb[l];

@@ -74,6 +74,36 @@ def test_iv2(name, tol_g, tol_o):
     eng.close()
 
 
+@pytest.mark.parametrize("tower,hidden,heads", [("clip", 128, 2), ("clip", 192, 2), ("clip", 256, 2), ("iv2", 704, 8), ("iv2", 192, 2), ("iv2", 256, 2)])
+def test_towers_at_other_head_dims(tower, hidden, heads):
+    """The attention kernel's operand paths by head dim, at toy depth against the oracle (bf16 emulation): 64 (CLIP reads q, k, v in place),
+    88 (InternVideo2: q in place with its RMSNorm in the prologue, softmax scale / shift folded into the S^T MFMAs, ones-column row sum),
+    96 (V in place, no padding) and 128 (Q / K pages + V^T transpose pass -- the in-place V gather is built for 64 and 96 only); each also
+    against the paged path (gvl_debug_set vision_in_place = 0)."""
+    px_seed = f"hd.{tower}.{hidden}.{heads}"
+    if tower == "clip":
+        c = dict(hidden=hidden, inter=2 * hidden, layers=3, heads=heads, image=42, patch=14)          # S = 1 + 9
+        eng, W = _clip_engine(c, px_seed)
+        px = synth.det_tensor(px_seed + ".px", (2, 3, 42, 42))
+        run = lambda: eng.clip_encode(px.to(DEV))
+        ref = O.clip_penultimate(px, W, c["layers"], c["heads"], emu=True)
+    else:
+        c = dict(dim=hidden, inter=2 * hidden, depth=3, heads=heads, image=56, frames=2)               # S = 1 + 2 * 16
+        eng, W = _iv2_engine(c, px_seed)
+        px = synth.det_tensor(px_seed + ".px", (2, 3, 2, 56, 56))
+        run = lambda: eng.iv2_encode(px.to(DEV))
+        ref = O.iv2_encode(px, W, c["depth"], c["heads"], emu=True)
+    got = run()
+    check(got, ref, 1.2e-2, f"{tower} hidden {hidden} / {heads} heads (head dim {hidden // heads}) vs oracle (bf16 emulation)")
+    eng.debug_set("vision_in_place", 0)
+    paged = run()
+    if tower == "iv2" and hidden // heads == 88:
+        check(got, paged.float(), 1.2e-2, f"{tower} head dim 88: folded in-place attention vs the paged path")
+    else:
+        assert torch.equal(got, paged)
+    eng.close()
+
+
 @pytest.mark.parametrize("name,tol_g,tol_o", [("glue_phi3_5", 9.2e-3, 6.0e-3), ("glue_llama3", 6.9e-3, 8.2e-3)])   # observed 6.1e-3 / 4.0e-3, 4.6e-3 / 5.4e-3
 def test_encode_segments_and_splice(name, tol_g, tol_o):
     """encode_images + prepare_multimodal_inputs on the 2-segment skeleton."""

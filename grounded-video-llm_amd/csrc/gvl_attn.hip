@@ -289,6 +289,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
 #ifdef GVL_ATTN_LAB
     if (GVL_ATTN_LAB & 4) { s[0][0] = (float)t; s[1][3] = qf[0][0]; } else
 #endif
+#ifdef GVL_ATTN_PRIO
+    if (GVL_ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int kk = 0; kk < DK; ++kk) {            // kk outer: the two accumulators alternate, no back-to-back dependent MFMAs
 #pragma unroll
@@ -298,6 +301,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qf[kk]), s[kb], 0, 0, 0);
       }
     }
+#ifdef GVL_ATTN_PRIO
+    if (GVL_ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(0);
+#endif
     // ---- online softmax (lane-local; raw-score max, scale folded into the exp2 argument) ---------------
     const bool need_mask = (t == n_tiles_all - 1 && (Sk & 63)) || (a.causal && t * 64 + 63 > qpos0 + qw);
     if (need_mask) {
@@ -370,6 +376,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
 #ifdef GVL_ATTN_LAB
     if (GVL_ATTN_LAB & 8) { o[0][0] += s[0][1] + s[1][2]; } else
 #endif
+#ifdef GVL_ATTN_PRIO
+    if (GVL_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const int kb = st >> 1, r0 = (st & 1) * 8;
@@ -385,6 +394,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o[db], 0, 0, 0);
       }
     }
+#ifdef GVL_ATTN_PRIO
+    if (GVL_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(0);
+#endif
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------

@@ -62,6 +62,12 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsign
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // row i of the S^T MFMA reads key kperm(i) of the 32-key block, so that accumulator register r of
 // lane (q, h) holds key (r>>3)*16 + 8*h + (r&7).
 __device__ __forceinline__ int kperm(int i) {
@@ -316,9 +322,17 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
           s[kb][r] = dead ? -1e30f : s[kb][r];
         }
     }
-    float mx = fmaxf(s[0][0], s[1][0]);
+    // row max of the lane's 32 scores: a depth-4 tree of 16 v_max3_f32 (fmaxf() makes hipcc quiet every MFMA result with a v_max_f32 x, x first --
+    // 8 extra instructions per tile -- and chains the 15 max3 it then emits)
+    float mx;
+    {
+      float l1[11];
 #pragma unroll
-    for (int r = 1; r < 16; r += 1) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);     // v_max3_f32
+      for (int i = 0; i < 5; ++i) { l1[i] = vmax3(s[0][3 * i], s[0][3 * i + 1], s[0][3 * i + 2]); l1[5 + i] = vmax3(s[1][3 * i], s[1][3 * i + 1], s[1][3 * i + 2]); }
+      l1[10] = vmax3(s[0][15], s[1][15], l1[0]);
+      const float a2 = vmax3(l1[1], l1[2], l1[3]), b2 = vmax3(l1[4], l1[5], l1[6]), c2 = vmax3(l1[7], l1[8], l1[9]);
+      mx = vmax3(vmax3(a2, b2, c2), l1[10], l1[10]);
+    }
     {   // exchange with the partner half-wave (lane ^ 32) in the VALU: v_permlane32_swap, no LDS round trip
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
       mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));

@@ -21,7 +21,6 @@ from typing import Dict, Optional, Sequence
 import torch
 import torch.nn.functional as F
 
-from . import lib as L
 
 bf = torch.bfloat16
 

@@ -12,7 +12,6 @@ from __future__ import annotations
 
 import argparse
 import os
-import re
 import sys
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -1,5 +1,5 @@
 """Run the attention kernel alone (target for rocprofv3 --pmc / timing)."""
-import os, sys, time
+import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import _gvl_bootstrap  # noqa

@@ -966,7 +966,7 @@ int gvl_launch_kv_page_copy(bf16_t* kpool, bf16_t* vpool, size_t layer_stride, s
   hipLaunchKernelGGL(kv_page_copy_kernel, dim3(layers, 2), dim3(256), 0, st, kpool, vpool, layer_stride, page_elems, src_page, dst_page);
   return CHECK_LAUNCH();
 }
-__global__ void inc_many_kernel(const IntPtrs ptrs) { if (threadIdx.x < ptrs.n) (*ptrs.p[threadIdx.x])++; }
+__global__ void inc_many_kernel(const IntPtrs ptrs) { if ((int)threadIdx.x < ptrs.n) (*ptrs.p[threadIdx.x])++; }
 int gvl_launch_inc_many(const IntPtrs& ptrs, hipStream_t st) {
   if (ptrs.n < 1 || ptrs.n > GVL_MAX_DECODE_BATCH) return -1;
   hipLaunchKernelGGL(inc_many_kernel, dim3(1), dim3(64), 0, st, ptrs);

@@ -495,13 +495,12 @@ int decode_group(gvl_ctx* ctx, Seq* const* sqs, int B, int max_new, int eos_id, 
   for (int b = 1; b < B; ++b) if (sqs[b]->n_gen != start_gen) return fail(ctx, GVL_ERR_STATE, "decode batch: sequences are at different generation steps");
   struct Watch { gvl_ctx* c; ~Watch() { c->watch_eos = -1; } } watch{ctx};
   bool done[GVL_MAX_DECODE_BATCH] = {false};
-  int n_done = 0;
   if (eos_id >= 0) {
     // the tokens produced so far (the prefill's first token) were selected without a watch: look at them once, then arm the flags
     HIPCHK(ctx, hipStreamSynchronize(st));
     for (int b = 0; b < B; ++b) {
       HIPCHK(ctx, hipMemcpy(out_ids[b], sqs[b]->d_out, (size_t)start_gen * 4, hipMemcpyDeviceToHost));
-      for (int i = 0; i < start_gen && !done[b]; ++i) if (out_ids[b][i] == eos_id) { done[b] = true; ++n_done; }
+      for (int i = 0; i < start_gen && !done[b]; ++i) if (out_ids[b][i] == eos_id) done[b] = true;
       *sqs[b]->h_eos = 0;
     }
     ctx->watch_eos = eos_id;
@@ -515,7 +514,7 @@ int decode_group(gvl_ctx* ctx, Seq* const* sqs, int B, int max_new, int eos_id, 
   for (;;) {
     if (eos_id >= 0 && enq >= 2) {
       HIPCHK(ctx, hipEventSynchronize(ctx->step_ev[(enq - 2) % 3]));
-      for (int b = 0; b < B; ++b) if (!done[b] && *sqs[b]->h_eos != 0) { done[b] = true; ++n_done; }
+      for (int b = 0; b < B; ++b) if (!done[b] && *sqs[b]->h_eos != 0) done[b] = true;
     }
     Seq* now[GVL_MAX_DECODE_BATCH]; int n_now = 0;
     for (int b = 0; b < B; ++b) if (!done[b] && sqs[b]->n_gen < max_new && sqs[b]->pos < sqs[b]->max_tokens) now[n_now++] = sqs[b];

@@ -457,12 +457,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
 template <int D, int NWAVES, int NS, int ONES = 0, int VROW = 0>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
   constexpr int LDS = NS * 2 * 64 * D * 2 + 1024;   // ring + page-id table (256 pages)
-  static bool attr_set = false;
+  static GvlDevOnce once;
   auto kern = attn_fwd_kernel<D, NWAVES, NS, ONES, VROW>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-    attr_set = true;
-  }
+  if (gvl_set_max_lds(once, (const void*)kern, LDS)) return -3;
   const int nq = (a.S + NWAVES * 32 - 1) / (NWAVES * 32);
   dim3 grid((unsigned)(((a.KV * a.B + 7) / 8) * 8 * (a.H / a.KV) * nq));
   hipLaunchKernelGGL(kern, grid, dim3(NWAVES * 64), LDS, st, a);

@@ -715,11 +715,11 @@ template <int B>
 static int launch_gemv_b(const GemvArgs& a, int R, int blocks, size_t lds, hipStream_t st) {
   switch (R) {
 #define GEMV_CASE(RR) case RR: { auto k = gemv_kernel<RR, B>; \
-      if (lds > 48 * 1024) { static bool set_ = false; if (!set_) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -3; set_ = true; } } \
+      if (lds > 48 * 1024) { static GvlDevOnce once_; if (gvl_set_max_lds(once_, (const void*)k, 160 * 1024 - 1024)) return -3; } \
       hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, a); break; }
     GEMV_CASE(1) GEMV_CASE(2) GEMV_CASE(3) GEMV_CASE(4) GEMV_CASE(6)
     default: { auto k = gemv_kernel<8, B>;
-      if (lds > 48 * 1024) { static bool set_ = false; if (!set_) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -3; set_ = true; } }
+      if (lds > 48 * 1024) { static GvlDevOnce once_; if (gvl_set_max_lds(once_, (const void*)k, 160 * 1024 - 1024)) return -3; }
       hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, a); break; }
 #undef GEMV_CASE
   }

@@ -738,15 +738,13 @@ static int launch_pp(const GemmArgs& a_in, hipStream_t st) {
   constexpr int STGB = (STG && EPI >= 0 && (EPI & 4)) ? 8 * 32 * (128 * 4 + 16) : 0;    // f32 staging: 132 KiB
   constexpr bool TAB = STG && EPI >= 0 && (EPI & 3) == GVL_ACT_GELU;
   constexpr int LDS = (RING > STGB ? RING : STGB) + (STG ? 8 * 128 * 8 : 0) + (TAB ? GELU_TAB_BYTES : 0);   // + bias/gamma scratch + Phi table
-  static bool attr_set = false;
-  static int n_cu = 256;
-  auto kern = gemm_pp_kernel<BM, BN, EPI, STG>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+  static GvlDevOnce once;
+  static const int n_cu = [] {                      // the devices of a node are alike: asked once
     hipDeviceProp_t p; int d = 0;
-    if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n_cu = p.multiProcessorCount & ~7;
-    attr_set = true;
-  }
+    return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? (p.multiProcessorCount & ~7) : 256;
+  }();
+  auto kern = gemm_pp_kernel<BM, BN, EPI, STG>;
+  if (gvl_set_max_lds(once, (const void*)kern, LDS)) return -3;
   GemmArgs a = a_in;
   const int tiles_m = (a.M - a.m_begin + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const int tiles = tiles_m * tiles_n;
@@ -787,12 +785,9 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int STAG, int EPI = -1, int 
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int LDS = NS * (BM + BN) * 128;
-  static bool attr_set = false;
+  static GvlDevOnce once;
   auto kern = gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAG, EPI, STG, NS>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-    attr_set = true;
-  }
+  if (gvl_set_max_lds(once, (const void*)kern, LDS)) return -3;
   const int tiles_m = (a.M - a.m_begin + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT), LDS, st, a, tiles_m, tiles_n);
   return hipGetLastError() == hipSuccess ? 0 : -3;

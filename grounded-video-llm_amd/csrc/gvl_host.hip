@@ -24,6 +24,13 @@ int gvl_kv_info(const gvl_ctx* ctx, int* total_pages, int* free_pages, int64_t* 
   return 0;
 }
 
+int gvl_decode_group_info(const gvl_ctx* ctx, int* max_group, int* any_size) {
+  if (!ctx) return GVL_ERR_ARG;
+  if (max_group) *max_group = ctx->decode_mfma ? GVL_MAX_DECODE_BATCH : GVL_MAX_VALU_BATCH;
+  if (any_size) *any_size = ctx->decode_mfma ? 1 : 0;
+  return 0;
+}
+
 // ---- packed weight file (safetensors container): u64 header length, JSON header, raw little-endian tensor bytes ----------------
 namespace {
 struct StEntry { std::string name, dtype; std::vector<int64_t> shape; uint64_t b = 0, e = 0; };

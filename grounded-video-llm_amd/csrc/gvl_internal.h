@@ -27,6 +27,22 @@ constexpr int GVL_MAX_DECODE_BATCH = 16;  // sequences decoded together: the wei
 constexpr int GVL_MAX_VALU_BATCH = 4;     // the round-1 VALU GEMV (fallback for K % 256 != 0 geometries) holds B vectors in LDS: 1, 2 or 4
 constexpr int GVL_MAX_PREFILL_BATCH = 8;  // most sequences whose rows share one pass of the prefill GEMMs (gvl_debug_set prefill_group picks 1 .. 8; default 4)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a host may hold one gvl_ctx per device in ONE process
+// (include/gvl.h allows it), so "set once" means once per device ordinal -- a process-global flag would leave the second device at the
+// 64 KB default and its first big-LDS launch would fail.  One bit per ordinal (mod 64); racing first launches set it twice, harmlessly.
+#include <atomic>
+struct GvlDevOnce { std::atomic<unsigned long long> mask{0}; };
+inline int gvl_set_max_lds(GvlDevOnce& once, const void* kern, int bytes) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) return -3;
+  const unsigned long long bit = 1ull << (d & 63);
+  if (!(once.mask.load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return -3;
+    once.mask.fetch_or(bit, std::memory_order_release);
+  }
+  return 0;
+}
+
 // ---- device helpers ---------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }

@@ -508,7 +508,12 @@ int decode_group(gvl_ctx* ctx, Seq* const* sqs, int B, int max_new, int eos_id, 
   // Only LIVE members are stepped: a sequence that produced eos (seen two steps late) or reached its own capacity / max_new leaves the
   // group, so it can neither truncate the answers of longer-running members nor append past its pages.  A sequence's ids do not depend
   // on the group it is decoded in (gvl_decode.hip), so shrinking the group changes no result; the captured step is re-recorded.
-  std::unique_ptr<StepGraph> sg(new StepGraph());
+  // The live set is stepped as PARTS of sizes the decode path takes (decode_group_size: any size up to 16 on the skinny-MFMA path;
+  // 4 / 2 / 1 on the VALU fallback, so three survivors of a group of four run as 2 + 1), one captured step graph per part.
+  // Retired graphs are destroyed after the final synchronise only: up to two replays may still be in flight when a member leaves.
+  struct Part { Seq* m[GVL_MAX_DECODE_BATCH]; int n; std::unique_ptr<StepGraph> sg; };
+  std::vector<Part> parts;
+  std::vector<std::unique_ptr<StepGraph>> retired;
   Seq* live[GVL_MAX_DECODE_BATCH]; int n_live = -1;
   int enq = 0;
   for (;;) {
@@ -520,11 +525,19 @@ int decode_group(gvl_ctx* ctx, Seq* const* sqs, int B, int max_new, int eos_id, 
     for (int b = 0; b < B; ++b) if (!done[b] && sqs[b]->n_gen < max_new && sqs[b]->pos < sqs[b]->max_tokens) now[n_now++] = sqs[b];
     if (n_now == 0) break;
     if (n_now != n_live || memcmp(now, live, sizeof(Seq*) * n_now) != 0) {
-      if (n_live >= 0) sg.reset(new StepGraph());
+      for (auto& p : parts) retired.push_back(std::move(p.sg));
+      parts.clear();
+      for (int o = 0; o < n_now;) {
+        Part p; p.n = decode_group_size(ctx, n_now - o);
+        memcpy(p.m, now + o, sizeof(Seq*) * p.n); p.sg.reset(new StepGraph());
+        o += p.n; parts.push_back(std::move(p));
+      }
       memcpy(live, now, sizeof(Seq*) * n_now); n_live = n_now;
     }
-    const int rc = decode_step_replay(ctx, live, n_live, st, *sg);
-    if (rc) return rc;
+    for (auto& p : parts) {
+      const int rc = decode_step_replay(ctx, p.m, p.n, st, *p.sg);
+      if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    }
     if (eos_id >= 0) HIPCHK(ctx, hipEventRecord(ctx->step_ev[enq % 3], st));
     ++enq;
   }

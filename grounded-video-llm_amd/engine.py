@@ -183,6 +183,13 @@ class Engine:
         self._chk(self.lib.gvl_kv_info(self.ctx, C.byref(t), C.byref(f), C.byref(b), C.byref(m)), "gvl_kv_info")
         return {"total_pages": t.value, "free_pages": f.value, "pool_bytes": b.value, "max_live_seqs": m.value, "tokens": t.value * 64}
 
+    def decode_group_info(self) -> Dict[str, int]:
+        """gvl_decode_group_info: the group sizes one batched decode step takes ({max_group: 16, any_size: 1} on the skinny-MFMA path;
+        {4, 0} = sizes 1 / 2 / 4 on the VALU fallback)."""
+        m, a = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.gvl_decode_group_info(self.ctx, C.byref(m), C.byref(a)), "gvl_decode_group_info")
+        return {"max_group": m.value, "any_size": a.value}
+
     # ---- multi-GPU exchange through the C ABI (RCCL dlopen'ed by libgvl) -----------------------------
     def comm_unique_id(self) -> bytes:
         buf = C.create_string_buffer(128)

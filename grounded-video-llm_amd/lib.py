@@ -46,6 +46,7 @@ _SIGS = {
     "gvl_comm_unique_id": (C.c_int, [C.c_char_p]),
     "gvl_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "gvl_comm_destroy": (C.c_int, [C.c_void_p]),
+    "gvl_decode_group_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gvl_comm_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "gvl_allgather_visual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gvl_clip_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -283,12 +283,12 @@ class LLAVA_NEXT_VIDEO:
         the host."""
         from . import beam as B
         eng = self.engine
-        g_ = self.geo                                    # the skinny-MFMA decode path (groups of any size up to 16) needs every K to be a multiple of 256
-        self._decode_mfma = all(k % 256 == 0 for k in (g_.hidden, g_.inter)) and g_.hidden <= 4096 and (g_.hidden // g_.heads) % 2 == 0   # csrc/gvl_model.hip: ctx->decode_mfma
+        gi = eng.decode_group_info()                     # which group sizes ONE batched step takes: asked from the library, not restated here
         eos = getattr(self.tokenizer, "eos_token_id", None)
         emb = eng.splice(row, vis)
         cap = min(emb.shape[0] + max_new + 1, self.geo.max_seq)
-        beams: List[int] = [eng.seq_alloc(cap)]
+        beams: List[Optional[int]] = [eng.seq_alloc(cap)]
+        fresh: List[int] = []                            # clones of the step in progress: owned here until they are installed in `beams`
         try:
             first = eng.prefill(beams[0], emb, want_logits=True)
 
@@ -297,23 +297,27 @@ class LLAVA_NEXT_VIDEO:
                 for j, p_ in enumerate(parents):             # clones first: every parent is still at the length the children continue from
                     if p_ in keep:
                         new[j] = eng.seq_clone(beams[p_], cap)
+                        fresh.append(new[j])                 # if a later clone raises (pool exhausted, kMaxSeqs), `finally` frees these
                     else:
                         keep[p_] = j
                 for p_, j in keep.items():
                     new[j] = beams[p_]
-                for p_, s_ in enumerate(beams):
-                    if p_ not in keep:
-                        eng.seq_free(s_)
-                beams[:] = new
-                if len(beams) <= 16 and (self._decode_mfma or len(beams) in (1, 2, 4)):
+                losers = [s_ for p_, s_ in enumerate(beams) if p_ not in keep]
+                beams[:] = new                               # install before freeing: `finally` never sees an id twice or a freed id
+                del fresh[:]
+                for s_ in losers:
+                    eng.seq_free(s_)
+                if len(beams) <= gi["max_group"] and (gi["any_size"] or len(beams) in (1, 2, 4)):
                     return eng.decode_step_logits_batch(beams, toks)        # the k beams share ONE stream of the weights
                 return torch.stack([eng.decode_step_logits(s_, t) for s_, t in zip(beams, toks)])
 
             return B.beam_search(step, first, num_beams, max_new, eos, length_penalty, early_stopping)
         finally:
-            for s_ in beams:
-                if s_ is not None:
+            for s_ in set(x for x in list(beams) + fresh if x is not None):
+                try:
                     eng.seq_free(s_)
+                except Exception:                            # never mask the original error with a cleanup error
+                    pass
 
     @torch.inference_mode()
     def generate_shared(self, samples, prompts: Sequence[str], **generate_kwargs) -> List[str]:
@@ -355,6 +359,12 @@ class LLAVA_NEXT_VIDEO:
         shared = min(k + n_vis + tail, min(e.shape[0] for e in embs) - 1)     # every prompt keeps at least one row of its own (its last row feeds the first token)
         prefix = shared // 128 * 128
         if prefix < 128:
+            return None
+        # LongRoPE (modeling_phi3.py:381-385) picks ONE factor set per forward from the TOTAL length: a full prefill of a prompt longer than
+        # original_max_position_embeddings ropes every row -- the shared ones too -- with the long factors, while a base prefill of a prefix
+        # that still fits the original context would cache its K with the short ones.  Share only when base and forks agree.
+        omax = self.geo.rope_orig_max_pos if self.geo.rope_long is not None else 0
+        if omax > 0 and prefix <= omax and any(e.shape[0] > omax for e in embs):
             return None
         self.last_shared_prefix = prefix
         eos = getattr(self.tokenizer, "eos_token_id", None)

@@ -132,13 +132,22 @@ int gvl_seq_free(gvl_ctx* ctx, int seq_id);
  * fresh pages up to max_tokens.  gvl_prefill_extend then runs the decoder over the remaining n_new prompt rows only: they take
  * positions prefix .. prefix + n_new - 1 and attend to the cached prefix plus themselves; last_logits / first token as gvl_prefill.
  * With a prefix that is a multiple of 128 tokens the result is BIT-IDENTICAL to a gvl_prefill of the whole prompt (same query blocks,
- * same page tiles, same k order); any multiple of 64 is within bf16 rounding of it. */
+ * same page tiles, same k order); any multiple of 64 is within bf16 rounding of it.  LongRoPE models (cfg.rope_orig_max_pos > 0): a prefill
+ * picks ONE factor set from the length it sees (short up to the original context, long beyond; modeling_phi3.py:381-385) -- the prefix's
+ * cached K carries the choice made when IT was prefilled, so the identity holds only when prefix and whole prompt fall on the same side of
+ * rope_orig_max_pos; the host must not share a prefix <= rope_orig_max_pos with a prompt longer than it (model.py falls back to full
+ * prefills). */
 int gvl_seq_fork(gvl_ctx* ctx, int src_seq, int n_tokens, int max_tokens, int* dst_seq);
 int gvl_prefill_extend(gvl_ctx* ctx, int seq_id, const uint16_t* embeds_new, int n_new, float* last_logits, void* stream);
 /* A copy of a sequence AT ITS CURRENT LENGTH (beam search: HF's cache reorder, transformers GenerationMixin._reorder_cache [ext]): whole pages
  * are shared by reference, the partial last page is copied on `stream` (one launch over all layers); the clone then appends to its own pages. */
 int gvl_seq_clone(gvl_ctx* ctx, int src_seq, int max_tokens, int* dst_seq, void* stream);
 int gvl_kv_info(const gvl_ctx* ctx, int* total_pages, int* free_pages, int64_t* pool_bytes, int* max_live_seqs);
+/* The group sizes ONE batched decode step takes (gvl_decode_step_logits_batch, and the parts gvl_decode_greedy_batch / gvl_decode_steps
+ * step together), valid after gvl_finalize_weights: *max_group = 16 on the skinny-MFMA decode path, 4 on the VALU fallback
+ * (geometries whose projection widths are not multiples of 256); *any_size = 1 when every size 1 .. max_group is taken, 0 when only
+ * 1, 2 and 4 are.  Hosts that form their own groups (beam search) ask here instead of restating the library's predicate. */
+int gvl_decode_group_info(const gvl_ctx* ctx, int* max_group, int* any_size);
 int gvl_prefill(gvl_ctx* ctx, int seq_id, const uint16_t* embeds, int seq_len, float* last_logits,
                 void* stream);
 int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t* out_ids_host,
@@ -244,7 +253,11 @@ int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launche
  *   "vision_in_place"  1 (default): non-causal attention (vision towers, gvl_op_attention) reads V -- and Q, K when the head dim needs no padding
  *                      or transform; with InternVideo2's q RMSNorm applied in the kernel prologue -- straight from the fused-qkv matrix;
  *                      2: V only; 0: the round-2 path through Q / K pages and a V^T transpose pass
- * None of them may change a single output bit (asserted in tests/test_gpu_llm.py). */
+ * None of them may change a single output bit (asserted in tests/test_gpu_llm.py) -- with ONE stated exception: "vision_in_place" = 1 on a head
+ * dim that is padded (InternVideo2, 88 -> 96) folds the softmax scale and shift into q before its one rounding to bf16, a different (not larger)
+ * set of rounding points: modes 0 and 2 are bit-identical to each other, mode 1 is bit-identical to them for CLIP (head dim 64) and agrees within
+ * bf16 noise for InternVideo2 (one block 4.1e-3 of the output scale; 39 blocks vs the reference: the same error as the reference's own bf16,
+ * tests/test_gpu_towers.py, tests/test_gpu_c0.py). */
 int gvl_debug_set(gvl_ctx* ctx, const char* key, int value);
 
 /* ---- operator-level entry points (parity tests call the kernels through these) --------------- */

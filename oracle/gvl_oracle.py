@@ -602,16 +602,20 @@ def llm_forward(cfg: LLMConfig, W, x: torch.Tensor, emu=False, cache=None, pos0:
 
 
 def greedy_generate(cfg: LLMConfig, W, inputs_embeds: torch.Tensor, max_new_tokens: int, eos_token_id: Optional[int],
-                    emu=False, use_cache=True, return_margins=False):
+                    emu=False, use_cache=True, return_margins=False, return_scales=False):
     """language_model.generate(inputs_embeds=..., do_sample=False, num_beams=1) semantics
     (models/llava_next_video.py:655-661; transformers GenerationMixin [ext]): only NEW ids are
     returned, the step that emits eos is included, generation stops after it.
 
     use_cache=False is the O(n^2) definition (SURVEY §8c 'Greedy-decode oracle'); use_cache=True is
-    the mathematically identical KV-cached loop used for the CPU baseline."""
+    the mathematically identical KV-cached loop used for the CPU baseline.
+
+    return_margins: also the top-1 minus top-2 logit of every step; return_scales: also max|logit| of every step, so that a test can
+    state "ids must agree wherever the margin exceeds x of the logit scale" instead of an absolute margin."""
     e = _r(W["model.embed_tokens.weight"], emu)
     out: List[int] = []
     margins: List[float] = []
+    scales: List[float] = []
     if use_cache:
         cache = [None] * cfg.layers
         logits = llm_forward(cfg, W, inputs_embeds, emu, cache, 0, last_only=True)
@@ -623,6 +627,7 @@ def greedy_generate(cfg: LLMConfig, W, inputs_embeds: torch.Tensor, max_new_toke
         top2 = torch.topk(logits[-1], 2)
         tok = int(top2.indices[0])
         margins.append(float(top2.values[0] - top2.values[1]))
+        scales.append(float(logits[-1].abs().max()))
         out.append(tok)
         if eos_token_id is not None and tok == eos_token_id:
             break
@@ -634,6 +639,8 @@ def greedy_generate(cfg: LLMConfig, W, inputs_embeds: torch.Tensor, max_new_toke
         else:
             seq = torch.cat([seq, e[tok][None]], dim=0)
             logits = llm_forward(cfg, W, seq, emu, None, 0, last_only=True)
+    if return_scales:
+        return out, margins, scales
     return (out, margins) if return_margins else out
 
 

@@ -39,7 +39,7 @@ def test_generate_matches_oracle(llm):
                               iv2_depth=3, iv2_heads=4, emu=True)[0]
     ocfg = O.LLMConfig(kind, hid, 256, 2, 4, geo.kv_heads, vocab, 1e-5, geo.rope_theta, 131072, 4096, geo.rope_short, geo.rope_long)
     ref_emb = O.splice(torch.tensor(ids), ref_vis, sd["language_model"]["model.embed_tokens.weight"], emu=True)
-    ref_ids, margins = O.greedy_generate(ocfg, sd["language_model"], ref_emb, 10, tok.eos_token_id, emu=True, return_margins=True)
+    ref_ids, margins, scales = O.greedy_generate(ocfg, sd["language_model"], ref_emb, 10, tok.eos_token_id, emu=True, return_margins=True, return_scales=True)
     # --- product
     feats = model.encode_images(samples)
     err = float((feats[0].float().cpu() - ref_vis).abs().max() / ref_vis.abs().max())
@@ -49,7 +49,10 @@ def test_generate_matches_oracle(llm):
     got = model.generate_ids(ids_arr, mask, feats, 10)[0]
     for i, (a, b) in enumerate(zip(got, ref_ids)):
         if a != b:
-            assert margins[i] < 0.05, f"token {i}: {a} vs {b}, oracle margin {margins[i]}"
+            # ids may part ways only where the oracle's top-1 margin is inside twice the bf16-class logit tolerance (2e-2 of the logit scale,
+            # the bound every logit test of these small models uses) -- relative to the scale, as tests/test_gpu_c0.py does at full size
+            print(f"[parity] generate({llm}): ids part ways at token {i} ({a} vs {b}); oracle margin {margins[i] / scales[i]:.3e} of the logit scale")
+            assert margins[i] < 2 * 2e-2 * scales[i], f"token {i}: {a} vs {b}, oracle margin {margins[i]} = {margins[i] / scales[i]:.3e} of the scale {scales[i]}"
             break
     else:
         assert len(got) == len(ref_ids)
@@ -198,3 +201,37 @@ def test_training_forward_loss_matches_oracle(llm):
     print(f"[parity] forward({llm}) loss gpu {got:.5f} oracle {tot / cnt:.5f} over {cnt} labelled tokens")
     assert abs(got - tot / cnt) < 1e-2 * (tot / cnt)
     model.engine.close()
+
+
+def test_generate_shared_respects_the_longrope_switch():
+    """LongRoPE picks ONE factor set per forward from the total length (modeling_phi3.py:381-385).  When the prompts are longer than
+    original_max_position_embeddings but their 128-aligned common prefix is not, a shared base prefill would cache the prefix K with the SHORT
+    factors while a full prefill ropes every row with the LONG ones: generate_shared must fall back to full prefills there (same texts as one
+    generate() per prompt, nothing shared); once the prefix itself is past the switch, sharing is on again and still identical."""
+    llm, hid, vocab = "phi3.5", 128, 640
+    short, long = synth.longrope_factors(32)
+    tok = SyntheticTokenizer(vocab, 300)
+    prompts = [P.build_prompt(llm, "grounding", "When does the person open the door in the video?"), P.build_prompt(llm, "grounding", "When does the dog jump?"),
+               P.build_prompt(llm, "qa", "Describe the video in detail please.")]
+    n_vis = 2 * 285
+    totals = [len(P.tokenize_with_image(p, tok, tok.bos_token_id)) - 1 + n_vis for p in prompts]
+    sd = {"vision_tower": synth.clip_weights(64, 128, 3, seed="gen.clip"), "video_encoder": synth.iv2_weights(64, 128, 3, 2, seed="gen.iv2"),
+          "projectors": synth.projector_weights(llm, hid, 64, 64, seed="gen.proj"), "language_model": synth.llm_weights("phi3", hid, 256, 2, 4, 4, vocab, True, seed="gen.llm")}
+    sp = synth.det_tensor("gen.sp", (1, 2, 3, 336, 336)).to(DEV)
+    tp = synth.det_tensor("gen.tp", (1, 4, 3, 224, 224)).to(DEV)
+    one = {"spatial_pixel_values": sp, "temporal_pixel_values": tp, "video_ids": ["x"]}
+    texts = {}
+    for omax, shared_expected in ((min(totals) - 8, False), (400, True)):       # 512 <= omax < every total: mixed factors -> fall back; omax < 512: prefix and prompts both long
+        assert (512 <= omax < min(totals)) == (not shared_expected)
+        geo = E.TowerGeometry(llm=llm, clip_hidden=64, clip_inter=128, clip_layers=3, clip_heads=4, iv2_dim=64, iv2_inter=128, iv2_depth=3, iv2_heads=4, hidden=hid,
+                              inter=256, layers=2, heads=4, kv_heads=4, vocab=vocab, rope_short=short, rope_long=long, rope_theta=10000.0, rope_orig_max_pos=omax,
+                              max_seq=2048, max_segs=6, kv_pages=60, max_prefill=1024)
+        model = LLAVA_NEXT_VIDEO(stage="sft", max_txt_len=64, num_frames=4, num_segs=2, num_temporal_tokens=300, lora=False, llm=llm, geometry=geo, tokenizer=tok,
+                                 state_dicts=sd, device=DEV)
+        per_prompt = [model.generate({**one, "prompts": [p]}, do_sample=False, num_beams=1, max_new_tokens=10)[0] for p in prompts]
+        shared = model.generate_shared(one, prompts, do_sample=False, num_beams=1, max_new_tokens=10)
+        assert shared == per_prompt, f"rope_orig_max_pos={omax}: generate_shared differs from one generate() per prompt"
+        assert (model.last_shared_prefix >= 128) == shared_expected, (omax, model.last_shared_prefix)
+        assert model.engine.kv_info()["free_pages"] == model.engine.kv_info()["total_pages"]
+        texts[omax] = per_prompt
+        model.engine.close()

@@ -761,8 +761,10 @@ def test_finished_members_do_not_truncate_the_group():
     geo = _phi_geo(c, max_seq=512, max_prefill=128, kv_pages=32)
     W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed="t.eos", device=DEV)
     eng = llm_engine(geo, W)
-    xs = [synth.det_tensor(f"t.eos.x{i}", (n, c["hidden"]), 0.5).to(DEV).to(bf) for i, n in enumerate((20, 33, 47))]
-    room = (5, 41, 13)
+    assert eng.decode_group_info() == {"max_group": 4, "any_size": 0}               # hidden 64: the VALU fallback steps groups of 1, 2 or 4
+    # FOUR members form one group of four; it shrinks to three (stepped as 2 + 1: the fallback has no group of three -- ADVICE r3), two, one
+    xs = [synth.det_tensor(f"t.eos.x{i}", (n, c["hidden"]), 0.5).to(DEV).to(bf) for i, n in enumerate((20, 33, 47, 26))]
+    room = (5, 41, 13, 22)
 
     def run(batched, eos):
         seqs = [eng.seq_alloc(x.shape[0] + r) for x, r in zip(xs, room)]
@@ -774,7 +776,7 @@ def test_finished_members_do_not_truncate_the_group():
         return out
 
     singles = run(False, None)
-    assert [len(o) for o in singles] == [6, 40, 14], [len(o) for o in singles]      # the prefill's token + one per free KV slot, capped by max_new
+    assert [len(o) for o in singles] == [6, 40, 14, 23], [len(o) for o in singles]  # the prefill's token + one per free KV slot, capped by max_new
     assert run(True, None) == singles
     eos = singles[1][8]                                                               # member 1 stops at its 9th token (or earlier), others where they must
     assert run(True, eos) == run(False, eos)

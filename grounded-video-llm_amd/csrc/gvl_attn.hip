@@ -451,9 +451,342 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
       }
   }
 }
-// (A software-pipelined variant -- S^T of tile t + 1 issued under the softmax of tile t, third ring slot, second score tile, two waves per
-//  SIMD -- was built in round 2, passed every test and measured 16 % SLOWER (19.6 vs 16.9 ms of attention per clip): removed in round 3,
-//  DESIGN.md §3.2 keeps the numbers.)
+// =====================================================================================================
+// attn_iv2_pipe_kernel -- the InternVideo2 shape (head dim 88 -> 96, q in place + folded softmax, ones-row sum, non-causal, no block table)
+// with a HAND-PLACED, software-pipelined key-tile loop (round 4).
+//
+// attn_fwd_kernel runs a tile as three serial stretches -- 12 S^T MFMAs (matrix pipe only), the row max (VALU only), 32 exp2 + 16 packs
+// feeding 12 P.V MFMAs -- and relies on three resident waves per SIMD to overlap them: PMC showed the matrix pipe 0.64 busy, the two
+// pipes adding up instead of overlapping (profiles/r03_attention_pmc.txt).  Here ONE wave's own instruction stream keeps both pipes fed:
+//   phase 1:  S^T(t+1) = K(t+1).Q^T   12 MFMAs   ||   P(t) = exp2(S(t)), packed to bf16   (32 v_exp_f32 + 16 v_cvt_pk) + the 12 K fragment reads
+//   phase 2:  O^T += V(t).P(t)        12 MFMAs   ||   row max of S(t+1)                    (16 v_max3 + the half-wave exchange) + the 24 V tr-reads
+// Every MFMA heads a GROUP {MFMA, <= 5 single-issue fillers} closed by __builtin_amdgcn_sched_barrier(0): hipcc may not move anything
+// across a group boundary, so the emitted stream IS this listing (its sched_group_barrier requests were honoured only partially in
+// round 2), while hipcc still owns register allocation, s_waitcnt counts and the hazard nops.  A 32x32x16 MFMA occupies the matrix pipe
+// for 32 cycles = 8 issue slots; <= 5 fillers ride in its shadow (MI355X_MICROARCH.md, cycle constants).  The LDS fragment of MFMA i is
+// requested two groups ahead.  The two score tiles swap roles by a 2x unroll (no register copies); the unroll parity also fixes the ring
+// slot, so every LDS address is one per-lane register plus an immediate.  Two waves per SIMD (<= 256 VGPRs), 2 blocks of 4 waves per CU.
+//
+// Ring (2 slots of {K tile, V tile}, 48 KB per block as before), now phase-shifted: iteration t reads K(t+1) and V(t), so after the top
+// barrier of iteration t the K half of slot t&1 (K(t), consumed by iteration t-1) takes K(t+2) and the V half of slot (t+1)&1 (V(t-1))
+// takes V(t+1); both DMA sets are issued inside phase 1 (under MFMAs) and awaited (vmcnt(0) + barrier) at the top of iteration t+1.
+//
+// Arithmetic is EXACTLY attn_fwd_kernel<96, 4, 2, 1, 3>'s: same MFMAs on the same values in the same order, same lazy-reference rule at
+// the same point of the O accumulation (after tile t's P.V, before tile t+1's) -- the two kernels are bit-identical (asserted:
+// gvl_debug_set("attn_pipe", 0 | 1), tests/test_gpu_towers.py).
+#define GVL_SB() __builtin_amdgcn_sched_barrier(0)
+template <int I> struct IC { static constexpr int v = I; };
+// three DMA pieces from one SGPR base, each under its own lane mask (the V image's pad-chunk lanes stay off), in ONE branch-free statement:
+// hipcc's own predication is an s_cbranch_execz per piece, i.e. three basic-block splits in the middle of a hand-placed phase
+__device__ __forceinline__ void glds16x3_masked(const void* sbase, const unsigned (&v)[3], const unsigned long long (&mask)[3], unsigned lds_dst0, unsigned lds_step) {
+  unsigned keep, d;
+  unsigned long long ex;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b64 %2, exec\n\t"
+      "s_mov_b32 m0, %7\n\ts_and_b64 exec, %2, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6\n\t"
+      "s_add_u32 %1, %7, %8\n\ts_mov_b32 m0, %1\n\ts_and_b64 exec, %2, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\t"
+      "s_add_u32 %1, %1, %8\n\ts_mov_b32 m0, %1\n\ts_and_b64 exec, %2, %11\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6\n\t"
+      "s_mov_b64 exec, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(d), "=&s"(ex)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(sbase), "s"(lds_dst0), "s"(lds_step), "s"(mask[0]), "s"(mask[1]), "s"(mask[2])
+      : "memory", "scc");
+}
+
+__global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a) {
+  constexpr int D = 96, NT = 256, DK = 6, DB = 3, CPR = 12, NIK = 3, TILE_BYTES = 64 * D * 2, STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int VLAST = 2 * STAGE_BYTES;               // a third V slot that only ever holds the LAST key tile when it is partial
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  // XCD-aware block -> (query block, head, batch) exactly as attn_fwd_kernel (H == KV here)
+  const int nq = (a.S + 127) / 128;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int qb = j % nq, grp = (j / nq) * 8 + xcd;
+  if (grp >= a.KV * a.B) return;
+  const int b = grp / a.KV, head = grp - b * a.KV;
+  const int qw = qb * 128 + wave * 32;
+  const int S = a.S, n_tiles = (S + 63) >> 6, v_ld = a.v_ld, Dout = a.Dout;
+  const bool partial = (S & 63) != 0;
+  const int last_full = partial ? n_tiles - 2 : n_tiles - 1;     // -1: the only tile is partial
+
+  unsigned koff[NIK], voff[NIK];
+  unsigned long long vmask[NIK];
+#pragma unroll
+  for (int i = 0; i < NIK; ++i) {
+    const int pos = i * NT + tid, r = pos / CPR, c = pos - r * CPR;
+    koff[i] = (unsigned)(r * D + KSwz<D>::logical(r, c) * 8) * 2;
+    voff[i] = (unsigned)(r * v_ld + c * 8) * 2;
+    vmask[i] = __ballot(c * 8 < Dout);                 // pad chunk: no DMA (VSwz<96> is the identity); never all-off within a wave
+  }
+  // q fragments: issued here, consumed after the first tiles are requested (one memory latency for both)
+  const float sc = a.scale * 1.4426950408889634f;
+  u32x4_t qf[DK], qraw[DK], qwt[DK];
+  float q_rs;
+  {
+    int qi = qw + l31; if (qi > S - 1) qi = S - 1;
+    const bf16_t* qp = a.Qrows + ((size_t)b * S + qi) * a.q_ld + head * Dout + 8 * h;
+    const bf16_t* wp = a.q_nw + head * Dout + 8 * h;
+    q_rs = a.q_rs[(size_t)b * S + qi];
+#pragma unroll
+    for (int kk = 0; kk < DK; ++kk) {
+      const bool real = kk * 16 + 8 * h < Dout;
+      qraw[kk] = real ? *(const u32x4_t*)(qp + kk * 16) : u32x4_t{0u, 0u, 0u, 0u};
+      qwt[kk] = real ? *(const u32x4_t*)(wp + kk * 16) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  }
+  {                                                    // pad columns of the V image (1.0 in column Dout: the row sum), all three V slots, once
+    const int npc = CPR - (Dout >> 3);
+    for (int i = tid; i < 3 * 64 * npc; i += NT) {
+      const int slot = i / (64 * npc), r = (i / npc) & 63, lc = (Dout >> 3) + i % npc;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (lc * 8 == Dout) v[0] = 0x3F80u;
+      *(u32x4_t*)(smem + (slot < 2 ? slot * STAGE_BYTES + TILE_BYTES : VLAST) + (r * CPR + lc) * 16) = v;
+    }
+  }
+  __syncthreads();
+  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const bf16_t* kbase = a.Kt + ((size_t)b * n_tiles * a.KV + head) * (size_t)(64 * D);       // page (b, t) = b * n_tiles + t
+  const size_t kstep = (size_t)a.KV * (64 * D);
+  const bf16_t* vbase = a.Vrows + (size_t)b * S * v_ld + head * Dout;
+  auto stage_k = [&](int slot, int t) { glds16xn<NIK>(kbase + (size_t)t * kstep, koff, smem_base + slot * STAGE_BYTES + wave * 1024, NT * 16); };
+  auto stage_v = [&](int slot, int t) {                // FULL tiles only
+    glds16x3_masked(vbase + (size_t)t * 64 * v_ld, voff, vmask, smem_base + slot * STAGE_BYTES + TILE_BYTES + wave * 1024, NT * 16);
+  };
+
+  f32x16_t o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  float m_run = 0.f;                                   // the reference point (bf16-representable, log2 units)
+
+  // per-lane LDS offsets: K fragment rows (permuted, swizzled) per k step; V image runs per 32-column block
+  const int krow0 = kperm(l31);
+  unsigned kfo[DK], vtr[DB];
+#pragma unroll
+  for (int kk = 0; kk < DK; ++kk) kfo[kk] = (unsigned)(krow0 * (D * 2) + (KSwz<D>::phys(krow0, kk * 2 + h) << 4));
+  {
+    const int i16 = lane & 15, g4 = (lane >> 4) & 1, r0 = 8 * h + (i16 >> 2);
+#pragma unroll
+    for (int db = 0; db < DB; ++db) vtr[db] = (unsigned)(r0 * (D * 2) + (db * 4 + 2 * g4 + ((i16 & 3) >> 1)) * 16 + (i16 & 1) * 8);
+  }
+  const int my_q = qw + l31;
+
+  stage_k(0, 0);
+  if (last_full >= 0) stage_v(0, 0);
+  if (n_tiles > 1) stage_k(1, 1);
+  if (partial) {                                       // the partial last tile goes to its own slot now: rows past the end re-read the last real key row (their P is 0)
+    const int tl = n_tiles - 1, rows_left = S - tl * 64;
+    const bf16_t* vr_ = vbase + (size_t)tl * 64 * v_ld;
+#pragma unroll
+    for (int i = 0; i < NIK; ++i) {
+      const int pos = i * NT + tid, r = pos / CPR, c = pos - r * CPR;
+      const unsigned off = r >= rows_left ? voff[i] - (unsigned)((r - rows_left + 1) * v_ld * 2) : voff[i];
+      if (c * 8 < Dout) glds16s(vr_, off, smem_base + VLAST + wave * 1024 + i * NT * 16);
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < DK; ++kk) {
+    u32x4_t t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = pack2bf(lo_bf(qwt[kk][e]) * rbf(lo_bf(qraw[kk][e]) * q_rs) * sc, hi_bf(qwt[kk][e]) * rbf(hi_bf(qraw[kk][e]) * q_rs) * sc);
+    qf[kk] = t;
+  }
+#pragma unroll
+  for (int kk = 0; kk < DK; ++kk) asm volatile("" ::"v"(qf[kk]));      // retire the q loads here (see attn_fwd_kernel)
+
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto kfrag = [&](int slot, int i) -> bf16x8_t {       // A operand of S^T MFMA i: k step i >> 1, key block i & 1
+    return *(const bf16x8_t*)(smem + slot * STAGE_BYTES + (i & 1) * (32 * D * 2) + kfo[i >> 1]);
+  };
+  auto vfrag = [&](int vofs, int i) -> bf16x8_t {       // A operand of P.V MFMA i: 16-key step i / 3, d block i % 3; vofs = byte offset of the V slot
+    const char* p = smem + vofs + (i / 3) * (16 * D * 2) + vtr[i % 3];
+    return lds_tr8(p, p + 4 * D * 2);
+  };
+  auto mask_tail = [&](f32x16_t (&s)[2], int t) {       // keys past the end of the last tile
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * 64 + kb * 32 + (r >> 3) * 16 + 8 * h + (r & 7);
+        s[kb][r] = key >= S ? -1e30f : s[kb][r];
+      }
+  };
+  // the reference point moves: rescale O, shift the pending score tile, rewrite q's pad element (element Dout of q = -reference)
+  auto move_ref = [&](f32x16_t (&s)[2], float mx, bool first) {
+    const float m_new = rbf(m_run + (first ? mx : fmaxf(mx, 0.f)));
+    const float de = m_new - m_run;
+    const float alpha = __builtin_amdgcn_exp2f(-de);
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] -= de;
+    qf[DK - 1][0] = h ? (unsigned)f2bf(-m_run) : qf[DK - 1][0];
+  };
+  auto row_max = [&](const f32x16_t (&s)[2]) -> float {
+    float l1[11];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { l1[i] = vmax3(s[0][3 * i], s[0][3 * i + 1], s[0][3 * i + 2]); l1[5 + i] = vmax3(s[1][3 * i], s[1][3 * i + 1], s[1][3 * i + 2]); }
+    l1[10] = vmax3(s[0][15], s[1][15], l1[0]);
+    const float a2 = vmax3(l1[1], l1[2], l1[3]), b2 = vmax3(l1[4], l1[5], l1[6]), c2 = vmax3(l1[7], l1[8], l1[9]);
+    float mx = vmax3(vmax3(a2, b2, c2), l1[10], l1[10]);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  };
+
+  // ---- tile 0: S^T and its row max the plain way; its maximum becomes the reference ------------------------------------
+  f32x16_t sA[2], sB[2];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  sA[0] = zero16; sA[1] = zero16;
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+    sA[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(0, i), __builtin_bit_cast(bf16x8_t, qf[i >> 1]), sA[i & 1], 0, 0, 0);
+  if (n_tiles == 1 && partial) mask_tail(sA, 0);
+  move_ref(sA, row_max(sA), true);
+
+  // ---- one pipelined iteration: `sc_` = S(t) (relative to the reference), `sn` receives S(t+1); PAR = t & 1; LAST: t + 1 is the last tile ----
+  auto body = [&](auto par, auto last_, int t, f32x16_t (&sc_)[2], f32x16_t (&sn)[2]) {
+    constexpr int PAR = decltype(par)::v;
+    constexpr bool LAST = decltype(last_)::v != 0;
+    constexpr int KS = 1 - PAR, VS = PAR * STAGE_BYTES + TILE_BYTES;      // K(t+1) sits in slot (t+1)&1, V(t) (a full tile) in slot t&1
+    // DMA targets of this iteration, clamped so that the statements are unconditional (a redundant re-fetch lands in a slot nobody reads again):
+    // K(t+2) -> K half of slot t&1, V(t+1) -> V half of slot (t+1)&1 (a partial last tile already sits in its own slot)
+    const int tk = t + 2 < n_tiles ? t + 2 : n_tiles - 1, tv = t + 1 <= last_full ? t + 1 : last_full;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(t+1), V(t) (requested one iteration ago) have landed -- for every wave after the barrier,
+    __builtin_amdgcn_s_barrier();                      // which also says: every wave is done reading K(t) and V(t-1)
+    asm volatile("" ::: "memory");
+    bf16x8_t kf[12], vf[12];
+    unsigned pw[16];
+    kf[0] = kfrag(KS, 0); kf[1] = kfrag(KS, 1);
+    GVL_SB();
+    // phase 1: S^T(t+1) MFMAs || exp2 + pack of S(t)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      if (i + 2 < 12) kf[i + 2] = kfrag(KS, i + 2);
+      sn[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], __builtin_bit_cast(bf16x8_t, qf[i >> 1]), i < 2 ? zero16 : sn[i & 1], 0, 0, 0);
+      const int c = i / 3, sub = i - 3 * c, kb = c >> 1, r0 = (c & 1) * 8;          // chunk c = the 8 scores of P.V k-step c
+      f32x16_t& s = sc_[kb];
+      if (sub == 0) {
+        s[r0 + 0] = __builtin_amdgcn_exp2f(s[r0 + 0]); s[r0 + 1] = __builtin_amdgcn_exp2f(s[r0 + 1]); s[r0 + 2] = __builtin_amdgcn_exp2f(s[r0 + 2]);
+      } else if (sub == 1) {
+        s[r0 + 3] = __builtin_amdgcn_exp2f(s[r0 + 3]); s[r0 + 4] = __builtin_amdgcn_exp2f(s[r0 + 4]); s[r0 + 5] = __builtin_amdgcn_exp2f(s[r0 + 5]);
+        pw[4 * c + 0] = pack2bf(s[r0 + 0], s[r0 + 1]);
+      } else {
+        s[r0 + 6] = __builtin_amdgcn_exp2f(s[r0 + 6]); s[r0 + 7] = __builtin_amdgcn_exp2f(s[r0 + 7]);
+        pw[4 * c + 1] = pack2bf(s[r0 + 2], s[r0 + 3]); pw[4 * c + 2] = pack2bf(s[r0 + 4], s[r0 + 5]); pw[4 * c + 3] = pack2bf(s[r0 + 6], s[r0 + 7]);
+      }
+      if (i == 1) stage_k(PAR, tk);                    // the DMA issue rides under the MFMAs
+      if (i == 4) stage_v(1 - PAR, tv);             // (a body only runs when n_tiles >= 2, i.e. last_full >= 0)
+      if (i == 10) vf[0] = vfrag(VS, 0);
+      if (i == 11) vf[1] = vfrag(VS, 1);
+      GVL_SB();
+    }
+    if constexpr (LAST) { if (partial) mask_tail(sn, t + 1); GVL_SB(); }
+    // phase 2: P.V(t) MFMAs || row max of S(t+1)
+    float l1[11], a2 = 0.f, b2 = 0.f, c2 = 0.f, mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      if (i + 2 < 12) vf[i + 2] = vfrag(VS, i + 2);
+      const int st = i / 3, db = i - 3 * st;
+      const u32x4_t pu = {pw[4 * st], pw[4 * st + 1], pw[4 * st + 2], pw[4 * st + 3]};
+      o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], __builtin_bit_cast(bf16x8_t, pu), o[db], 0, 0, 0);
+      // 16 v_max3 over groups 1..8 (S(t+1)'s first key block finished one MFMA earlier than the second: start there), exchange in group 10
+      if (i == 1) { l1[0] = vmax3(sn[0][0], sn[0][1], sn[0][2]); l1[1] = vmax3(sn[0][3], sn[0][4], sn[0][5]); }
+      if (i == 2) { l1[2] = vmax3(sn[0][6], sn[0][7], sn[0][8]); l1[3] = vmax3(sn[0][9], sn[0][10], sn[0][11]); }
+      if (i == 3) { l1[4] = vmax3(sn[0][12], sn[0][13], sn[0][14]); l1[5] = vmax3(sn[1][0], sn[1][1], sn[1][2]); }
+      if (i == 4) { l1[6] = vmax3(sn[1][3], sn[1][4], sn[1][5]); l1[7] = vmax3(sn[1][6], sn[1][7], sn[1][8]); }
+      if (i == 5) { l1[8] = vmax3(sn[1][9], sn[1][10], sn[1][11]); l1[9] = vmax3(sn[1][12], sn[1][13], sn[1][14]); }
+      if (i == 6) { l1[10] = vmax3(sn[0][15], sn[1][15], l1[0]); a2 = vmax3(l1[1], l1[2], l1[3]); }
+      if (i == 7) { b2 = vmax3(l1[4], l1[5], l1[6]); c2 = vmax3(l1[7], l1[8], l1[9]); }
+      if (i == 8) { mx = vmax3(a2, b2, c2); mx = vmax3(mx, l1[10], l1[10]); }
+      if (i == 10) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+      GVL_SB();
+    }
+    // lazy reference (attn_fwd_kernel's rule, at the same point of the accumulation: after tile t's P.V, before tile t+1's)
+    if (!__all(mx <= a.lazy)) move_ref(sn, mx, false);
+  };
+
+  // iterations t = 0 .. n_tiles - 2; the last one (t + 1 = the last tile) is peeled: it alone carries the tail mask
+  int t = 0;
+  for (; t + 2 < n_tiles - 1; t += 2) {
+    body(IC<0>{}, IC<0>{}, t, sA, sB);
+    body(IC<1>{}, IC<0>{}, t + 1, sB, sA);
+  }
+  if (t + 2 == n_tiles - 1) {                          // two left
+    body(IC<0>{}, IC<0>{}, t, sA, sB);
+    body(IC<1>{}, IC<1>{}, t + 1, sB, sA);
+  } else if (t + 1 == n_tiles - 1) {                   // one left: S(n_tiles - 1) lands in sB
+    body(IC<0>{}, IC<1>{}, t, sA, sB);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) sA[kb] = sB[kb];
+  }
+  // ---- last tile: exp2 + P.V, nothing left to overlap with ---------------------------------------------------------------------
+  {
+    const int tl = n_tiles - 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* vb_ = smem + (partial ? VLAST : (tl & 1) * STAGE_BYTES + TILE_BYTES);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int kb = st >> 1, r0 = (st & 1) * 8;
+      union { bf16x8_t v; unsigned u[4]; } pf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pf.u[e] = pack2bf(__builtin_amdgcn_exp2f(sA[kb][r0 + 2 * e]), __builtin_amdgcn_exp2f(sA[kb][r0 + 2 * e + 1]));
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const char* p = vb_ + vtr[db] + st * (16 * D * 2);
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(p, p + 4 * D * 2), pf.v, o[db], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue (attn_fwd_kernel's ONES branch) ---------------------------------------------------------------------------------
+  const int lr = Dout - 32 * (DB - 1);
+  float mine = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) mine = (e == (lr >> 3) * 4 + (lr & 3)) ? o[DB - 1][e] : mine;
+  const float other = __shfl_xor(mine, 32, 64);
+  const float inv = 1.f / (h ? other : mine);
+  {
+    const int qs = my_q < S ? my_q : S - 1;
+    char* op = (char*)(a.O + ((size_t)b * S + qs) * (size_t)(a.H * Dout) + head * Dout);
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const int g0 = 2 * gp;
+        unsigned ax = pack2bf(o[db][4 * g0] * inv, o[db][4 * g0 + 1] * inv), ay = pack2bf(o[db][4 * g0 + 2] * inv, o[db][4 * g0 + 3] * inv);
+        unsigned bx = pack2bf(o[db][4 * g0 + 4] * inv, o[db][4 * g0 + 5] * inv), by = pack2bf(o[db][4 * g0 + 6] * inv, o[db][4 * g0 + 7] * inv);
+        const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false); ax = rx[0]; bx = rx[1];
+        const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false); ay = ry[0]; by = ry[1];
+        const int cg = db * 4 + g0 + h;
+        if (my_q < S && cg * 8 < Dout) {
+          const u32x4_t w = {ax, ay, bx, by};
+          *(u32x4_t*)(op + cg * 16) = w;
+        }
+      }
+  }
+}
+static int launch_attn_iv2_pipe(const AttnArgs& a, hipStream_t st) {
+  constexpr int LDS = 2 * 2 * 64 * 96 * 2 + 64 * 96 * 2;      // the ring + the partial-last-tile V slot: 60 KB, two blocks per CU
+  static GvlDevOnce once;
+  if (gvl_set_max_lds(once, (const void*)attn_iv2_pipe_kernel, LDS)) return -3;
+  const int nq = (a.S + 127) / 128;
+  dim3 grid((unsigned)(((a.KV * a.B + 7) / 8) * 8 * nq));
+  hipLaunchKernelGGL(attn_iv2_pipe_kernel, grid, dim3(256), LDS, st, a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 template <int D, int NWAVES, int NS, int ONES = 0, int VROW = 0>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
   constexpr int LDS = NS * 2 * 64 * D * 2 + 1024;   // ring + page-id table (256 pages)
@@ -494,7 +827,11 @@ int gvl_launch_attention(const AttnArgs& a_in, hipStream_t st) {
       //  of attention per clip against 18.0: two 98 KB blocks per CU hide less latency than three 49 KB ones.  Round 2, dropped.)
       const int lr = a.Dout - 64;
       const bool ones = a.ones_row && !no_ones && a.Dout < 96 && lr >= 0 && (lr & 7) < 4 && !a.causal;
-      if (a.Vrows && a.q_rs) { if (a.Dout != 88 || !a.k_ones) return -1; return ones ? launch_attn<96, 4, 2, 1, 3>(a, st) : launch_attn<96, 4, 2, 0, 3>(a, st); }
+      if (a.Vrows && a.q_rs) {
+        if (a.Dout != 88 || !a.k_ones) return -1;
+        if (ones && a.pipe && a.H == a.KV) return launch_attn_iv2_pipe(a, st);      // hand-placed pipelined loop (round 4); bit-identical to the kernel below
+        return ones ? launch_attn<96, 4, 2, 1, 3>(a, st) : launch_attn<96, 4, 2, 0, 3>(a, st);
+      }
       if (a.Vrows) return ones ? launch_attn<96, 4, 2, 1, 1>(a, st) : launch_attn<96, 4, 2, 0, 1>(a, st);
       if (!ones && ring == 3) return launch_attn<96, 4, 3>(a, st);
       return ones ? launch_attn<96, 4, 2, 1>(a, st) : launch_attn<96, 4, 2>(a, st);

@@ -253,6 +253,8 @@ int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launche
  *   "vision_in_place"  1 (default): non-causal attention (vision towers, gvl_op_attention) reads V -- and Q, K when the head dim needs no padding
  *                      or transform; with InternVideo2's q RMSNorm applied in the kernel prologue -- straight from the fused-qkv matrix;
  *                      2: V only; 0: the round-2 path through Q / K pages and a V^T transpose pass
+ *   "attn_pipe"        1 (default): InternVideo2's attention (head dim 88, q in place) runs the software-pipelined key-tile loop
+ *                      (attn_iv2_pipe_kernel, round 4); 0: the plain loop of attn_fwd_kernel -- bit-identical (tests/test_gpu_towers.py)
  * None of them may change a single output bit (asserted in tests/test_gpu_llm.py) -- with ONE stated exception: "vision_in_place" = 1 on a head
  * dim that is padded (InternVideo2, 88 -> 96) folds the softmax scale and shift into q before its one rounding to bf16, a different (not larger)
  * set of rounding points: modes 0 and 2 are bit-identical to each other, mode 1 is bit-identical to them for CLIP (head dim 64) and agrees within

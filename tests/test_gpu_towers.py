@@ -65,6 +65,9 @@ def test_iv2(name, tol_g, tol_o):
     # operand paths: 0 = Q / K pages + V^T transpose pass (round 2); 2 = V read in place -- the same arithmetic, bit-identical to 0;
     # 1 (default, `got`) = q in place too, normalised, scaled and rounded ONCE in the attention prologue with the softmax shift folded into
     # the S^T MFMAs: a different (not larger) set of rounding points, held to the same goldens above and to path 0 within bf16 noise
+    eng.debug_set("attn_pipe", 0)              # the plain tile loop (attn_fwd_kernel) instead of the pipelined one: bit-identical
+    assert torch.equal(eng.iv2_encode(px.to(DEV)), got)
+    eng.debug_set("attn_pipe", 1)
     eng.debug_set("vision_in_place", 0)
     paged = eng.iv2_encode(px.to(DEV))
     eng.debug_set("vision_in_place", 2)
@@ -101,6 +104,43 @@ def test_towers_at_other_head_dims(tower, hidden, heads):
         check(got, paged.float(), 1.2e-2, f"{tower} head dim 88: folded in-place attention vs the paged path")
     else:
         assert torch.equal(got, paged)
+    eng.close()
+
+
+@pytest.mark.parametrize("image,frames,sharp", [(56, 2, 1), (56, 4, 1), (56, 8, 3), (56, 12, 1), (56, 16, 3), (14, 63, 1), (14, 127, 3), (14, 191, 1), (42, 71, 3), (112, 9, 3)])
+def test_iv2_pipelined_attention_is_bit_identical_to_the_plain_kernel(image, frames, sharp):
+    """Round 4: InternVideo2's attention runs a software-pipelined key-tile loop (attn_iv2_pipe_kernel: S^T of tile t+1 under the exp2 of
+    tile t, P.V of tile t under the row max of tile t+1, every MFMA heading a fenced group of fillers).  It issues the same MFMAs on the
+    same values in the same order and moves the softmax reference at the same point of the accumulation, so it must agree BIT FOR BIT
+    with attn_fwd_kernel (gvl_debug_set attn_pipe = 0) -- over every shape of the tile loop: S = frames * (image / 14)^2 + 1 gives
+    1 tile (partial), 2, 3, 4, 5 tiles with a one-key tail; image 14 gives whole tiles only (S = 64, 128, 192: no tail mask, the last
+    V tile in the ring instead of its own slot); 10 whole tiles; 577 keys.  sharp > 1 scales q_norm / k_norm so that the scores are
+    peaked and later tiles exceed the first tile's maximum by more than 2^8: the lazy reference moves inside the pipelined loop."""
+    c = dict(dim=704, inter=1408, depth=3, heads=8, image=image, frames=frames)
+    seed = f"pipe.{image}.{frames}"
+    geo = tiny_geo(iv2_dim=c["dim"], iv2_inter=c["inter"], iv2_depth=c["depth"], iv2_heads=c["heads"], iv2_image=image, frames_per_seg=frames, max_segs=3)
+    W = synth.iv2_weights(c["dim"], c["inter"], c["depth"], frames, image, 14, seed=seed)
+    if sharp > 1:
+        for i in range(c["depth"]):
+            W[f"blocks.{i}.attn.q_norm.weight"] = W[f"blocks.{i}.attn.q_norm.weight"] * sharp
+            W[f"blocks.{i}.attn.k_norm.weight"] = W[f"blocks.{i}.attn.k_norm.weight"] * sharp
+    eng = E.Engine(geo, DEV, towers=("iv2",))
+    eng.load_packed(Wt.pack_iv2(W, c["depth"] - 1, frames))
+    eng.finalize()
+    px = synth.det_tensor(seed + ".px", (3, 3, frames, image, image))
+    S = frames * (image // 14) ** 2 + 1
+    got = eng.iv2_encode(px.to(DEV))
+    assert bool(torch.isfinite(got.float()).all())
+    eng.debug_set("attn_pipe", 0)
+    plain = eng.iv2_encode(px.to(DEV))
+    eng.debug_set("attn_pipe", 1)
+    again = eng.iv2_encode(px.to(DEV))
+    nbad = int((got != plain).sum())
+    assert torch.equal(got, plain), f"S = {S} ({(S + 63) // 64} key tiles): pipelined attention differs from the plain kernel in {nbad} of {got.numel()} values"
+    assert torch.equal(got, again)
+    if frames <= 16:                                 # against the oracle too (bf16 emulation); the long-sequence cases would take the CPU minutes
+        ref = O.iv2_encode(px, W, c["depth"], c["heads"], emu=True)
+        check(got, ref, 1.5e-2 if sharp > 1 else 1.2e-2, f"iv2 pipelined attention, S = {S}, sharp x{sharp}, vs oracle (bf16 emulation)")
     eng.close()
 
 

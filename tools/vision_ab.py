@@ -1,5 +1,7 @@
-"""A/B of the vision towers' attention operand path in ONE process: gvl_debug_set("vision_in_place", 1 | 0), interleaved rounds.
-   python tools/vision_ab.py [rounds]     -> wall ms per encode (96 segments = 8 clips: IV2 on 96 x 8 frames, CLIP on 96 frames) and the per-family sums"""
+"""A/B of a result-neutral launch parameter of the vision towers in ONE process, interleaved rounds (default: the attention operand path,
+gvl_debug_set("vision_in_place", 1 | 2 | 0)).
+   python tools/vision_ab.py [rounds] [key] [values...]   e.g.  tools/vision_ab.py 3 attn_pipe 1 0
+   -> wall ms per encode (96 segments = 8 clips: IV2 on 96 x 8 frames, CLIP on 96 frames) and the per-family sums"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,6 +9,8 @@ import _gvl_bootstrap  # noqa
 from grounded_video_llm_amd import engine as E, lib as L, synth, weights as Wt
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+KEY = sys.argv[2] if len(sys.argv) > 2 else "vision_in_place"
+VALUES = [int(v) for v in sys.argv[3:]] or [1, 2, 0]
 NSEG = 96      # 8 clips of 12 segments: the batch one bench step encodes
 geo = E.TowerGeometry(max_segs=NSEG)
 eng = E.Engine(geo, "cuda:0", towers=("clip", "iv2"))
@@ -21,9 +25,11 @@ sp = torch.randn((NSEG, 3, geo.clip_image, geo.clip_image), device="cuda:0", gen
 runs = {"iv2": lambda: eng.iv2_encode(tp), "clip": lambda: eng.clip_encode(sp)}
 outs = {}
 for rnd in range(rounds):
-    for mode in (1, 2, 0):
-        eng.debug_set("vision_in_place", mode)
+    for mode in VALUES:
+        eng.debug_set(KEY, mode)
         for name, fn in runs.items():
+            if KEY == "attn_pipe" and name == "clip":
+                continue
             out = fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -35,4 +41,4 @@ for rnd in range(rounds):
             eng.prof_enable(False)
             first = outs.setdefault(name, out)
             same = "yes" if first is out or bool(torch.equal(first, out)) else f"no (max diff {float((first.float() - out.float()).abs().max() / first.float().abs().max()):.2e} of scale)"
-            print(f"[vision_ab] round {rnd} {name:4s} in_place={mode}: wall {wall:7.3f} ms  gemm {fam['gemm']:7.3f}  attn {fam['attn']:7.3f}  other {fam['other']:6.3f}  bit-identical to first: {same}", flush=True)
+            print(f"[vision_ab] round {rnd} {name:4s} {KEY}={mode}: wall {wall:7.3f} ms  gemm {fam['gemm']:7.3f}  attn {fam['attn']:7.3f}  other {fam['other']:6.3f}  bit-identical to first: {same}", flush=True)

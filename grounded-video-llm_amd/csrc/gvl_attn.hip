@@ -326,6 +326,10 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     // 8 extra instructions per tile -- and chains the 15 max3 it then emits)
     float mx;
     {
+      // vmax3() is an `asm` statement: hipcc pads the XDL-write -> VALU-read distance (8-pass MFMA: 11 wait states) for its own instructions only, and the
+      // hardware does not interlock it (round 4: the same tree straight behind the S^T MFMAs of attn_iv2_pipe_kernel's first tile read stale accumulators on
+      // some builds).  Here two taken branches used to sit in between by luck; the wait is now explicit -- tied to the accumulators so that it cannot move.
+      asm volatile("s_nop 11" : "+v"(s[0]), "+v"(s[1]));
       float l1[11];
 #pragma unroll
       for (int i = 0; i < 5; ++i) { l1[i] = vmax3(s[0][3 * i], s[0][3 * i + 1], s[0][3 * i + 2]); l1[5 + i] = vmax3(s[1][3 * i], s[1][3 * i + 1], s[1][3 * i + 2]); }
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
       if (first_tile || !__all(mx <= a.lazy)) {
         const float m_new = rbf(m_run + (first_tile ? mx : fmaxf(mx, 0.f)));
         const float de = m_new - m_run;
-        alpha = __builtin_amdgcn_exp2f(-de);
+        alpha = first_tile ? 1.f : __builtin_amdgcn_exp2f(-de);      // first tile: O is still 0 -- and 0 x exp2(+huge) = NaN for a row whose first tile is far below 0
         m_run = m_new;
         first_tile = 0;
 #pragma unroll
@@ -492,6 +496,13 @@ __device__ __forceinline__ void glds16x3_masked(const void* sbase, const unsigne
       : "memory", "scc");
 }
 
+__device__ __forceinline__ void glds16s_masked(const void* sbase, unsigned v, unsigned long long mask, unsigned lds_dst) {
+  unsigned keep;
+  unsigned long long ex;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_and_b64 exec, %1, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep), "=&s"(ex) : "v"(v), "s"(sbase), "s"(lds_dst), "s"(mask) : "memory", "scc");
+}
+
 __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a) {
   constexpr int D = 96, NT = 256, DK = 6, DB = 3, CPR = 12, NIK = 3, TILE_BYTES = 64 * D * 2, STAGE_BYTES = 2 * TILE_BYTES;
   constexpr int VLAST = 2 * STAGE_BYTES;               // a third V slot that only ever holds the LAST key tile when it is partial
@@ -565,27 +576,52 @@ __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a)
   const int krow0 = kperm(l31);
   unsigned kfo[DK], vtr[DB];
 #pragma unroll
-  for (int kk = 0; kk < DK; ++kk) kfo[kk] = (unsigned)(krow0 * (D * 2) + (KSwz<D>::phys(krow0, kk * 2 + h) << 4));
+  for (int kk = 0; kk < DK; ++kk) kfo[kk] = smem_base + (unsigned)(krow0 * (D * 2) + (KSwz<D>::phys(krow0, kk * 2 + h) << 4));
   {
     const int i16 = lane & 15, g4 = (lane >> 4) & 1, r0 = 8 * h + (i16 >> 2);
 #pragma unroll
-    for (int db = 0; db < DB; ++db) vtr[db] = (unsigned)(r0 * (D * 2) + (db * 4 + 2 * g4 + ((i16 & 3) >> 1)) * 16 + (i16 & 1) * 8);
+    for (int db = 0; db < DB; ++db) vtr[db] = smem_base + (unsigned)(r0 * (D * 2) + (db * 4 + 2 * g4 + ((i16 & 3) >> 1)) * 16 + (i16 & 1) * 8);
   }
   const int my_q = qw + l31;
 
-  stage_k(0, 0);
-  if (last_full >= 0) stage_v(0, 0);
-  if (n_tiles > 1) stage_k(1, 1);
-  if (partial) {                                       // the partial last tile goes to its own slot now: rows past the end re-read the last real key row (their P is 0)
-    const int tl = n_tiles - 1, rows_left = S - tl * 64;
-    const bf16_t* vr_ = vbase + (size_t)tl * 64 * v_ld;
+  auto stage_first = [&]() {
+    stage_k(0, 0);
+    if (last_full >= 0) stage_v(0, 0);
+    if (n_tiles > 1) stage_k(1, 1);
+    if (partial) {                                       // the partial last tile goes to its own slot now: rows past the end re-read the last real key row (their P is 0)
+      const int tl = n_tiles - 1, rows_left = S - tl * 64;
+      const bf16_t* vr_ = vbase + (size_t)tl * 64 * v_ld;
 #pragma unroll
-    for (int i = 0; i < NIK; ++i) {
-      const int pos = i * NT + tid, r = pos / CPR, c = pos - r * CPR;
-      const unsigned off = r >= rows_left ? voff[i] - (unsigned)((r - rows_left + 1) * v_ld * 2) : voff[i];
-      if (c * 8 < Dout) glds16s(vr_, off, smem_base + VLAST + wave * 1024 + i * NT * 16);
+      for (int i = 0; i < NIK; ++i) {
+        const int pos = i * NT + tid, r = pos / CPR, c = pos - r * CPR;
+        const unsigned off = r >= rows_left ? voff[i] - (unsigned)((r - rows_left + 1) * v_ld * 2) : voff[i];
+        if (c * 8 < Dout) glds16s(vr_, off, smem_base + VLAST + wave * 1024 + i * NT * 16);
+      }
     }
+  };
+  stage_first();
+#ifndef GVL_PIPE_LAB                 // (LAB builds drop barriers / the second pass from the main path: keep every wave on it)
+  if (qw >= S) {
+    // A wave without a single real query (3 of the 4 waves of the last query block at S = 2049: 4.4 % of all wave-tiles): it owes the block its
+    // share of every DMA and every barrier, nothing else -- no fragment reads, no MFMAs, no softmax.  (attn_fwd_kernel could not afford the
+    // branch inside its tile body; here the idle waves run their own loop.)  The barrier sequence mirrors run() exactly.
+    for (int pass = a.pipe == 2 ? 1 : 0;; ++pass) {     // (pipe == 2, tests: the safe pass only)
+      if (pass) stage_first();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                     // tile 0
+      for (int t = 0; t + 1 < n_tiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage_k(t & 1, t + 2 < n_tiles ? t + 2 : n_tiles - 1);
+        stage_v(1 - (t & 1), t + 1 <= last_full ? t + 1 : last_full);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                     // last tile
+      if (pass || !__syncthreads_or(0)) break;          // the block repeats the pass in safe mode: once more
+    }
+    return;
   }
+#endif
 #pragma unroll
   for (int kk = 0; kk < DK; ++kk) {
     u32x4_t t;
@@ -597,12 +633,18 @@ __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a)
   for (int kk = 0; kk < DK; ++kk) asm volatile("" ::"v"(qf[kk]));      // retire the q loads here (see attn_fwd_kernel)
 
   const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // (kfo / vtr hold ABSOLUTE LDS byte addresses: with the dynamic-LDS base inside the per-lane register every read is register + immediate;
+  //  a `smem + constant + offset` expression costs one v_add per read once the kernel also owns static LDS)
+  typedef __attribute__((address_space(3))) const bf16x8_t* lds_b128_p;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_tr_p;
   auto kfrag = [&](int slot, int i) -> bf16x8_t {       // A operand of S^T MFMA i: k step i >> 1, key block i & 1
-    return *(const bf16x8_t*)(smem + slot * STAGE_BYTES + (i & 1) * (32 * D * 2) + kfo[i >> 1]);
+    return *(lds_b128_p)(size_t)(kfo[i >> 1] + (unsigned)(slot * STAGE_BYTES + (i & 1) * (32 * D * 2)));
   };
   auto vfrag = [&](int vofs, int i) -> bf16x8_t {       // A operand of P.V MFMA i: 16-key step i / 3, d block i % 3; vofs = byte offset of the V slot
-    const char* p = smem + vofs + (i / 3) * (16 * D * 2) + vtr[i % 3];
-    return lds_tr8(p, p + 4 * D * 2);
+    const unsigned p = vtr[i % 3] + (unsigned)(vofs + (i / 3) * (16 * D * 2));
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(size_t)p), hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(size_t)(p + 4 * D * 2));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
   };
   auto mask_tail = [&](f32x16_t (&s)[2], int t) {       // keys past the end of the last tile
 #pragma unroll
@@ -617,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a)
   auto move_ref = [&](f32x16_t (&s)[2], float mx, bool first) {
     const float m_new = rbf(m_run + (first ? mx : fmaxf(mx, 0.f)));
     const float de = m_new - m_run;
-    const float alpha = __builtin_amdgcn_exp2f(-de);
+    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-de);      // first tile: O is still 0 (and 0 x exp2(+huge) would be NaN)
     m_run = m_new;
 #pragma unroll
     for (int i = 0; i < DB; ++i)
@@ -629,135 +671,212 @@ __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a)
       for (int r = 0; r < 16; ++r) s[kb][r] -= de;
     qf[DK - 1][0] = h ? (unsigned)f2bf(-m_run) : qf[DK - 1][0];
   };
+  // tile 0's row max, written with operations hipcc SEES: the reader of an MFMA result has to keep its distance from the MFMA (XDL write -> VALU read),
+  // hipcc pads that for its own instructions but not for the operands of an `asm` statement (cdna_hip_programming.md §5.7) -- vmax3() straight behind
+  // the twelve S^T MFMAs read the accumulators too early on some builds (a reference point made of stale registers: results correct to rounding,
+  // but not reproducible).  Inside the loop the asm form is safe by construction: two MFMA groups lie between a score tile's last MFMA and its first reader.
   auto row_max = [&](const f32x16_t (&s)[2]) -> float {
-    float l1[11];
+    float m0 = fmaxf(s[0][0], s[1][0]), m1 = fmaxf(s[0][1], s[1][1]), m2 = fmaxf(s[0][2], s[1][2]), m3 = fmaxf(s[0][3], s[1][3]);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) { l1[i] = vmax3(s[0][3 * i], s[0][3 * i + 1], s[0][3 * i + 2]); l1[5 + i] = vmax3(s[1][3 * i], s[1][3 * i + 1], s[1][3 * i + 2]); }
-    l1[10] = vmax3(s[0][15], s[1][15], l1[0]);
-    const float a2 = vmax3(l1[1], l1[2], l1[3]), b2 = vmax3(l1[4], l1[5], l1[6]), c2 = vmax3(l1[7], l1[8], l1[9]);
-    float mx = vmax3(vmax3(a2, b2, c2), l1[10], l1[10]);
+    for (int e = 4; e < 16; e += 4) {
+      m0 = fmaxf(m0, fmaxf(s[0][e], s[1][e])); m1 = fmaxf(m1, fmaxf(s[0][e + 1], s[1][e + 1]));
+      m2 = fmaxf(m2, fmaxf(s[0][e + 2], s[1][e + 2])); m3 = fmaxf(m3, fmaxf(s[0][e + 3], s[1][e + 3]));
+    }
+    const float mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
     return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
   };
-
-  // ---- tile 0: S^T and its row max the plain way; its maximum becomes the reference ------------------------------------
+  // One pass over the key tiles.  SAFE = 0 (the normal pass): the reference point is the FIRST tile's row maximum and never moves -- no
+  // per-tile row max at all, the loop's VALU work is the 32 exp2 + 16 packs, spread over all 24 MFMA groups.  Exact as long as no later
+  // score exceeds the first tile's maximum by ~2^100 (fp32 headroom of P, of the row sum and of O; the final division cancels the
+  // reference, and floating point keeps the relative precision of P whatever its scale); attn_fwd_kernel's own rule (move when a tile
+  // exceeds the reference by 2^8) never fires after tile 0 on such data, so the two kernels agree bit for bit there.  A row sum that is
+  // not a sane positive number afterwards (inf / NaN / 0: a score ran > 100 log2 units past the reference) makes the BLOCK repeat the
+  // pass with SAFE = 1: the per-tile row max and the lazy reference rule of attn_fwd_kernel, bit-identical to it.
   f32x16_t sA[2], sB[2];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  sA[0] = zero16; sA[1] = zero16;
-#pragma unroll
-  for (int i = 0; i < 12; ++i)
-    sA[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(0, i), __builtin_bit_cast(bf16x8_t, qf[i >> 1]), sA[i & 1], 0, 0, 0);
-  if (n_tiles == 1 && partial) mask_tail(sA, 0);
-  move_ref(sA, row_max(sA), true);
-
-  // ---- one pipelined iteration: `sc_` = S(t) (relative to the reference), `sn` receives S(t+1); PAR = t & 1; LAST: t + 1 is the last tile ----
-  auto body = [&](auto par, auto last_, int t, f32x16_t (&sc_)[2], f32x16_t (&sn)[2]) {
-    constexpr int PAR = decltype(par)::v;
-    constexpr bool LAST = decltype(last_)::v != 0;
-    constexpr int KS = 1 - PAR, VS = PAR * STAGE_BYTES + TILE_BYTES;      // K(t+1) sits in slot (t+1)&1, V(t) (a full tile) in slot t&1
-    // DMA targets of this iteration, clamped so that the statements are unconditional (a redundant re-fetch lands in a slot nobody reads again):
-    // K(t+2) -> K half of slot t&1, V(t+1) -> V half of slot (t+1)&1 (a partial last tile already sits in its own slot)
-    const int tk = t + 2 < n_tiles ? t + 2 : n_tiles - 1, tv = t + 1 <= last_full ? t + 1 : last_full;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(t+1), V(t) (requested one iteration ago) have landed -- for every wave after the barrier,
-    __builtin_amdgcn_s_barrier();                      // which also says: every wave is done reading K(t) and V(t-1)
-    asm volatile("" ::: "memory");
-    bf16x8_t kf[12], vf[12];
-    unsigned pw[16];
-    kf[0] = kfrag(KS, 0); kf[1] = kfrag(KS, 1);
-    GVL_SB();
-    // phase 1: S^T(t+1) MFMAs || exp2 + pack of S(t)
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      if (i + 2 < 12) kf[i + 2] = kfrag(KS, i + 2);
-      sn[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], __builtin_bit_cast(bf16x8_t, qf[i >> 1]), i < 2 ? zero16 : sn[i & 1], 0, 0, 0);
-      const int c = i / 3, sub = i - 3 * c, kb = c >> 1, r0 = (c & 1) * 8;          // chunk c = the 8 scores of P.V k-step c
-      f32x16_t& s = sc_[kb];
-      if (sub == 0) {
-        s[r0 + 0] = __builtin_amdgcn_exp2f(s[r0 + 0]); s[r0 + 1] = __builtin_amdgcn_exp2f(s[r0 + 1]); s[r0 + 2] = __builtin_amdgcn_exp2f(s[r0 + 2]);
-      } else if (sub == 1) {
-        s[r0 + 3] = __builtin_amdgcn_exp2f(s[r0 + 3]); s[r0 + 4] = __builtin_amdgcn_exp2f(s[r0 + 4]); s[r0 + 5] = __builtin_amdgcn_exp2f(s[r0 + 5]);
-        pw[4 * c + 0] = pack2bf(s[r0 + 0], s[r0 + 1]);
-      } else {
-        s[r0 + 6] = __builtin_amdgcn_exp2f(s[r0 + 6]); s[r0 + 7] = __builtin_amdgcn_exp2f(s[r0 + 7]);
-        pw[4 * c + 1] = pack2bf(s[r0 + 2], s[r0 + 3]); pw[4 * c + 2] = pack2bf(s[r0 + 4], s[r0 + 5]); pw[4 * c + 3] = pack2bf(s[r0 + 6], s[r0 + 7]);
-      }
-      if (i == 1) stage_k(PAR, tk);                    // the DMA issue rides under the MFMAs
-      if (i == 4) stage_v(1 - PAR, tv);             // (a body only runs when n_tiles >= 2, i.e. last_full >= 0)
-      if (i == 10) vf[0] = vfrag(VS, 0);
-      if (i == 11) vf[1] = vfrag(VS, 1);
-      GVL_SB();
-    }
-    if constexpr (LAST) { if (partial) mask_tail(sn, t + 1); GVL_SB(); }
-    // phase 2: P.V(t) MFMAs || row max of S(t+1)
-    float l1[11], a2 = 0.f, b2 = 0.f, c2 = 0.f, mx = 0.f;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      if (i + 2 < 12) vf[i + 2] = vfrag(VS, i + 2);
-      const int st = i / 3, db = i - 3 * st;
-      const u32x4_t pu = {pw[4 * st], pw[4 * st + 1], pw[4 * st + 2], pw[4 * st + 3]};
-      o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], __builtin_bit_cast(bf16x8_t, pu), o[db], 0, 0, 0);
-      // 16 v_max3 over groups 1..8 (S(t+1)'s first key block finished one MFMA earlier than the second: start there), exchange in group 10
-      if (i == 1) { l1[0] = vmax3(sn[0][0], sn[0][1], sn[0][2]); l1[1] = vmax3(sn[0][3], sn[0][4], sn[0][5]); }
-      if (i == 2) { l1[2] = vmax3(sn[0][6], sn[0][7], sn[0][8]); l1[3] = vmax3(sn[0][9], sn[0][10], sn[0][11]); }
-      if (i == 3) { l1[4] = vmax3(sn[0][12], sn[0][13], sn[0][14]); l1[5] = vmax3(sn[1][0], sn[1][1], sn[1][2]); }
-      if (i == 4) { l1[6] = vmax3(sn[1][3], sn[1][4], sn[1][5]); l1[7] = vmax3(sn[1][6], sn[1][7], sn[1][8]); }
-      if (i == 5) { l1[8] = vmax3(sn[1][9], sn[1][10], sn[1][11]); l1[9] = vmax3(sn[1][12], sn[1][13], sn[1][14]); }
-      if (i == 6) { l1[10] = vmax3(sn[0][15], sn[1][15], l1[0]); a2 = vmax3(l1[1], l1[2], l1[3]); }
-      if (i == 7) { b2 = vmax3(l1[4], l1[5], l1[6]); c2 = vmax3(l1[7], l1[8], l1[9]); }
-      if (i == 8) { mx = vmax3(a2, b2, c2); mx = vmax3(mx, l1[10], l1[10]); }
-      if (i == 10) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      }
-      GVL_SB();
-    }
-    // lazy reference (attn_fwd_kernel's rule, at the same point of the accumulation: after tile t's P.V, before tile t+1's)
-    if (!__all(mx <= a.lazy)) move_ref(sn, mx, false);
-  };
-
-  // iterations t = 0 .. n_tiles - 2; the last one (t + 1 = the last tile) is peeled: it alone carries the tail mask
-  int t = 0;
-  for (; t + 2 < n_tiles - 1; t += 2) {
-    body(IC<0>{}, IC<0>{}, t, sA, sB);
-    body(IC<1>{}, IC<0>{}, t + 1, sB, sA);
-  }
-  if (t + 2 == n_tiles - 1) {                          // two left
-    body(IC<0>{}, IC<0>{}, t, sA, sB);
-    body(IC<1>{}, IC<1>{}, t + 1, sB, sA);
-  } else if (t + 1 == n_tiles - 1) {                   // one left: S(n_tiles - 1) lands in sB
-    body(IC<0>{}, IC<1>{}, t, sA, sB);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) sA[kb] = sB[kb];
-  }
-  // ---- last tile: exp2 + P.V, nothing left to overlap with ---------------------------------------------------------------------
-  {
-    const int tl = n_tiles - 1;
+  auto run = [&](auto safe_) {
+    constexpr bool SAFE = decltype(safe_)::v != 0;
+    if constexpr (SAFE) stage_first();                   // (the normal pass: requested before the q prologue, one memory latency for both)
+    // ---- tile 0: S^T and its row max the plain way; its maximum becomes the reference ------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const char* vb_ = smem + (partial ? VLAST : (tl & 1) * STAGE_BYTES + TILE_BYTES);
+    sA[0] = zero16; sA[1] = zero16;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      const int kb = st >> 1, r0 = (st & 1) * 8;
-      union { bf16x8_t v; unsigned u[4]; } pf;
+    for (int i = 0; i < 12; ++i)
+      sA[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(0, i), __builtin_bit_cast(bf16x8_t, qf[i >> 1]), sA[i & 1], 0, 0, 0);
+    if (n_tiles == 1 && partial) mask_tail(sA, 0);
+    move_ref(sA, row_max(sA), true);
+
+    // ---- one pipelined iteration: `sc_` = S(t) (relative to the reference), `sn` receives S(t+1); PAR = t & 1; LAST: t + 1 is the last tile ----
+    auto body = [&](auto par, auto last_, int t, f32x16_t (&sc_)[2], f32x16_t (&sn)[2]) {
+      constexpr int PAR = decltype(par)::v;
+      constexpr bool LAST = decltype(last_)::v != 0;
+      constexpr int KS = 1 - PAR, VS = PAR * STAGE_BYTES + TILE_BYTES;      // K(t+1) sits in slot (t+1)&1, V(t) (a full tile) in slot t&1
+      // DMA targets of this iteration, clamped so that the statements are unconditional (a redundant re-fetch lands in a slot nobody reads again):
+      // K(t+2) -> K half of slot t&1, V(t+1) -> V half of slot (t+1)&1 (a partial last tile already sits in its own slot)
+      const int tk = t + 2 < n_tiles ? t + 2 : n_tiles - 1, tv = t + 1 <= last_full ? t + 1 : last_full;
+#ifdef GVL_PIPE_LAB                 // LAB (wrong results, timing only): bit 0 no K / V DMA in the loop, 1 no top-of-iteration wait + barrier, 2 no exp2, 3 only two K and two V fragment reads per tile
+      if (!(GVL_PIPE_LAB & 2)) {
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(t+1), V(t) (requested one iteration ago) have landed -- for every wave after the barrier,
+      __builtin_amdgcn_s_barrier();                      // which also says: every wave is done reading K(t) and V(t-1)
+      asm volatile("" ::: "memory");
+#ifdef GVL_PIPE_LAB
+      }
+#endif
+      bf16x8_t kf[12], vf[12];
+      unsigned pw[16];
+      // the VALU fillers of MFMA group g (0..11 = phase 1, 12..23 = phase 2): chunk c = the 8 scores of P.V k-step c (needed by group 12 + 3c).
+      // fast: 12 ops per chunk over 5 groups from group 5c (<= 3 per gap); safe: over 3 groups from group 3c (phase 2 carries the row max)
+      auto fill = [&](int g) {
+        constexpr int SPAN = SAFE ? 3 : 5;
+        const int c = g / SPAN, sub = g - SPAN * c;
+        if (c >= 4) return;
+        const int kb = c >> 1, r0 = (c & 1) * 8;
+        f32x16_t& s = sc_[kb];
+#ifdef GVL_PIPE_LAB
+        auto ex = [&](int e) { if (!(GVL_PIPE_LAB & 4)) s[r0 + e] = __builtin_amdgcn_exp2f(s[r0 + e]); };
+#else
+        auto ex = [&](int e) { s[r0 + e] = __builtin_amdgcn_exp2f(s[r0 + e]); };
+#endif
+        auto pk = [&](int e) { pw[4 * c + e] = pack2bf(s[r0 + 2 * e], s[r0 + 2 * e + 1]); };
+        if constexpr (SAFE) {
+          if (sub == 0) { ex(0); ex(1); ex(2); }
+          else if (sub == 1) { ex(3); ex(4); ex(5); pk(0); }
+          else { ex(6); ex(7); pk(1); pk(2); pk(3); }
+        } else {
+          if (sub == 0) { ex(0); ex(1); ex(2); }
+          else if (sub == 1) { ex(3); ex(4); pk(0); }
+          else if (sub == 2) { ex(5); ex(6); pk(1); }
+          else if (sub == 3) { ex(7); pk(2); }
+          else pk(3);
+        }
+      };
+      kf[0] = kfrag(KS, 0); kf[1] = kfrag(KS, 1);
+      GVL_SB();
+      // phase 1: S^T(t+1) MFMAs
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pf.u[e] = pack2bf(__builtin_amdgcn_exp2f(sA[kb][r0 + 2 * e]), __builtin_amdgcn_exp2f(sA[kb][r0 + 2 * e + 1]));
+      for (int i = 0; i < 12; ++i) {
+#ifdef GVL_PIPE_LAB
+        if (GVL_PIPE_LAB & 8) { if (i + 2 < 12) kf[i + 2] = kf[i]; } else
+#endif
+        if (i + 2 < 12) kf[i + 2] = kfrag(KS, i + 2);
+        sn[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], __builtin_bit_cast(bf16x8_t, qf[i >> 1]), i < 2 ? zero16 : sn[i & 1], 0, 0, 0);
+        fill(i);
+#ifdef GVL_PIPE_LAB
+        if (GVL_PIPE_LAB & 64) {                         // one piece per group (groups 1..3 K, 5..7 V) instead of two statements of three
+          if (i >= 1 && i <= 3) glds16s(kbase + (size_t)tk * kstep, koff[i - 1], smem_base + PAR * STAGE_BYTES + wave * 1024 + (i - 1) * NT * 16);
+          if (i >= 5 && i <= 7) glds16s_masked(vbase + (size_t)tv * 64 * v_ld, voff[i - 5], vmask[i - 5], smem_base + (1 - PAR) * STAGE_BYTES + TILE_BYTES + wave * 1024 + (i - 5) * NT * 16);
+        } else
+        if (!(GVL_PIPE_LAB & 1)) {
+        if (i == 1 && !(GVL_PIPE_LAB & 32)) stage_k(PAR, tk);
+        if (i == 4 && !(GVL_PIPE_LAB & 16)) stage_v(1 - PAR, tv);
+        }
+#else
+        if (i == 1) stage_k(PAR, tk);                    // the DMA issue rides under the MFMAs
+        if (i == 4) stage_v(1 - PAR, tv);                // (a body only runs when n_tiles >= 2, i.e. last_full >= 0)
+#endif
+        if (i == 10) vf[0] = vfrag(VS, 0);
+        if (i == 11) vf[1] = vfrag(VS, 1);
+        GVL_SB();
+      }
+      if constexpr (LAST) { if (partial) mask_tail(sn, t + 1); GVL_SB(); }
+      // phase 2: P.V(t) MFMAs (|| row max of S(t+1) in the safe pass)
+      float l1[11], a2 = 0.f, b2 = 0.f, c2 = 0.f, mx = 0.f;
 #pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        const char* p = vb_ + vtr[db] + st * (16 * D * 2);
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr8(p, p + 4 * D * 2), pf.v, o[db], 0, 0, 0);
+      for (int i = 0; i < 12; ++i) {
+#ifdef GVL_PIPE_LAB
+        if (GVL_PIPE_LAB & 8) { if (i + 2 < 12) vf[i + 2] = vf[i]; } else
+#endif
+        if (i + 2 < 12) vf[i + 2] = vfrag(VS, i + 2);
+        fill(12 + i);
+        const int st = i / 3, db = i - 3 * st;
+        const u32x4_t pu = {pw[4 * st], pw[4 * st + 1], pw[4 * st + 2], pw[4 * st + 3]};
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], __builtin_bit_cast(bf16x8_t, pu), o[db], 0, 0, 0);
+        if constexpr (SAFE) {
+          // 16 v_max3 over groups 1..8 (S(t+1)'s first key block finished one MFMA earlier than the second: start there), exchange in group 10
+          if (i == 1) { l1[0] = vmax3(sn[0][0], sn[0][1], sn[0][2]); l1[1] = vmax3(sn[0][3], sn[0][4], sn[0][5]); }
+          if (i == 2) { l1[2] = vmax3(sn[0][6], sn[0][7], sn[0][8]); l1[3] = vmax3(sn[0][9], sn[0][10], sn[0][11]); }
+          if (i == 3) { l1[4] = vmax3(sn[0][12], sn[0][13], sn[0][14]); l1[5] = vmax3(sn[1][0], sn[1][1], sn[1][2]); }
+          if (i == 4) { l1[6] = vmax3(sn[1][3], sn[1][4], sn[1][5]); l1[7] = vmax3(sn[1][6], sn[1][7], sn[1][8]); }
+          if (i == 5) { l1[8] = vmax3(sn[1][9], sn[1][10], sn[1][11]); l1[9] = vmax3(sn[1][12], sn[1][13], sn[1][14]); }
+          if (i == 6) { l1[10] = vmax3(sn[0][15], sn[1][15], l1[0]); a2 = vmax3(l1[1], l1[2], l1[3]); }
+          if (i == 7) { b2 = vmax3(l1[4], l1[5], l1[6]); c2 = vmax3(l1[7], l1[8], l1[9]); }
+          if (i == 8) { mx = vmax3(a2, b2, c2); mx = vmax3(mx, l1[10], l1[10]); }
+          if (i == 10) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+          }
+        }
+        GVL_SB();
+      }
+      // safe pass: the lazy reference (attn_fwd_kernel's rule, at the same point of the accumulation: after tile t's P.V, before tile t+1's)
+      if constexpr (SAFE) { if (!__all(mx <= a.lazy)) move_ref(sn, mx, false); }
+    };
+
+    // iterations t = 0 .. n_tiles - 2; the last one (t + 1 = the last tile) is peeled: it alone carries the tail mask
+    int t = 0;
+    for (; t + 2 < n_tiles - 1; t += 2) {
+      body(IC<0>{}, IC<0>{}, t, sA, sB);
+      body(IC<1>{}, IC<0>{}, t + 1, sB, sA);
+    }
+    if (t + 2 == n_tiles - 1) {                          // two left
+      body(IC<0>{}, IC<0>{}, t, sA, sB);
+      body(IC<1>{}, IC<1>{}, t + 1, sB, sA);
+    } else if (t + 1 == n_tiles - 1) {                   // one left: S(n_tiles - 1) lands in sB
+      body(IC<0>{}, IC<1>{}, t, sA, sB);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) sA[kb] = sB[kb];
+    }
+    // ---- last tile: exp2 + P.V, nothing left to overlap with ---------------------------------------------------------------------
+    {
+      const int tl = n_tiles - 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int vofs = partial ? VLAST : (tl & 1) * STAGE_BYTES + TILE_BYTES;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int kb = st >> 1, r0 = (st & 1) * 8;
+        union { bf16x8_t v; unsigned u[4]; } pf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf.u[e] = pack2bf(__builtin_amdgcn_exp2f(sA[kb][r0 + 2 * e]), __builtin_amdgcn_exp2f(sA[kb][r0 + 2 * e + 1]));
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(vofs, st * 3 + db), pf.v, o[db], 0, 0, 0);
       }
     }
+  };
+  // row Dout of O^T = the softmax row sum (ones column of the V image): held by the h = 0 lane of the query
+  auto row_sum = [&]() -> float {
+    const int lr = Dout - 32 * (DB - 1);
+    float mine = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mine = (e == (lr >> 3) * 4 + (lr & 3)) ? o[DB - 1][e] : mine;
+    const float other = __shfl_xor(mine, 32, 64);
+    return h ? other : mine;
+  };
+  float l_tot = 0.f;
+  bool redo = a.pipe == 2;                               // gvl_debug_set("attn_pipe", 2) (tests): the safe pass only
+  if (!redo) {
+    run(IC<0>{});
+    l_tot = row_sum();
+#ifndef GVL_PIPE_LAB                                     // (LAB builds compute garbage on purpose: no second pass)
+    redo = __syncthreads_or(!(l_tot > 0.f && l_tot < 1.2676506e30f)) != 0;     // 2^100; also catches NaN.  Block-uniform: every wave repeats the pass (the barriers are shared)
+#endif
+  }
+  if (redo) {
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+    m_run = 0.f;
+    qf[DK - 1][0] = h ? 0u : qf[DK - 1][0];            // q's pad element: reference 0 again
+    run(IC<1>{});
+    l_tot = row_sum();
   }
   // ---- epilogue (attn_fwd_kernel's ONES branch) ---------------------------------------------------------------------------------
-  const int lr = Dout - 32 * (DB - 1);
-  float mine = 0.f;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) mine = (e == (lr >> 3) * 4 + (lr & 3)) ? o[DB - 1][e] : mine;
-  const float other = __shfl_xor(mine, 32, 64);
-  const float inv = 1.f / (h ? other : mine);
+  const float inv = 1.f / l_tot;
   {
     const int qs = my_q < S ? my_q : S - 1;
     char* op = (char*)(a.O + ((size_t)b * S + qs) * (size_t)(a.H * Dout) + head * Dout);

@@ -1177,7 +1177,7 @@ int gvl_debug_set(gvl_ctx* ctx, const char* key, int value) {
   else if (k == "decode_graph") ctx->dbg.decode_graph = value != 0;
   else if (k == "attn_ring") { if (value != 0 && value != 2 && value != 3) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: attn_ring must be 0, 2 or 3"); ctx->dbg.attn_ring = value; }
   else if (k == "prefill_group") { if (value < 1 || value > GVL_MAX_PREFILL_BATCH) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: prefill_group must be 1 .. 8"); ctx->dbg.prefill_group = value; }
-  else if (k == "attn_pipe") ctx->dbg.attn_pipe = value != 0;
+  else if (k == "attn_pipe") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: attn_pipe must be 0, 1 or 2"); ctx->dbg.attn_pipe = value; }
   else if (k == "vision_in_place") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: vision_in_place must be 0, 1 or 2"); ctx->dbg.vision_in_place = value; }
   else return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: unknown key " + k);
   return 0;

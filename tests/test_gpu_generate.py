@@ -213,7 +213,7 @@ def test_generate_shared_respects_the_longrope_switch():
     tok = SyntheticTokenizer(vocab, 300)
     prompts = [P.build_prompt(llm, "grounding", "When does the person open the door in the video?"), P.build_prompt(llm, "grounding", "When does the dog jump?"),
                P.build_prompt(llm, "qa", "Describe the video in detail please.")]
-    n_vis = 2 * 285
+    n_vis = 2 * (156 + 16 * 2 + 1)                  # 2 segments x (156 image tokens + 16 per frame x 2 frames + newline)
     totals = [len(P.tokenize_with_image(p, tok, tok.bos_token_id)) - 1 + n_vis for p in prompts]
     sd = {"vision_tower": synth.clip_weights(64, 128, 3, seed="gen.clip"), "video_encoder": synth.iv2_weights(64, 128, 3, 2, seed="gen.iv2"),
           "projectors": synth.projector_weights(llm, hid, 64, 64, seed="gen.proj"), "language_model": synth.llm_weights("phi3", hid, 256, 2, 4, 4, vocab, True, seed="gen.llm")}
@@ -221,8 +221,9 @@ def test_generate_shared_respects_the_longrope_switch():
     tp = synth.det_tensor("gen.tp", (1, 4, 3, 224, 224)).to(DEV)
     one = {"spatial_pixel_values": sp, "temporal_pixel_values": tp, "video_ids": ["x"]}
     texts = {}
-    for omax, shared_expected in ((min(totals) - 8, False), (400, True)):       # 512 <= omax < every total: mixed factors -> fall back; omax < 512: prefix and prompts both long
-        assert (512 <= omax < min(totals)) == (not shared_expected)
+    prefix = (17 + n_vis) // 128 * 128                # the common prefix ends inside the visual tokens' tail: 17 shared ids + 378 visual rows -> 384
+    for omax, shared_expected in ((min(totals) - 8, False), (300, True)):       # prefix <= omax < every total: mixed factors -> fall back; omax < prefix: prefix and prompts both long
+        assert (prefix <= omax < min(totals)) == (not shared_expected), (prefix, omax, totals)
         geo = E.TowerGeometry(llm=llm, clip_hidden=64, clip_inter=128, clip_layers=3, clip_heads=4, iv2_dim=64, iv2_inter=128, iv2_depth=3, iv2_heads=4, hidden=hid,
                               inter=256, layers=2, heads=4, kv_heads=4, vocab=vocab, rope_short=short, rope_long=long, rope_theta=10000.0, rope_orig_max_pos=omax,
                               max_seq=2048, max_segs=6, kv_pages=60, max_prefill=1024)

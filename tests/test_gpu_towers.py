@@ -107,15 +107,20 @@ def test_towers_at_other_head_dims(tower, hidden, heads):
     eng.close()
 
 
-@pytest.mark.parametrize("image,frames,sharp", [(56, 2, 1), (56, 4, 1), (56, 8, 3), (56, 12, 1), (56, 16, 3), (14, 63, 1), (14, 127, 3), (14, 191, 1), (42, 71, 3), (112, 9, 3)])
-def test_iv2_pipelined_attention_is_bit_identical_to_the_plain_kernel(image, frames, sharp):
-    """Round 4: InternVideo2's attention runs a software-pipelined key-tile loop (attn_iv2_pipe_kernel: S^T of tile t+1 under the exp2 of
-    tile t, P.V of tile t under the row max of tile t+1, every MFMA heading a fenced group of fillers).  It issues the same MFMAs on the
-    same values in the same order and moves the softmax reference at the same point of the accumulation, so it must agree BIT FOR BIT
-    with attn_fwd_kernel (gvl_debug_set attn_pipe = 0) -- over every shape of the tile loop: S = frames * (image / 14)^2 + 1 gives
-    1 tile (partial), 2, 3, 4, 5 tiles with a one-key tail; image 14 gives whole tiles only (S = 64, 128, 192: no tail mask, the last
-    V tile in the ring instead of its own slot); 10 whole tiles; 577 keys.  sharp > 1 scales q_norm / k_norm so that the scores are
-    peaked and later tiles exceed the first tile's maximum by more than 2^8: the lazy reference moves inside the pipelined loop."""
+@pytest.mark.parametrize("image,frames,sharp", [(56, 2, 1), (56, 4, 1), (56, 8, 3), (56, 12, 1), (56, 16, 12), (14, 63, 1), (14, 127, 3), (14, 191, 1), (42, 71, 12), (112, 9, 3), (112, 9, 1), (56, 16, 60)])
+def test_iv2_pipelined_attention_against_the_plain_kernel(image, frames, sharp):
+    """Round 4: InternVideo2's attention runs a software-pipelined key-tile loop (attn_iv2_pipe_kernel: S^T of tile t+1 and P.V of tile t
+    carry the exp2 + pack work of tile t in their shadow, every MFMA heading a fenced group of <= 3 VALU fillers).  Its normal pass keeps
+    the FIRST tile's row maximum as the softmax reference for the whole row (no per-tile row max); attn_fwd_kernel (gvl_debug_set
+    attn_pipe = 0) moves its reference only when a later tile exceeds it by 2^8, which ordinary data never does -- there the two issue the
+    same MFMAs on the same values in the same order and must agree BIT FOR BIT, over every shape of the tile loop: S = frames *
+    (image / 14)^2 + 1 gives 1 tile (partial), 2, 3, 4, 5 tiles with a one-key tail; image 14 gives whole tiles only (S = 64, 128, 192:
+    no tail mask, the last V tile in the ring instead of its own slot); 10 whole tiles; 577 keys.
+    sharp = 3 scales q_norm / k_norm so that later tiles DO exceed the first tile's maximum by more than 2^8: the plain kernel moves its
+    reference, the pipelined one does not -- the same softmax up to the rounding of P to bf16 (a different, not larger, set of rounding points; on such peaked rows one flipped P ulp is
+    visible: checked to the bound both hold against the oracle, 1.5e-2 of the output scale).  sharp = 12 (and 60) makes the scores so peaked that exp2(score - first-tile max) overflows: the row-sum check at the end of the pass
+    sends the block through the SAFE pass (per-tile max + lazy reference = the plain kernel's arithmetic): finite, and equal to the plain
+    kernel wherever it ran."""
     c = dict(dim=704, inter=1408, depth=3, heads=8, image=image, frames=frames)
     seed = f"pipe.{image}.{frames}"
     geo = tiny_geo(iv2_dim=c["dim"], iv2_inter=c["inter"], iv2_depth=c["depth"], iv2_heads=c["heads"], iv2_image=image, frames_per_seg=frames, max_segs=3)
@@ -130,15 +135,26 @@ def test_iv2_pipelined_attention_is_bit_identical_to_the_plain_kernel(image, fra
     px = synth.det_tensor(seed + ".px", (3, 3, frames, image, image))
     S = frames * (image // 14) ** 2 + 1
     got = eng.iv2_encode(px.to(DEV))
-    assert bool(torch.isfinite(got.float()).all())
     eng.debug_set("attn_pipe", 0)
     plain = eng.iv2_encode(px.to(DEV))
+    eng.debug_set("attn_pipe", 2)                    # the pipelined kernel's SAFE pass alone (per-tile row max + lazy reference): the plain kernel's arithmetic
+    safe = eng.iv2_encode(px.to(DEV))
     eng.debug_set("attn_pipe", 1)
+    nsafe = int((safe != plain).sum())
+    print(f"[parity] iv2 pipelined attention S = {S}, sharp x{sharp}: safe pass differs from the plain kernel in {nsafe} of {safe.numel()} values")
+    assert nsafe == 0
+    nf_got, nf_plain = int((~torch.isfinite(got.float())).sum()), int((~torch.isfinite(plain.float())).sum())
+    assert nf_got == 0 and nf_plain == 0, f"S = {S}, sharp x{sharp}: non-finite outputs: pipelined {nf_got}, plain {nf_plain} of {got.numel()}"
     again = eng.iv2_encode(px.to(DEV))
+    assert torch.equal(got, again), f"S = {S}, sharp x{sharp}: the pipelined kernel is not reproducible ({int((got != again).sum())} values differ between two runs)"
     nbad = int((got != plain).sum())
-    assert torch.equal(got, plain), f"S = {S} ({(S + 63) // 64} key tiles): pipelined attention differs from the plain kernel in {nbad} of {got.numel()} values"
-    assert torch.equal(got, again)
-    if frames <= 16:                                 # against the oracle too (bf16 emulation); the long-sequence cases would take the CPU minutes
+    dmax = float((got.float() - plain.float()).abs().max() / plain.float().abs().max())
+    print(f"[parity] iv2 pipelined attention S = {S} ({(S + 63) // 64} key tiles), sharp x{sharp}: {nbad} of {got.numel()} values differ from the plain kernel (max {dmax:.2e} of the scale)")
+    if sharp == 1:
+        assert nbad == 0, f"S = {S} ({(S + 63) // 64} key tiles): pipelined attention differs from the plain kernel in {nbad} of {got.numel()} values"
+    else:
+        check(got, plain.float(), 1.5e-2, f"iv2 pipelined attention, S = {S}, sharp x{sharp}, vs the plain kernel")
+    if frames <= 16 and sharp <= 3:                  # against the oracle too (bf16 emulation); the long-sequence cases would take the CPU minutes
         ref = O.iv2_encode(px, W, c["depth"], c["heads"], emu=True)
         check(got, ref, 1.5e-2 if sharp > 1 else 1.2e-2, f"iv2 pipelined attention, S = {S}, sharp x{sharp}, vs oracle (bf16 emulation)")
     eng.close()

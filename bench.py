@@ -211,7 +211,7 @@ class Stepper:
     def _exchange(self, vis, force=False):
         return self._exchange_multi([vis], force)[0]
 
-    def _exchange_multi(self, vis_list, force=False):
+    def _exchange_multi(self, vis_list, force=False, all_clips=False):
         """N > 1: ONE all-gather per STEP: this rank's 12 segment blocks of each of the step's `cps` clip rounds travel together
         (cps x 3.5 MB per rank; xGMI is point-to-point, every rank pushes to its 7 peers at once), then each round picks the blocks
         of this rank's clip in segment order.  force: run the collective at world == 1 too (RCCL smoke test on a 1-GPU box)."""
@@ -220,13 +220,24 @@ class Stepper:
         cps, rows = len(vis_list), vis_list[0].shape[0]
         send = torch.cat(vis_list, 0) if cps > 1 else vis_list[0]
         recv = torch.empty((self.world * send.shape[0], send.shape[1]), dtype=bf, device=self.dev)
+        recv = self._allgather(send, recv).view(self.world, cps, rows, -1)
+        if all_clips:                                                  # the rank-0-LLM plan: every clip of the round, in clip order
+            idx = [gdist.rotated_gather_index(12, c, self.world) for c in range(self.world)] if self.world > 1 else [[(0, 0, rows // self.L)]]
+            return [[torch.cat([recv[src, c, off * self.L:(off + n) * self.L] for src, off, n in g], 0) for g in idx] for c in range(cps)]
+        gather = self.gather if self.world > 1 else [(0, 0, rows // self.L)]
+        return [torch.cat([recv[src, c, off * self.L:(off + n) * self.L] for src, off, n in gather], 0) for c in range(cps)]   # clip == rank, segment order
+
+    def _allgather(self, send, recv):
+        """The collective of the exchange.  exchange == "gvl": libgvl's own RCCL communicator behind the C ABI (gvl_comm_init once,
+        gvl_allgather_visual per step) -- what a non-Python host calls; "torch": torch.distributed.all_gather_into_tensor (RCCL; gloo on CPU
+        tensors in the plumbing test)."""
+        if self.exchange == "gvl":
+            return self.eng.allgather_visual(send)
         if torch.distributed.get_backend() == "gloo" and send.device.type != "cpu":   # debug only (GVL_BENCH_BACKEND=gloo on a GPU): stage through the host
             rc = recv.cpu(); torch.distributed.all_gather_into_tensor(rc, send.cpu()); recv.copy_(rc)
         else:
-            torch.distributed.all_gather_into_tensor(recv, send)      # RCCL over xGMI (gloo on CPU tensors in the plumbing test)
-        recv = recv.view(self.world, cps, rows, -1)
-        gather = self.gather if self.world > 1 else [(0, 0, rows // self.L)]
-        return [torch.cat([recv[src, c, off * self.L:(off + n) * self.L] for src, off, n in gather], 0) for c in range(cps)]   # clip == rank, segment order
+            torch.distributed.all_gather_into_tensor(recv, send)
+        return recv
 
     def encode(self, i):
         """vision towers + projectors for pool entry i (+ the all-gather for N > 1) -> visual tokens of THIS rank's clip."""
@@ -326,7 +337,9 @@ class Stepper:
         lo, hi = gdist.my_shard(12, self.rank, self.world)
         local = self.eng.encode_segments(sp[lo:hi], tp[lo:hi]) if hi > lo else torch.empty((0, self.geo.hidden), dtype=bf, device=self.dev)
         if self.world > 1:
-            if torch.distributed.get_backend() == "gloo" and local.device.type != "cpu":
+            if self.exchange == "gvl":
+                vis = gdist.allgather_visual(local, 12, self.L, gather=self.eng.allgather_visual)
+            elif torch.distributed.get_backend() == "gloo" and local.device.type != "cpu":
                 vis = gdist.allgather_visual(local.cpu(), 12, self.L).to(self.dev)
             else:
                 vis = gdist.allgather_visual(local, 12, self.L)
@@ -340,6 +353,47 @@ class Stepper:
         out = self.eng.decode_greedy(seq, self.new_tokens, None)
         self.eng.seq_free(seq)
         return out
+
+    # ---- the north-star plan as a THROUGHPUT mode: every rank encodes, rank 0 alone runs the LLM, pipelined ------------------------
+    def r0_prompt(self, rnd, clip):
+        """prompt of clip `clip` of pool round `rnd` -- what rank `clip` uses for it in the weak-scaling plan"""
+        return make_prompt(77 + 31 * (rnd % self.pool) + 7919 * clip)
+
+    def r0_start(self):
+        self.sV, self.sL = self.D.stream(), self.D.stream()
+        self.evV = self.D.event()
+        with self.D.on(self.sV):
+            self.r0_round = self.window(1)[0]
+            self.r0_next = self._exchange_multi([self.eng.encode_segments(*self.px(self.r0_round))], all_clips=True)[0]
+            self.evV.record(self.sV)
+
+    def r0_step(self):
+        """One clip ROUND = `world` clips: every rank has encoded its 12 segment blocks of the round (rotated plan) and all-gathered them;
+        rank 0 prefills the `world` clips as ONE ragged pass and decodes them together while ALL ranks (rank 0's vision stream too) encode
+        and exchange the next round.  Ranks >= 1 never touch their LLM.  Returns rank 0's ids of the round (None elsewhere)."""
+        rnd, clips = self.r0_round, self.r0_next
+        seqs = None
+        if self.rank == 0:
+            with self.D.on(self.sL):
+                self.sL.wait_event(self.evV)
+                embs = []
+                for c, vis in enumerate(clips):
+                    if self.D.gpu:
+                        vis.record_stream(self.sL)
+                    embs.append(self.eng.splice(self.r0_prompt(rnd, c), vis))
+                seqs = [self.eng.seq_alloc(e.shape[0] + self.new_tokens) for e in embs]
+                self.eng.prefill_batch(seqs, embs)
+        with self.D.on(self.sV):
+            self.r0_round = self.window(1)[0]
+            self.r0_next = self._exchange_multi([self.eng.encode_segments(*self.px(self.r0_round))], all_clips=True)[0]
+            self.evV.record(self.sV)
+        if self.rank != 0:
+            return None
+        with self.D.on(self.sL):
+            outs = self.eng.decode_greedy_batch(seqs, self.new_tokens, None)
+            for q in seqs:
+                self.eng.seq_free(q)
+        return outs
 
     # ---- two clips in flight per GPU: vision of clip k+1 overlaps the (HBM-bound) decode of clip k ---------------
     def pipe_start(self):
@@ -411,6 +465,7 @@ class Stepper:
         return out, S
 
     time_decode = False
+    exchange = "torch"
     clip_batch = False
     iv2_batch = int(os.environ.get("GVL_BENCH_IV2_BATCH", "0")) or 64      # clips per InternVideo2 call (capped by the clips of a step)
     last_idx = 0
@@ -441,7 +496,30 @@ def _cpu_layer_samples(O):
     return t
 
 
-def cpu_baseline(dev, new_tokens=12):
+def cpu_c1_measured(dev, O, Wc, Wv, Wp, Wl, new_tokens):
+    """ONE real pass of the HEADLINE configuration (BASELINE configs[1]: 96 frames = 12 segments, S = 3519 prefill, `new_tokens` greedy tokens) through the fp32
+    oracle on the host cores (--cpu-c1; ~6 min): the CPU figure beside `value`, measured instead of scaled from per-layer samples.  Inputs and weights are the
+    streams of tests/golden/c1_free.json, whose `free_ids` are the REFERENCE's own free-running greedy ids for this clip."""
+    with open(os.path.join(ROOT, "tests", "golden", "c1_free.json")) as f:
+        meta = json.load(f)
+    sd = meta["seeds"]
+    sp = synth.exact_tensor(sd["sp"], (1, 12, 3, 336, 336), device=str(dev)).cpu()
+    tp = synth.exact_tensor(sd["tp"], (1, 96, 3, 224, 224), device=str(dev)).cpu()
+    ocfg = O.LLMConfig("phi3", 3072, 8192, 32, 32, 32, 32366, 1e-5, 10000.0, 131072, 4096, *synth.longrope_factors(96))
+    ids = torch.tensor(json.loads(meta["ids"]) if isinstance(meta["ids"], str) else meta["ids"])
+    t0 = time.perf_counter()
+    vis = O.encode_images(sp, tp, Wc, Wv, Wp, "phi3.5")
+    t1 = time.perf_counter()
+    emb = O.splice(ids, vis[0], Wl["model.embed_tokens.weight"])
+    out = O.greedy_generate(ocfg, Wl, emb, new_tokens, None, use_cache=True)
+    t2 = time.perf_counter()
+    n = min(len(out), len(meta["free_ids"]))
+    return {"clips_per_s": round(1.0 / (t2 - t0), 6), "seconds": {"vision": round(t1 - t0, 1), "llm_prefill_plus_decode": round(t2 - t1, 1), "total": round(t2 - t0, 1)},
+            "prefill_len": int(emb.shape[0]), "new_tokens": new_tokens, "cores": torch.get_num_threads(),
+            "oracle_ids": out, "reference_free_ids": meta["free_ids"], "oracle_ids_equal_reference_golden": out[:n] == meta["free_ids"][:n]}
+
+
+def cpu_baseline(dev, new_tokens=12, c1=False):
     """The CPU oracle (fp32 torch restatement of the reference, eager attention, KV-cached greedy as HF generate does) timed END TO END
     on BASELINE configs[0] -- Phi-3.5, ONE 8-frame segment: CLIP 23 L + InternVideo2 39 blocks + projectors + splice + 32-layer
     prefill (S = 384) + 12 greedy tokens -- on this box's host cores (SURVEY §8d 'CPU baseline').  The weights are
@@ -473,6 +551,7 @@ def cpu_baseline(dev, new_tokens=12):
     out = O.greedy_generate(ocfg, Wl, emb, new_tokens, None, use_cache=True)
     t2 = time.perf_counter()
     ref_ids = meta["greedy_ids"][:new_tokens]
+    c1_measured = cpu_c1_measured(dev, O, Wc, Wv, Wp, Wl, new_tokens) if c1 else None
     t = _cpu_layer_samples(O)
     c1_s = t["iv2_block_1seg"] * 39 * 12 + t["clip_layer_1img"] * 23 * 12 + t["phi_layer_S880"] * 4 * 32 + t["phi_layer_decode_tok"] * 32 * 12
     return {"value": round(1.0 / (t2 - t0), 5), "unit": "clips/s (8-frame C0 clip)", "cores": torch.get_num_threads(), "kind": "port",
@@ -480,6 +559,7 @@ def cpu_baseline(dev, new_tokens=12):
                       "fp32 torch oracle (oracle/gvl_oracle.py), KV-cached greedy",
             "c0_seconds": {"vision": round(t1 - t0, 3), "llm_prefill_plus_decode": round(t2 - t1, 3), "total": round(t2 - t0, 3)},
             "oracle_ids_equal_reference_golden": out == ref_ids, "oracle_ids": out, "reference_ids": ref_ids,
+            "c1_measured": c1_measured if c1_measured is not None else "not run (bench.py --cpu-c1: one real 96-frame oracle pass, ~6 min of host time; profiles/r04_cpu_c1.json keeps one)",
             "c1_scaled_estimate_clips_per_s": round(1.0 / c1_s, 5),
             "c1_scaled_estimate_from": "one full-width layer of each tower at the 96-frame shapes x layer counts (attention growth of the S=3520 prefill ignored): "
                                        + json.dumps({k: round(v, 3) for k, v in t.items()})}
@@ -491,13 +571,13 @@ def rccl_ranks_seen(eng, rank, world, dev, backend):
     when the engine has no RCCL path (the CPU plumbing test's stub)."""
     if not hasattr(eng, "comm_unique_id") or os.environ.get("GVL_BENCH_SAME_DEVICE"):      # RCCL refuses two ranks on one device (debug runs)
         return None, None
-    uid = [eng.comm_unique_id() if rank == 0 else None]
-    torch.distributed.broadcast_object_list(uid, src=0)
-    eng.comm_init(uid[0], rank, world)
+    if getattr(eng, "comm_world", 0) != world:                # (already built when the exchange itself ran through it)
+        gdist.init_gvl_comm(eng)
     n = eng.comm_count()
     local = torch.full((1, 64), float(rank + 1), dtype=bf, device=dev)
     got = eng.allgather_visual(local)
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     ok = bool(torch.equal(got[:, 0].float().cpu(), torch.arange(1, world + 1, dtype=torch.float32)))
     return n, ok
 
@@ -516,6 +596,11 @@ def main(argv=None, engine_factory=None):
                     help="pipelined: 2 x cps clips in flight per GPU (vision of the next clips overlaps prefill + decode of the current ones); serial: one clip at a "
                          "time; serial_step: the launches of a pipelined step (cps clips, batched CLIP / InternVideo2 / prefill / decode) back to back on ONE stream -- "
                          "the rocprofv3 target whose per-kernel times `roofline` must agree with")
+    ap.add_argument("--exchange", choices=["torch", "gvl"], default=os.environ.get("GVL_BENCH_EXCHANGE", "torch"),
+                    help="N > 1: the all-gather of the visual tokens -- torch.distributed.all_gather_into_tensor (default), or libgvl's OWN RCCL communicator "
+                         "through the C ABI (gvl_comm_init + gvl_allgather_visual: the exchange a non-Python host of the library performs).  The other one is "
+                         "timed as an extra either way (`clips_per_s_other_exchange`)")
+    ap.add_argument("--cpu-c1", action="store_true", help="cpu_baseline: also time ONE real 96-frame (C1) oracle pass on the host cores (~6 min) instead of only scaling the C0 pass")
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=INT",
                     help="gvl_debug_set(KEY, INT) before the run (result-neutral launch parameters, include/gvl.h): A/B measurements in one place")
     ap.add_argument("--watchdog-s", type=float, default=float(os.environ.get("GVL_BENCH_WATCHDOG_S", "900")),
@@ -560,6 +645,13 @@ def main(argv=None, engine_factory=None):
         eng.debug_set(k, int(v))
     hw = getattr(eng, "bench_hw", (336, 224))
     st = Stepper(eng, geo, rank, world, args.new_tokens, pool=2 * cps, hw=hw)
+    can_gvl = world > 1 and hasattr(eng, "comm_unique_id") and not os.environ.get("GVL_BENCH_SAME_DEVICE")      # RCCL refuses two ranks on one device (debug runs)
+    if world > 1 and args.exchange == "gvl":
+        if not can_gvl:
+            raise SystemExit("--exchange gvl: this engine has no RCCL path")
+        prog.enter("gvl_comm_init (libgvl's own RCCL communicator: --exchange gvl)")
+        gdist.init_gvl_comm(eng)
+        st.exchange = "gvl"
 
     def barrier(stage):
         prog.enter(stage + ": barrier")
@@ -637,6 +729,37 @@ def main(argv=None, engine_factory=None):
         barrier("sharded clip")
     sharded_ms = 1e3 * (time.perf_counter() - ts) / 2
     prog.partial["single_clip_latency_ms_sharded"] = round(sharded_ms, 2)
+    # ---- the north-star plan as a throughput mode (N > 1): all ranks encode, ONE all-gather per clip round, rank 0 alone runs the LLM for the
+    # `world` clips of the round (one ragged prefill + one batched decode) while every rank encodes the next round -- the third N > 1 figure
+    r0 = None
+    if world > 1 and world <= cps and args.mode == "pipelined":
+        prog.enter("rank-0-LLM pipelined mode: start")
+        st.r0_start()
+        st.r0_step()
+        barrier("rank-0-LLM mode warm")
+        t0r = time.perf_counter()
+        outs_r0 = None
+        for k in range(args.steps):
+            prog.enter(f"rank-0-LLM pipelined mode: round {k}")
+            rnd_done = st.r0_round
+            outs_r0 = st.r0_step()
+        barrier("rank-0-LLM mode")
+        dtr = time.perf_counter() - t0r
+        if world > 1:
+            tt = torch.tensor([dtr], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dtr = float(tt.item())
+        # the ids rank 0 produced for clip c of the last round == what rank c produces for its own clip of that round (weak-scaling path, serial)
+        prog.enter("rank-0-LLM pipelined mode: id check")
+        mine_ids, _ = st.step(rnd_done)
+        gathered_ids = [None] * world
+        torch.distributed.all_gather_object(gathered_ids, list(mine_ids))
+        r0 = {"clips_per_s": round(world * args.steps / dtr, 4), "ms_per_round": round(1e3 * dtr / args.steps, 2), "clips_per_round": world,
+              "ids_match_the_per_rank_llm": None if rank != 0 else bool(outs_r0 is not None and [list(o) for o in outs_r0] == gathered_ids),
+              "plan": f"{world} ranks encode 12 segments each per round (rotated shard of the round's {world} clips), one all-gather, rank 0 prefills the "
+                      f"{world} clips as one ragged pass and decodes them together while every rank encodes the next round"}
+        prog.partial["rank0_llm_pipelined"] = r0
+        st.cursor = (st.cursor + cps - 1) // cps * cps            # the rounds advanced the pool cursor one clip at a time: back onto a window boundary
     # ---- untimed extras: PCIe-inclusive rate, single-clip latency, decode-only rate, per-kernel-family profile, CPU baseline -----
     # The boundary takes DEVICE pixel tensors (`value` above); here every clip's 74 MB of f32 pixels is first copied from pinned
     # host memory on the vision stream, as a caller holding CPU-preprocessed frames would (inference.py:119-120 of the reference).
@@ -723,22 +846,26 @@ def main(argv=None, engine_factory=None):
     gemm1_tflops = g1["work"] / (g1["ms"] * 1e-3) / 1e12 if g1["ms"] > 0 else 0.0
     # HBM-side bytes per GEMM launch: NOT measured by this run -- PMC counters need their own rocprofv3 passes (MI355X_MICROARCH.md);
     # the figure is read from the committed summary of those passes over this same command and labelled as such (traffic_source)
-    traffic, traffic_src = None, None
-    for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        if os.path.exists(os.path.join(ROOT, "profiles", cand)):
-            traffic_src = "profiles/" + cand
-            break
+    traffic, traffic_src, traffic_note = None, None, None
+    import glob
+    from grounded_video_llm_amd.build import source_sha16
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)
     try:
-        with open(os.path.join(ROOT, traffic_src)) as fpm:
+        with open(cands[0]) as fpm:
             pm = json.load(fpm)
+        if pm.get("src_sha16") != source_sha16():
+            traffic_note = (f"profiles/{os.path.basename(cands[0])} was collected on other sources (stamp {pm.get('src_sha16')} != this tree {source_sha16()}): "
+                            "not this run's figure, so none is printed; re-run tools/run_profiles.sh <tag> pmc")
+        else:
+            traffic_src = "profiles/" + os.path.basename(cands[0])
             # per LOGICAL GEMM launch of the traced mode: serial_step traces hold the step's batched launches, older ones one clip at a time
             per_clip = g["launches"] / n_prof if "serial_step" in pm.get("source", "") else g1["launches"]
             traffic = int(pm["families"]["gemm"]["total_traffic_bytes"] / max(1.0, pm["clips_in_trace"] * per_clip))
-    except Exception:
-        pass
+    except Exception as e:
+        traffic_note = f"no usable PMC summary under profiles/ ({type(e).__name__})"
     roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)", "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_source": None if traffic is None else traffic_src + " (separate rocprofv3 --pmc passes of the serial bench; not measured by this run)",
+                "traffic_source": traffic_note if traffic is None else traffic_src + " (separate rocprofv3 --pmc passes of the serial_step bench on THIS source tree -- stamp matches; not measured by this run)",
                 "measured_on": (f"the launches of ONE timed step ({n_prof} clips: CLIP batched over {12 * n_prof} key frames, one ragged prefill, one batched decode) "
                                 "back to back on one stream, hipEvent pairs around every launch" if n_prof > 1 else
                                 "ONE clip, stages back to back on one stream, hipEvent pairs around every launch"),
@@ -759,8 +886,50 @@ def main(argv=None, engine_factory=None):
     for k, p in prof1.items():
         stages[k + "_ms_per_clip_serial"] = round(p["ms"], 3)           # one clip alone
 
+    other_exchange = None
     diag_stuck = False
-    if world > 1:
+    if world > 1 and can_gvl and args.mode == "pipelined" and cps > 1:
+        # the same pipelined steps through the OTHER collective (libgvl's own communicator when `value` used torch.distributed, and vice versa):
+        # in a helper thread with its own bound -- a communicator bootstrap that hangs must not cost the line
+        other = "torch" if st.exchange == "gvl" else "gvl"
+        prog.enter(f"timed steps with --exchange {other} (bounded extra)")
+        reso = {}
+
+        def _other():
+            keep = st.exchange
+            try:
+                if D.gpu:
+                    torch.cuda.set_device(dev)
+                if other == "gvl" and getattr(eng, "comm_world", 0) != world:
+                    gdist.init_gvl_comm(eng)
+                st.exchange = other
+                stepfn(); stepfn()                                   # the encode in flight still used the first collective
+                torch.distributed.barrier(); D.sync()
+                tq = time.perf_counter()
+                for _ in range(args.steps):
+                    stepfn()
+                torch.distributed.barrier(); D.sync()
+                reso["dt"] = time.perf_counter() - tq
+                st.exchange = keep
+                stepfn()
+            except Exception as e:
+                reso["err"] = f"{type(e).__name__}: {e}"
+            finally:
+                st.exchange = keep
+        tho = threading.Thread(target=_other, daemon=True)
+        tho.start()
+        tho.join(timeout=2.0 * float(os.environ.get("GVL_BENCH_DIAG_S", "120")))
+        if tho.is_alive():
+            diag_stuck, other_exchange = True, {"exchange": other, "status": "timed out"}
+            ranks_seen = "timed out"                             # the communicator check below would park in the same bootstrap: skipped
+            print(f"bench: rank {rank}: the timed steps through --exchange {other} are still running after their bound: skipped", file=sys.stderr, flush=True)
+        elif "err" in reso:
+            other_exchange = {"exchange": other, "status": "failed: " + reso["err"][:200]}
+        else:
+            tt = torch.tensor([reso["dt"]], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            other_exchange = {"exchange": other, "clips_per_s": round(world * args.steps * cps / float(tt.item()), 4)}
+    if world > 1 and not diag_stuck:
         # libgvl's OWN communicator over all ranks (how many ranks RCCL itself reports, and its all-gather) -- the last collective work of
         # the run, in a helper thread with its own 120 s bound: a diagnostic that hangs or fails must not cost the line (everything else
         # is measured by now); on a time-out the line says so and the process leaves without tearing the process group down
@@ -807,6 +976,9 @@ def main(argv=None, engine_factory=None):
                "mode": args.mode, "ids_match_serial": same_ids,
                "roofline": roofline, "stages": stages, "kv_pool": eng.kv_info()}
         if world > 1:
+            out["exchange"] = st.exchange + (" (torch.distributed.all_gather_into_tensor)" if st.exchange == "torch" else " (gvl_allgather_visual through the C ABI, libgvl's own communicator)")
+            out["clips_per_s_other_exchange"] = other_exchange
+            out["rank0_llm_pipelined"] = r0
             out["per_rank_stage_ms"] = per_rank
             out["n_ranks_seen_by_rccl"] = ranks_seen
             out["gvl_allgather_matches_rank_order"] = gvl_gather_ok
@@ -814,7 +986,7 @@ def main(argv=None, engine_factory=None):
             prog.enter("cpu_baseline (host cores)")
             prog.limit = max(prog.limit, 1800.0) if prog.limit > 0 else 0
             eng.close()                                  # give the HBM back: the C0 weights are generated on the GPU, then copied to the host
-            out["cpu_baseline"] = cpu_baseline(dev, args.new_tokens)
+            out["cpu_baseline"] = cpu_baseline(dev, args.new_tokens, c1=args.cpu_c1)
         print(json.dumps(out), flush=True)
     prog.finish()
     if diag_stuck:

@@ -21,6 +21,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
+def source_sha16() -> str:
+    """Fingerprint of what decides the GEMM family's memory traffic: every kernel source / header of libgvl plus bench.py (launch shapes).
+    tools/pmc_traffic.py stamps it into profiles/rNN_pmc_traffic.json; bench.py reports `roofline.traffic` from that file only while the
+    stamp equals the tree it runs from -- a PMC figure of other code is not this run's figure."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(SOURCES + ["gvl_internal.h", "gvl_ctx.h"])] + [os.path.join(HERE, "..", "bench.py")]
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def _newer(dst, srcs):
     if not os.path.exists(dst):
         return True

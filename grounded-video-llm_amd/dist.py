@@ -33,11 +33,14 @@ def my_shard(n_units: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def allgather_visual(local: torch.Tensor, n_units: int, rows_per_unit: int, group: Optional[dist.ProcessGroup] = None,
-                     force_collective: bool = False) -> torch.Tensor:
+                     force_collective: bool = False, gather=None) -> torch.Tensor:
     """local: [n_local * rows_per_unit, D] for this rank's block -> full [n_units * rows_per_unit, D] on every rank.
 
     Blocks are padded to the largest block so that a single fixed-size all_gather_into_tensor is used
-    (12 segments over 8 ranks is uneven: 2,2,2,2,1,1,1,1)."""
+    (12 segments over 8 ranks is uneven: 2,2,2,2,1,1,1,1).
+    gather: None = torch.distributed.all_gather_into_tensor; or a callable send [rows, D] -> recv [world * rows, D] in rank order --
+    Engine.allgather_visual, i.e. libgvl's own RCCL communicator behind the C ABI (gvl_comm_init / gvl_allgather_visual): the exchange a
+    non-Python host of the library performs."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1 and not force_collective:       # force_collective: run the (degenerate) collective anyway -- RCCL smoke test on one GPU
@@ -49,8 +52,12 @@ def allgather_visual(local: torch.Tensor, n_units: int, rows_per_unit: int, grou
     assert local.shape[0] == (hi - lo) * rows_per_unit, (local.shape, lo, hi)
     send = local.new_zeros((max_units * rows_per_unit, D))
     send[: local.shape[0]] = local
-    recv = local.new_empty((world * max_units * rows_per_unit, D))
-    dist.all_gather_into_tensor(recv, send, group=group)
+    if gather is not None:
+        recv = gather(send)
+        assert recv.shape == (world * max_units * rows_per_unit, D), recv.shape
+    else:
+        recv = local.new_empty((world * max_units * rows_per_unit, D))
+        dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view(world, max_units * rows_per_unit, D)
     parts = [recv[r, : (b[1] - b[0]) * rows_per_unit] for r, b in enumerate(bounds)]
     return torch.cat(parts, dim=0)
@@ -67,6 +74,17 @@ def rotated_encode_plan(n_units: int, rank: int, world: int) -> List[Tuple[int, 
         if hi > lo:
             plan.append((c, lo, hi))
     return plan
+
+
+def init_gvl_comm(engine, group: Optional[dist.ProcessGroup] = None) -> None:
+    """libgvl's own communicator over the ranks of `group`: ncclGetUniqueId on the group's first rank (gvl_comm_unique_id), its 128 bytes
+    travel through torch.distributed's object broadcast (any host-side channel would do), ncclCommInitRank on every rank (gvl_comm_init).
+    Afterwards Engine.allgather_visual is the exchange of the visual tokens."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    uid = [engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=src, group=group)
+    engine.comm_init(uid[0], rank, world)
 
 
 def rotated_gather_index(n_units: int, rank: int, world: int) -> List[Tuple[int, int, int]]:

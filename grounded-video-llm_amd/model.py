@@ -110,7 +110,8 @@ class LLAVA_NEXT_VIDEO:
                  pretrained_video_path="weight_path/internvideo/vision-encoder-InternVideo2-stage2_1b-224p-f4.pt",
                  pretrained_vision_proj_llm_path="weight_path/Phi-3.5-vision-instruct-seperated/",
                  *, geometry: Optional[TowerGeometry] = None, tokenizer=None, state_dicts: Optional[Dict[str, Dict[str, torch.Tensor]]] = None,
-                 device: str = "cuda:0", group=None, packed_weights: Optional[str] = None, ckpt_path: Optional[str] = None):
+                 device: str = "cuda:0", group=None, packed_weights: Optional[str] = None, ckpt_path: Optional[str] = None,
+                 exchange: str = "torch"):
         if dtype not in (torch.bfloat16,):
             raise ValueError("the MI355X path computes in bfloat16 (the reference's recommended dtype, README.md:57)")
         if num_frames % num_segs != 0:
@@ -118,6 +119,9 @@ class LLAVA_NEXT_VIDEO:
         self.dtype, self.stage, self.max_txt_len = dtype, stage, max_txt_len
         self.num_frames, self.num_segs, self.lora, self.num_temporal_tokens, self.llm = num_frames, num_segs, lora, num_temporal_tokens, llm
         self.group = group
+        if exchange not in ("torch", "gvl"):
+            raise ValueError("exchange: 'torch' (torch.distributed all_gather_into_tensor) or 'gvl' (libgvl's own RCCL communicator through the C ABI)")
+        self.exchange = exchange         # the all-gather of the visual tokens when the segments are sharded over a process group (encode_images)
         if geometry is None:
             geometry = geometry_from_checkpoint_dirs(llm, config_path, pretrained_vision_proj_llm_path, stage, num_temporal_tokens)
         geometry = fit_geometry(geometry, llm, num_frames, num_segs, max_txt_len)     # a COPY: the caller's object is never edited
@@ -216,7 +220,11 @@ class LLAVA_NEXT_VIDEO:
             ms = max(1, self.geo.max_segs)
             parts = [self.engine.encode_segments(sp[i:min(i + ms, hi)], tp[i:min(i + ms, hi)]) for i in range(lo, hi, ms)]   # bs > 1: the shard may exceed max_segs
             local = (torch.cat(parts, 0) if len(parts) > 1 else parts[0]) if parts else torch.empty((0, self.geo.hidden), dtype=bf, device=self.engine.device)
-            vis = gdist.allgather_visual(local, n, L, self.group)
+            # the ONE collective of the sharded plan: torch.distributed's all_gather_into_tensor (RCCL), or -- exchange="gvl" -- libgvl's own
+            # communicator through the C ABI (gvl_comm_init / gvl_allgather_visual), what a non-Python host of the library calls
+            if self.exchange == "gvl" and getattr(self.engine, "comm_world", 0) != world:
+                gdist.init_gvl_comm(self.engine, self.group)
+            vis = gdist.allgather_visual(local, n, L, self.group, gather=self.engine.allgather_visual if self.exchange == "gvl" else None)
         else:
             ms = self.geo.max_segs
             if bs > 1 and S <= ms:

@@ -155,6 +155,71 @@ def g_phi3(ns):
     save("phi3_full_layer", dict(cfg=cfg, seed="g.phi.full", x="g.phi.full.x", x_shape=[1, 64, 3072]), logits=logits)
 
 
+class PeftLoraLinear030(torch.nn.Module):
+    """peft==0.3.0 (the version the reference pins: requirements.txt:12, README.md:52) `peft/tuners/lora.py`, class Linear(nn.Linear, LoraLayer),
+    restated for ONE adapter named "default" -- peft itself is not installed in this image [ext, restated from the published source]:
+        __init__ / update_layer:  lora_A = nn.Linear(in, r, bias=False); lora_B = nn.Linear(r, out, bias=False); scaling = lora_alpha / r;
+                                  lora_dropout = nn.Dropout(p) (identity in eval)
+        forward (not merged, r > 0):
+            result = F.linear(x, self.weight, bias=self.bias)
+            x = x.to(self.lora_A["default"].weight.dtype)
+            result += self.lora_B["default"](self.lora_A["default"](self.lora_dropout["default"](x))) * self.scaling["default"]
+            result = result.to(previous_dtype)
+    get_peft_model(model, LoraConfig(target_modules=[...])) replaces every nn.Linear whose name ends with a target by this module and
+    prefixes the whole model with `base_model.model.` -- hence the checkpoint keys `base_model.model.<path>.lora_A.default.weight`
+    (models/llava_next_video.py:212-229: r = 128, lora_alpha = 256, targets qkv_proj / o_proj / gate_up_proj / down_proj for Phi-3.5).
+    inference.py never calls merge_and_unload: the adapters run un-merged."""
+
+    def __init__(self, base: torch.nn.Linear, r: int, lora_alpha: float):
+        super().__init__()
+        self.weight, self.bias = base.weight, base.bias
+        self.lora_A = torch.nn.ModuleDict({"default": torch.nn.Linear(base.in_features, r, bias=False)})
+        self.lora_B = torch.nn.ModuleDict({"default": torch.nn.Linear(r, base.out_features, bias=False)})
+        self.lora_dropout = torch.nn.ModuleDict({"default": torch.nn.Dropout(p=0.05)})
+        self.scaling = {"default": lora_alpha / r}
+
+    def forward(self, x):
+        previous_dtype = x.dtype
+        result = torch.nn.functional.linear(x, self.weight, bias=self.bias)
+        x = x.to(self.lora_A["default"].weight.dtype)
+        result += self.lora_B["default"](self.lora_A["default"](self.lora_dropout["default"](x))) * self.scaling["default"]
+        return result.to(previous_dtype)
+
+
+def peft_wrap_(model, targets, r, lora_alpha):
+    """What get_peft_model does to the module tree (the `base_model.model.` prefix is added to the KEYS by the caller)."""
+    for name, mod in list(model.named_modules()):
+        for cname, child in list(mod.named_children()):
+            if isinstance(child, torch.nn.Linear) and cname in targets:
+                setattr(mod, cname, PeftLoraLinear030(child, r, lora_alpha))
+    return model
+
+
+def g_lora(ns):
+    """a11' pin: the REFERENCE's Phi3ForCausalLM (models/modeling_phi3.py) with its four target projections replaced by the restated
+    peft 0.3.0 LoRA Linear, loaded from a peft-KEYED state dict (grounded_video_llm_amd.synth.lora_wrap: `base_model.model.` prefix,
+    `lora_{A,B}.default.weight`), run un-merged in fp32 and in bf16 (adapters cast like llava_next_video.py:226-229 does).  Two sizes:
+    tiny (hidden 64, r = 8, alpha = 16) and one full-width layer with the real r = 128 / alpha = 256."""
+    for tag, (hidden, inter, layers, heads, vocab, r, S) in {"tiny": (64, 128, 2, 4, 100, 8, 24), "full": (3072, 8192, 1, 32, 64, 128, 64)}.items():
+        m, W = _phi(ns, hidden, inter, layers, heads, heads, vocab, f"g.lora.{tag}")
+        Wp = synth.lora_wrap(W, "phi3", r=r, seed=f"g.lora.{tag}.ab", std=0.5 * hidden ** -0.5)
+        peft_wrap_(m, ("qkv_proj", "o_proj", "gate_up_proj", "down_proj"), r, 2.0 * r)
+        sd = m.state_dict()
+        pre = "base_model.model."
+        assert sorted(pre + k for k in sd) == sorted(Wp), "peft key layout: the wrapped reference model and the synthetic checkpoint disagree"
+        m.load_state_dict({k[len(pre):]: v for k, v in Wp.items()}, strict=True)
+        m.eval()
+        x = synth.det_tensor(f"g.lora.{tag}.x", (1, S, hidden), 0.5)
+        logits = m(inputs_embeds=x, use_cache=False).logits[0, -1]
+        mb = m.to(torch.bfloat16)
+        logits_bf = mb(inputs_embeds=x.to(torch.bfloat16), use_cache=False).logits[0, -1].float()
+        keys = sorted(k for k in Wp if "lora_" in k)
+        save(f"lora_{tag}", dict(cfg=dict(kind="phi3", hidden=hidden, inter=inter, layers=layers, heads=heads, kv_heads=heads, vocab=vocab), r=r, lora_alpha=2.0 * r,
+                                 seed=f"g.lora.{tag}", ab_seed=f"g.lora.{tag}.ab", ab_std=0.5 * hidden ** -0.5, x=f"g.lora.{tag}.x", x_shape=[1, S, hidden],
+                                 lora_keys=keys, n_keys=len(Wp)),
+             logits=logits, logits_bf16ref=logits_bf)
+
+
 def g_llama(ns):
     from transformers import LlamaConfig
     cfg = dict(kind="llama", hidden=64, inter=128, layers=2, heads=4, kv_heads=2, vocab=100, rope_theta=500000.0)
@@ -870,5 +935,5 @@ if __name__ == "__main__":
     ns = ref_shims.load_reference() if any(w != "pre" for w in which) else None
     for w in which:
         {"int": g_int, "clip": g_clip, "iv2": g_iv2, "phi3": g_phi3, "llama": g_llama, "glue": g_glue, "pre": g_pre, "train": g_train, "c0": g_c0,
-         "llama_full": g_llama_full, "c3": g_c3, "c4": g_c4, "c1": g_c1,
+         "llama_full": g_llama_full, "lora": g_lora, "c3": g_c3, "c4": g_c4, "c1": g_c1,
          "free_c1": lambda n: g_free(n, "c1"), "free_c3": lambda n: g_free(n, "c3"), "free_c4": lambda n: g_free(n, "c4")}[w](ns)

@@ -26,6 +26,8 @@ class StubEngine:
         self.calls = 0
         self.hang_rank = int(os.environ.get("GVL_STUB_HANG_RANK", "-1"))
         self.rank = int(os.environ.get("RANK", "0"))
+        if os.environ.get("GVL_STUB_COMM"):             # offer the communicator entry points (a real engine always has them)
+            self.comm_unique_id, self.comm_init, self.comm_count, self.allgather_visual = self._comm_unique_id, self._comm_init, self._comm_count, self._allgather_visual
         if os.environ.get("GVL_STUB_COMM_HANG"):        # a libgvl communicator whose bootstrap never returns (bench's bounded end-of-run diagnostic)
             self.comm_unique_id = lambda: b"stub-unique-id"
             self.comm_init = lambda uid, rank, world: time.sleep(3600)
@@ -86,6 +88,23 @@ class StubEngine:
 
     def decode_greedy_batch(self, seqs, max_new, eos):
         return [self.decode_greedy(s, max_new, eos) for s in seqs]
+
+    # ---- "libgvl's own communicator": the C-ABI exchange of the real engine, played by gloo here (GVL_STUB_COMM=1) ---------------------
+    def _comm_unique_id(self):
+        return b"stub-unique-id".ljust(128, b"\0")
+
+    def _comm_init(self, uid, rank, world):
+        assert uid == self._comm_unique_id()
+        self.comm_world = world
+
+    def _comm_count(self):
+        return self.comm_world
+
+    def _allgather_visual(self, local):
+        out = torch.empty((self.comm_world * local.shape[0], local.shape[1]), dtype=local.dtype)
+        torch.distributed.all_gather_into_tensor(out, local.contiguous())
+        self.gvl_gathers = getattr(self, "gvl_gathers", 0) + 1
+        return out
 
     def kv_info(self):
         return {"total_pages": 0, "free_pages": 0, "pool_bytes": 0, "max_live_seqs": 0, "tokens": 0}

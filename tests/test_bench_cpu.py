@@ -104,3 +104,25 @@ def test_a_hung_libgvl_communicator_check_does_not_cost_the_line():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["value"] > 0 and d["n_ranks_seen_by_rccl"] == "timed out" and "hang" not in d and len(d["per_rank_stage_ms"]) == 2 and "roofline" in d
+
+
+@pytest.mark.parametrize("exchange", ["gvl", "torch"])
+def test_bench_exchange_through_the_engines_own_communicator_and_rank0_llm_mode(exchange):
+    """--exchange gvl: the all-gather of the visual tokens goes through the ENGINE's communicator (gvl_comm_init + gvl_allgather_visual on a real
+    engine; the stub plays it with gloo) in the timed region, the sharded single clip and the rank-0-LLM mode; the other collective is timed as an
+    extra.  The rank-0-LLM pipelined mode (every rank encodes, rank 0 alone runs the LLM of the round's clips) must give, clip by clip, the ids
+    the clip's own rank produces in the weak-scaling plan."""
+    if __import__("torch").cuda.is_available():
+        pytest.skip("plumbing test is for the GPU-less container")
+    outs = _run(2, ("--steps", "3", "--warmup", "1", "--new-tokens", "6", "--exchange", exchange), {"GVL_STUB_COMM": "1"})
+    for rc, o, e in outs:
+        assert rc == 0, e[-2000:]
+    lines = [l for l in outs[0][1].splitlines() if l.startswith("{")]
+    assert len(lines) == 1, outs[0][1]
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["ids_match_serial"] is True and d["exchange"].startswith(exchange)
+    other = d["clips_per_s_other_exchange"]
+    assert other["exchange"] == ("torch" if exchange == "gvl" else "gvl") and other["clips_per_s"] > 0, other
+    r0 = d["rank0_llm_pipelined"]
+    assert r0["clips_per_s"] > 0 and r0["clips_per_round"] == 2 and r0["ids_match_the_per_rank_llm"] is True, r0
+    assert d["n_ranks_seen_by_rccl"] == 2 and d["gvl_allgather_matches_rank_order"] is True

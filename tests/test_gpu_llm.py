@@ -427,6 +427,33 @@ def test_lora_merged_on_device_equals_unmerged_peft_forward(case):
     eng.close()
 
 
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_lora_peft_keyed_checkpoint_vs_reference_golden(tag):
+    """a11' pinned (round 4): tests/golden/lora_*.npz holds the logits of the REFERENCE's Phi3ForCausalLM running peft 0.3.0's LoRA Linear
+    UN-merged (oracle/make_golden.py g_lora: the reference modules, the adapter forward restated from peft's published source with its
+    citation) on a peft-keyed state dict -- `base_model.model.<path>.lora_{A,B}.default.weight`, r = 128 / alpha = 256 at full width.
+    libgvl loads the same dict (weights.pack_llm merges W' = W + (alpha / r) B A in fp32, rounds once to bf16) and must land in the
+    bf16 noise class of the reference's own bf16 evaluation of the un-merged model."""
+    from grounded_video_llm_amd import weights as Wt
+    meta, g = load_golden("lora_" + tag)
+    c = meta["cfg"]
+    geo = _phi_geo(c, max_seq=256, max_prefill=128, kv_pages=4)
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
+    Wp = synth.lora_wrap(W, "phi3", r=meta["r"], seed=meta["ab_seed"], std=meta["ab_std"])
+    assert sorted(k for k in Wp if "lora_" in k) == meta["lora_keys"]
+    eng = E.Engine(geo, DEV, towers=("llm",))
+    eng.load_packed(Wt.pack_llm(Wp, "phi3", geo.layers, geo.heads, geo.kv_heads, geo.max_seq, geo.rope_theta, geo.rope_short, geo.rope_long,
+                                geo.rope_max_pos, geo.rope_orig_max_pos, lora_alpha=meta["lora_alpha"], lora_r=meta["r"]))
+    eng.finalize()
+    x = synth.det_tensor(meta["x"], meta["x_shape"], 0.5)[0]
+    seq = eng.seq_alloc(x.shape[0] + 8)
+    got = eng.prefill(seq, x.to(DEV).to(bf), want_logits=True)
+    check_bf16_class(got, torch.as_tensor(g["logits"]), torch.as_tensor(g["logits_bf16ref"]), TINY_TOL if tag == "tiny" else 1e-2,
+                     f"LoRA {tag}: merged-on-device logits vs the reference running peft 0.3.0's un-merged forward (fp32)")
+    eng.seq_free(seq)
+    eng.close()
+
+
 def test_decode_groups_up_to_16_are_bit_identical_to_single_at_full_width():
     """Skinny-GEMM decode path (full-width Phi-3.5 layer geometry, 2 layers): 11 sequences of DIFFERENT lengths (one crosses a page
     boundary while decoding) advance together in one group -- the weights are streamed once per step for all of them -- and every

@@ -129,6 +129,34 @@ def test_phi3_full_layer():
     _close(O.llm_forward(_cfg(c), W, x), g["logits"][0], 5e-5)
 
 
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_lora_unmerged_peft_forward_and_merge_vs_reference_golden(tag):
+    """a11' (SURVEY §8): tests/golden/lora_{tiny,full}.npz = the REFERENCE's Phi3ForCausalLM with its four target projections wrapped in
+    peft 0.3.0's LoRA Linear (restated in oracle/make_golden.py with its citation; peft is not installable here) and loaded from a
+    peft-KEYED state dict.  Pins (1) the key layout (`base_model.model.<path>.lora_{A,B}.default.weight`) the packer must accept,
+    (2) the oracle's un-merged forward (_wlin) and (3) the merge W' = W + (alpha / r) B A that libgvl's loader performs."""
+    meta, g = load_golden("lora_" + tag)
+    c = meta["cfg"]
+    W = synth.llm_weights("phi3", c["hidden"], c["inter"], c["layers"], c["heads"], c["kv_heads"], c["vocab"], True, seed=meta["seed"])
+    Wp = synth.lora_wrap(W, "phi3", r=meta["r"], seed=meta["ab_seed"], std=meta["ab_std"])
+    assert sorted(k for k in Wp if "lora_" in k) == meta["lora_keys"] and len(Wp) == meta["n_keys"]
+    assert all(k.startswith("base_model.model.") for k in Wp)
+    x = synth.det_tensor(meta["x"], meta["x_shape"], 0.5)[0]
+    Wo = {k[len("base_model.model."):]: v for k, v in Wp.items()}
+    old = O.LORA_SCALE
+    O.LORA_SCALE = meta["lora_alpha"] / meta["r"]
+    try:
+        _close(O.llm_forward(_cfg(c), Wo, x, last_only=True)[0], g["logits"], 5e-5)                    # un-merged, as peft runs it
+    finally:
+        O.LORA_SCALE = old
+    from grounded_video_llm_amd import weights as Wt
+    merged = Wt._strip_peft(Wp, meta["lora_alpha"], meta["r"])
+    assert not any("lora_" in k or k.startswith("base_model.") for k in merged)
+    _close(O.llm_forward(_cfg(c), merged, x, last_only=True)[0], g["logits"], 5e-5)                   # merged in fp32: the same function
+    base = O.llm_forward(_cfg(c), W, x, last_only=True)[0]
+    assert float((base - torch.as_tensor(g["logits"])).abs().max()) > 0.05 * float(np.abs(g["logits"]).max()), "the adapters of this fixture do not matter"
+
+
 def test_llama_tiny():
     meta, g = load_golden("llama_tiny")
     c = meta["cfg"]

@@ -4,8 +4,13 @@ usage: python tools/pmc_traffic.py <fetch.db> <write.db> <out.json> [clips_in_tr
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 64 B per 128-B request for wide coalesced reads, so
 read bytes = 2 x FETCH_SIZE; both counters are in KiB-like units of 1 KB?  -- rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB."""
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _gvl_bootstrap  # noqa: E402,F401
+from grounded_video_llm_amd.build import source_sha16  # noqa: E402
 
 FAMILIES = [("gemm", ("gemm_pp_kernel", "gemm_bf16_kernel")), ("attention", ("attn_fwd_kernel",)),
             ("decode_attention", ("decode_attn_kernel",)), ("gemv", ("gemv_kernel", "dgemm_kernel"))]
@@ -36,6 +41,7 @@ def main(fetch_db, write_db, out, clips=7):
                      "total_traffic_bytes": int((rd + wr) * n)}
     doc = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --plain --mode serial_step --steps 1 --warmup 1 (tools/run_profiles.sh)",
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> read bytes = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM); fabric-side traffic incl. Infinity-Cache hits; counter unit KB",
+           "src_sha16": source_sha16(),     # the tree these counters were collected on: bench.py prints `roofline.traffic` only while it still runs that tree
            "clips_in_trace": int(clips),   # bench.py --plain --mode serial_step: (warmup + steps) x 8 clips, nothing else in the process
            "note": "`launches` counts KERNELS (a logical GEMM may run as two kernels after the wave-quantisation split); bench.py divides total_traffic_bytes by clips x logical launches per clip",
            "families": fams}

@@ -12,6 +12,13 @@ Semantics kept from 4.40.1 (batch of one, one beam group):
   * the search is done when k hypotheses exist and (early_stopping, or the worst of them is at least the best running
     sum-log-prob / cur_len ** length_penalty); at max_new_tokens the running beams are added as hypotheses;
   * the answer is the best hypothesis, with eos appended when it ended by eos.
+
+Beam-SAMPLE (`generate(num_beams=k, do_sample=True)`; reachable from inference.py:45-49,170-176; 4.40.1 GenerationMixin._beam_sample): the same
+bookkeeping, but the 2k candidates of a step are DRAWN: every running beam's log-softmax goes through the warpers (temperature -> top-k ->
+top-p, min_tokens_to_keep = 2 as HF sets it for num_beams > 1), the beam scores are added, and 2k (token, beam) pairs are sampled without
+replacement from softmax over the k x V grid, then visited in order of their score.  torch.multinomial's random stream cannot be reproduced
+across implementations (the same caveat as plain sampling, include/gvl.h): parity = same candidate distribution; draws come from a seeded
+torch.Generator, so a run is reproducible under `seed`.
 """
 from __future__ import annotations
 
@@ -52,11 +59,30 @@ class _Hyps:
         return self.worst >= best_sum_logprobs / (cur_len ** self.lp)
 
 
+def warp_scores(scores: torch.Tensor, temperature: float = 1.0, top_k: Optional[int] = 50, top_p: Optional[float] = None, min_keep: int = 2) -> torch.Tensor:
+    """transformers 4.40.1 logits warpers in generate()'s order on `scores` [rows, V] (here: log-probabilities): TemperatureLogitsWarper (scores / T),
+    TopKLogitsWarper (everything below the k-th largest -> -inf; k = max(top_k, min_keep)), TopPLogitsWarper (ascending sort, drop the tokens whose
+    cumulative probability stays <= 1 - top_p, never the last min_keep)."""
+    s = scores.float()
+    if temperature is not None and temperature != 1.0:
+        s = s / float(temperature)
+    if top_k is not None and top_k > 0:
+        kk = min(max(int(top_k), min_keep), s.shape[-1])
+        s = s.masked_fill(s < torch.topk(s, kk).values[..., -1, None], float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        srt, idx = torch.sort(s, descending=False)
+        remove = srt.softmax(dim=-1).cumsum(dim=-1) <= (1.0 - float(top_p))
+        remove[..., -min_keep:] = False
+        s = s.masked_fill(remove.scatter(-1, idx, remove), float("-inf"))
+    return s
+
+
 def beam_search(step: Callable[[List[int], List[int]], torch.Tensor], first_logits: torch.Tensor, num_beams: int, max_new_tokens: int,
-                eos_id: Optional[int], length_penalty: float = 1.0, early_stopping=False) -> List[int]:
+                eos_id: Optional[int], length_penalty: float = 1.0, early_stopping=False, sample: Optional[dict] = None) -> List[int]:
     """first_logits [vocab]: logits after the prompt.  step(parents, tokens) -> logits [k, vocab] of the k new running beams, where new beam j
     continues old beam parents[j] with tokens[j] (the caller reorders its KV cache accordingly; at the first call every parent is 0 = the
-    prompt).  Returns the NEW ids of the best hypothesis (eos included when it ended by eos), as HF does for inputs_embeds prompts."""
+    prompt).  Returns the NEW ids of the best hypothesis (eos included when it ended by eos), as HF does for inputs_embeds prompts.
+    sample: None = beam search; dict(temperature, top_k, top_p, generator) = beam-sample (module docstring)."""
     k = int(num_beams)
     if k < 2:
         raise ValueError("beam_search needs num_beams >= 2")
@@ -70,9 +96,17 @@ def beam_search(step: Callable[[List[int], List[int]], torch.Tensor], first_logi
     hyps = _Hyps(k, length_penalty, early_stopping)
     done = False
     while True:
-        lp = torch.log_softmax(logits.float(), dim=-1) + scores[:, None]
-        top = torch.topk(lp.reshape(-1), 2 * k, largest=True, sorted=True)
-        vals, idxs = top.values.tolist(), top.indices.tolist()
+        lp = torch.log_softmax(logits.float(), dim=-1)
+        if sample is None:
+            lp = lp + scores[:, None]
+            top = torch.topk(lp.reshape(-1), 2 * k, largest=True, sorted=True)
+            vals, idxs = top.values.tolist(), top.indices.tolist()
+        else:
+            lp = warp_scores(lp, sample.get("temperature", 1.0), sample.get("top_k", 50), sample.get("top_p")) + scores[:, None]
+            flat = lp.reshape(-1)
+            picks = torch.multinomial(torch.softmax(flat, dim=-1), 2 * k, replacement=False, generator=sample.get("generator"))
+            pv, order = torch.sort(flat[picks], descending=True)
+            vals, idxs = pv.tolist(), picks[order].tolist()
         cur_len = len(seqs[0]) + 1
         nxt: List[Tuple[float, int, int]] = []
         for rank, (v, ix) in enumerate(zip(vals, idxs)):

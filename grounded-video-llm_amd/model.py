@@ -243,9 +243,8 @@ class LLAVA_NEXT_VIDEO:
         """HF generate's token selection for the kwargs the reference forwards (inference.py:170-176 -> llava_next_video.py:655-661):
         greedy, or temperature -> top-k (HF default 50) -> top-p sampling on the device; `seed` (extra) makes a run reproducible,
         otherwise every call draws a fresh seed from torch's CPU generator (so torch.manual_seed governs it, as it does HF's)."""
-        if kw.get("num_beams", 1) not in (1, None) and kw.get("do_sample", False):
-            raise NotImplementedError("beam-sample (num_beams > 1 with do_sample=True) is not built; use do_sample=False for beam search or num_beams=1")
-        if not kw.get("do_sample", False):
+        if not kw.get("do_sample", False) or kw.get("num_beams", 1) not in (1, None):
+            # greedy -- and every kind of beam search: the steps return logits, the selection (top-2k, or the beam-sample draw) lives in beam.py
             self.engine.set_sampling(False)
             return
         t = kw.get("temperature", 1.0)
@@ -275,15 +274,29 @@ class LLAVA_NEXT_VIDEO:
         feats = self.encode_images(samples)
         k = generate_kwargs.get("num_beams", 1) or 1
         if k > 1:                                         # HF beam search (do_sample=False), one sample at a time
+            sample = None
+            if generate_kwargs.get("do_sample", False):      # beam-sample (HF _beam_sample): the warpers' arguments as generate() takes them; one generator per call
+                t = generate_kwargs.get("temperature", 1.0)
+                t = 1.0 if t is None else float(t)
+                if not t > 0:
+                    raise ValueError("`temperature` has to be a strictly positive float")
+                top_p = generate_kwargs.get("top_p")
+                if top_p is not None and not (0 < float(top_p) <= 1.0):
+                    raise ValueError("`top_p` has to be a float > 0 and <= 1")
+                seed = generate_kwargs.get("seed")
+                gen = torch.Generator(device=self.engine.device)
+                gen.manual_seed(int(seed) if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item()))
+                sample = dict(temperature=t, top_k=generate_kwargs.get("top_k", 50), top_p=top_p, generator=gen)
             out_ids = [self.beam_generate_ids([int(t) for t, m in zip(ids_arr[b], mask[b]) if m], feats[b], k, max_new,
-                                              float(generate_kwargs.get("length_penalty", 1.0)), generate_kwargs.get("early_stopping", False))
+                                              float(generate_kwargs.get("length_penalty", 1.0)), generate_kwargs.get("early_stopping", False), sample)
                        for b in range(ids_arr.shape[0])]
         else:
             out_ids = self.generate_ids(ids_arr, mask, feats, max_new)
         texts = self.tokenizer.batch_decode(out_ids, skip_special_tokens=True)
         return [t.strip() for t in texts]
 
-    def beam_generate_ids(self, row: List[int], vis: torch.Tensor, num_beams: int, max_new: int, length_penalty: float = 1.0, early_stopping=False) -> List[int]:
+    def beam_generate_ids(self, row: List[int], vis: torch.Tensor, num_beams: int, max_new: int, length_penalty: float = 1.0, early_stopping=False,
+                          sample: Optional[dict] = None) -> List[int]:
         """generate(num_beams = k, do_sample = False): HF beam search (beam.py restates transformers 4.40.1's scorer) on the paged KV cache.  The k running
         beams are k sequences; HF's per-step cache reorder becomes gvl_seq_clone -- a beam that continues another one shares its whole KV pages by
         reference and copies only the partial last page; the first child of a parent simply keeps the parent's sequence.  All beams advance by ONE
@@ -319,7 +332,7 @@ class LLAVA_NEXT_VIDEO:
                     return eng.decode_step_logits_batch(beams, toks)        # the k beams share ONE stream of the weights
                 return torch.stack([eng.decode_step_logits(s_, t) for s_, t in zip(beams, toks)])
 
-            return B.beam_search(step, first, num_beams, max_new, eos, length_penalty, early_stopping)
+            return B.beam_search(step, first, num_beams, max_new, eos, length_penalty, early_stopping, sample)
         finally:
             for s_ in set(x for x in list(beams) + fresh if x is not None):
                 try:

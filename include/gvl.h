@@ -162,7 +162,8 @@ int gvl_decode_greedy(gvl_ctx* ctx, int seq_id, int max_new, int eos_id, int32_t
  * that repeats the current seed while sequences are live continues the numbering instead, so newcomers never share a stream with
  * a running sequence; callers that make several generate() calls per request pass a different seed per call.)
  * torch.multinomial's random stream is not reproduced (parity = same kept set + same distribution).  Beam search (num_beams > 1, do_sample = 0) is host
- * bookkeeping over gvl_seq_clone + gvl_decode_step_logits_batch (grounded_video_llm_amd/beam.py); beam-sample is not built. */
+ * bookkeeping over gvl_seq_clone + gvl_decode_step_logits_batch (grounded_video_llm_amd/beam.py); beam-sample (num_beams > 1, do_sample = 1) is the
+ * same bookkeeping with the 2 x num_beams candidates of a step drawn on the host from the warped beam distributions (beam.py). */
 int gvl_set_sampling(gvl_ctx* ctx, int do_sample, float temperature, int top_k, float top_p, uint64_t seed);
 /* Prefill of n_seqs sequences together, seq_lens[i] tokens each (ragged: prompts differ in length; the reference left-pads and
  * masks, llava_next_video.py:622-647 -- here the rows are packed back to back, no padding).  Groups of 4 / 2 / 1 sequences whose

@@ -45,6 +45,18 @@ def test_bench_exchange_path_world1(nccl_world1):
         got = st._exchange_multi(vis, force=True)
     torch.cuda.current_stream().wait_stream(side)
     assert len(got) == 4 and all(torch.equal(a, b) for a, b in zip(got, vis))
+    # --exchange gvl: the same step exchange through libgvl's own communicator (gvl_comm_init over the process group + gvl_allgather_visual)
+    eng = E.Engine(tiny_geo(), DEV, towers=())
+    gdist.init_gvl_comm(eng)
+    st.eng, st.exchange = eng, "gvl"
+    with torch.cuda.stream(side):
+        got = st._exchange_multi(vis, force=True)
+        allc = st._exchange_multi(vis[:1], force=True, all_clips=True)              # the rank-0-LLM plan's view: every clip of the round
+    torch.cuda.current_stream().wait_stream(side)
+    assert len(got) == 4 and all(torch.equal(a, b) for a, b in zip(got, vis))
+    assert len(allc) == 1 and len(allc[0]) == 1 and torch.equal(allc[0][0], vis[0])
+    assert eng.comm_count() == 1
+    eng.close()
 
 
 def test_c_abi_rccl_communicator_world1():
@@ -64,3 +76,28 @@ def test_c_abi_rccl_communicator_world1():
     with pytest.raises(E.L.GvlError):
         eng.comm_init(uid, 0, 1)                                      # already initialised
     eng.close()
+
+
+def test_two_contexts_in_one_process():
+    """a kernel's MaxDynamicSharedMemorySize is a per-DEVICE attribute; the launchers used to remember "set" in a process-global
+    flag, so a host holding one gvl_ctx per device in one process never raised it on the second device.  It is a per-device-ordinal bit now
+    (gvl_set_max_lds).  One GPU here: two engines on it, both driving the big-LDS kernels (256^2 ping-pong GEMM: 128 KB of LDS; attention), interleaved,
+    must agree with each other -- and on a multi-GPU box the second engine goes to the last device."""
+    dev2 = f"cuda:{torch.cuda.device_count() - 1}"
+    engs = [E.Engine(tiny_geo(), d, towers=()) for d in (DEV, dev2)]
+    g = torch.Generator(device="cpu"); g.manual_seed(7)
+    A = (torch.randn((40960, 2048), generator=g) * 0.5).to(bf)                      # 160 x 4 tiles of 256^2 and K >= 1408: the persistent ping-pong kernel (128 KB LDS)
+    W = (torch.randn((1024, 2048), generator=g) * 0.02).to(bf)
+    q = (torch.randn((200, 3 * 4 * 64), generator=g) * 0.5).to(bf)                 # fused qkv rows of one sequence: 4 heads of 64, S = 200
+    outs = []
+    for rnd in range(2):
+        for eng, d in zip(engs, (DEV, dev2)):
+            with torch.cuda.device(d):
+                c = eng.op_gemm(A.to(d), W.to(d))
+                o = eng.op_attention(q.to(d), 1, 200, 4, 4, 64, 0.125, False)
+                torch.cuda.synchronize(d)
+                outs.append((c.cpu(), o.cpu()))
+    for c, o in outs[1:]:
+        assert torch.equal(c, outs[0][0]) and torch.equal(o, outs[0][1])
+    for eng in engs:
+        eng.close()

@@ -59,7 +59,7 @@ def test_generate_matches_oracle(llm):
     texts = model.generate(samples, do_sample=False, num_beams=1, max_new_tokens=10)
     assert isinstance(texts, list) and len(texts) == 1 and texts[0] == tok.batch_decode([got], skip_special_tokens=True)[0].strip()
     # the reference's default CLI configuration is SAMPLING (inference.py:45-49: do_sample True, temperature 0.2): reproducible under a
-    # seed, top_k = 1 collapses to greedy, and a later do_sample=False call is greedy again; beam search is refused
+    # seed, top_k = 1 collapses to greedy, and a later do_sample=False call is greedy again
     smp = dict(do_sample=True, num_beams=1, max_new_tokens=10, temperature=1.5, top_p=None)
     s1 = model.generate(samples, seed=11, **smp)
     assert s1 == model.generate(samples, seed=11, **smp)
@@ -69,8 +69,9 @@ def test_generate_matches_oracle(llm):
     assert model.generate(samples, do_sample=True, temperature=0.2, max_new_tokens=10)[0] is not None      # unseeded: seed from torch's generator
     with pytest.raises(ValueError):
         model.generate(samples, do_sample=True, temperature=0.0)
-    with pytest.raises(NotImplementedError):
-        model.generate(samples, do_sample=True, num_beams=2)            # beam-sample is not built
+    bs1 = model.generate(samples, do_sample=True, num_beams=2, seed=4, max_new_tokens=8)          # beam-sample (HF _beam_sample; beam.py): reproducible under a seed,
+    assert isinstance(bs1[0], str) and bs1 == model.generate(samples, do_sample=True, num_beams=2, seed=4, max_new_tokens=8)
+    assert model.engine.kv_info()["free_pages"] == model.engine.kv_info()["total_pages"]             # ... and it gives its KV pages back
     # beam search (HF generate(num_beams = k, do_sample = False); grounded_video_llm_amd/beam.py restates the scorer, CPU-tested against the
     # installed transformers): the forked KV cache (gvl_seq_clone: whole pages shared, partial page copied) must give exactly what an
     # UNSHARED recomputation gives -- every beam rebuilt from the prompt by a fresh prefill + teacher-forced decode steps

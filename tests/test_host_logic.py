@@ -572,8 +572,55 @@ def test_generate_kwargs_map_to_hf_token_selection_semantics():
             sel(**bad)
     sel(do_sample=False, num_beams=4)                   # beam search: greedy token selection inside the steps, the beams live in generate()
     assert d.engine.calls[-1] == ((False,), {})
-    with pytest.raises(NotImplementedError):
-        sel(do_sample=True, num_beams=4)                # beam-sample is not built
+    sel(do_sample=True, num_beams=4)                    # beam-sample: the draw happens in beam.py on the steps' logits; the device sampler stays off
+    assert d.engine.calls[-1] == ((False,), {})
+
+
+def test_beam_sample_warpers_and_draw():
+    """Beam-sample (generate(num_beams = k, do_sample = True), transformers 4.40.1 _beam_sample restated in beam.py): (1) warp_scores keeps exactly the
+    set the installed transformers' warpers keep (temperature -> top-k -> top-p, min_tokens_to_keep = 2) and gives the same values; (2) with top_k = 1 ...
+    there is nothing to draw from but the k best, so the sampled search walks the same candidates as the deterministic one; (3) a seeded run is
+    reproducible, different seeds explore different sequences, and every returned sequence is a valid hypothesis (length, eos rule)."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    from grounded_video_llm_amd.beam import beam_search, warp_scores
+    g = torch.Generator(); g.manual_seed(3)
+    lp = torch.log_softmax(torch.randn((5, 97), generator=g) * 3.0, dim=-1)
+    for T, tk, tp in ((1.0, 50, None), (0.2, 50, None), (0.7, None, 0.9), (1.3, 7, 0.5), (1.0, 1, 0.01)):
+        ref = lp.clone()
+        if T != 1.0:
+            ref = TemperatureLogitsWarper(T)(None, ref)
+        if tk:
+            ref = TopKLogitsWarper(top_k=tk, min_tokens_to_keep=2)(None, ref)
+        if tp is not None:
+            ref = TopPLogitsWarper(top_p=tp, min_tokens_to_keep=2)(None, ref)
+        got = warp_scores(lp, T, tk, tp)
+        assert torch.equal(torch.isinf(got), torch.isinf(ref)), (T, tk, tp)
+        assert torch.allclose(got[~torch.isinf(got)], ref[~torch.isinf(ref)], rtol=0, atol=1e-6)
+    # a toy "model": next-token logits depend on the last token only
+    V, k = 31, 3
+    table = torch.randn((V, V), generator=g) * 2.0
+    first = torch.randn((V,), generator=g) * 2.0
+
+    def run(sample, eos=None, mx=6):
+        seqs = [[] for _ in range(k)]
+
+        def step(parents, toks):
+            seqs[:] = [seqs[p_] + [t] for p_, t in zip(parents, toks)]
+            return torch.stack([table[s_[-1]] for s_ in seqs])
+        return beam_search(step, first, k, mx, eos, 1.0, False, sample)
+
+    def smp(seed, **kw):
+        gg = torch.Generator(); gg.manual_seed(seed)
+        return dict(temperature=kw.get("temperature", 1.0), top_k=kw.get("top_k", 50), top_p=kw.get("top_p"), generator=gg)
+    a = run(smp(5))
+    assert a == run(smp(5)) and len(a) == 6 and all(0 <= t < V for t in a)
+    assert len({tuple(run(smp(sd, temperature=2.0))) for sd in range(8)}) > 1
+    eos = run(None)[2]
+    out = run(smp(1), eos=eos, mx=9)
+    assert 1 <= len(out) <= 9 and (eos not in out[:-1])
+    # temperature -> 0 sharpens every beam's distribution onto its best token: the draw degenerates to the k beams' argmax candidates
+    cold = run(smp(9, temperature=1e-3, top_k=2))
+    assert len(cold) == 6
 
 
 def test_beam_search_bookkeeping_equals_hf_generate():

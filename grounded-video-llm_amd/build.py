@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 # LAB builds (A/B of two kernel variants on one GPU box, loaded through GVL_LIB_PATH): GVL_BUILD_TAG=x GVL_BUILD_DEFS="-DFOO=1" -> libgvl_x.so
 TAG = os.environ.get("GVL_BUILD_TAG", "")
 OUT = os.path.join(HERE, f"libgvl_{TAG}.so" if TAG else "libgvl.so")
-SOURCES = ["gvl_gemm.hip", "gvl_attn.hip", "gvl_elem.hip", "gvl_decode.hip", "gvl_model.hip", "gvl_host.hip", "gvl_pre.hip", "gvl_probe.hip"]
+SOURCES = ["gvl_gemm.hip", "gvl_attn.hip", "gvl_elem.hip", "gvl_decode.hip", "gvl_model.hip", "gvl_host.hip", "gvl_pre.hip", "gvl_probe.hip", "gvl_patch.hip"]
 HEADERS = ["gvl_internal.h", "gvl_ctx.h", os.path.join("..", "..", "include", "gvl.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result", "-Wno-cuda-compat",
          # MFMA accumulators in VGPRs (gfx950 has a unified file): no v_accvgpr_read/write copies around the softmax / epilogue VALU

@@ -79,6 +79,8 @@ struct gvl_ctx {
   const float* l_heads = nullptr;    // its FP8 row scales
   int fp8 = 0;                       // format of the decode copies: 0 bf16, 1 FP8 e4m3 + row scales, 2 MXFP4 (cfg.decode_fp8 and the geometry allows it)
   std::vector<void*> dw_allocs;      // tile-order weight copies owned by the ctx
+  std::vector<void*> pw_allocs;      // tile-order patch-conv weights (gvl_patch.hip)
+  const bf16_t *c_patchwt = nullptr, *v_patchwt = nullptr;   // null: the tower's geometry takes the three-pass patch embedding
   // (all decode work buffers hold GVL_MAX_DECODE_BATCH rows: one per sequence of a batched decode step)
   float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_seq_tok = nullptr, *d_seq_out = nullptr;
   int nsplit = 16, outlist_cap = 8192, ids_cap = 16384;
@@ -92,7 +94,7 @@ struct gvl_ctx {
   struct { bool on = false; float inv_temp = 1.f, top_p = 0.f; int top_k = 0; unsigned long long seed = 0; unsigned next_stream = 0; } sample;
   // result-neutral launch parameters (gvl_debug_set): 0 = the launcher's own choice.  decode_graph: a decode group's step is captured once and
   // replayed (hipGraph) for the following tokens -- the host pays one graph launch per token instead of ~165 kernel launches
-  struct { int decode_attn_cpb = 0, decode_attn_hpb = 0; bool decode_graph = true; int vision_in_place = 1, prefill_group = 4, attn_ring = 0, attn_pipe = 1; } dbg;
+  struct { int decode_attn_cpb = 0, decode_attn_hpb = 0; bool decode_graph = true; int vision_in_place = 1, prefill_group = 4, attn_ring = 0, attn_pipe = 1, patch_fused = 1; } dbg;
   // RCCL communicator owned by the ctx (gvl_comm_init); the library is dlopen'ed on first use
   void* comm = nullptr; int comm_rank = 0, comm_world = 1;
   // profiling

@@ -207,6 +207,20 @@ int gvl_launch_clip_embed_ln(const bf16_t* patch, const float* cls, const float*
                              float* x, int n_img, int P, int C, float eps, hipStream_t st);
 // IV2 embeddings: x[b,0]=bf16(cls+pos0), x[b,1+j]=bf16(patch+pos) (all bf16) -> bf16 [B,1+TL,C]
 int gvl_launch_iv2_embed(const bf16_t* patch, const bf16_t* cls, const bf16_t* pos, bf16_t* x, int B, int TL, int C, hipStream_t st);
+// ---- fused patch embedding (gvl_patch.hip): im2col in the operand loader + patch GEMM + CLS / position rows (+ CLIP's pre-LayerNorm) as ONE kernel ----
+struct PatchEmbedArgs {
+  const float* px;        // f32 [n_img][3][T][image][image]
+  const bf16_t* Wt;       // tile-order conv weight (gvl_retile_patch_weight): [C / 16][3 * patch / 2][64][8]
+  int n_img, T, image, patch, C;
+  int M;                  // patch rows = n_img * T * (image / patch)^2
+  int S;                  // output rows per image (1 + T * L)
+  int mode;               // 0: CLIP (x f32, LayerNorm), 1: InternVideo2 (x bf16, conv bias)
+  const float* bias;      // mode 1: conv bias [C]
+  const float *cls_f32, *pos_f32, *lnw, *lnb; float eps; float* x_f32;      // mode 0
+  const bf16_t *cls_bf, *pos_bf; bf16_t* x_bf;                               // mode 1
+};
+int gvl_retile_patch_weight(const bf16_t* W, bf16_t* Wt, int C, int Kp, int p, hipStream_t st);
+int gvl_launch_patch_embed(const PatchEmbedArgs& a, hipStream_t st);      // -1: geometry outside the fused kernel (caller takes the three-pass path)
 // split a fused qkv row into attention operands.
 //  mode 0 (CLIP): plain.  mode 1 (IV2): RMS-normalise q and k over the full width with weights qn/kn.
 //  mode 2 (LLM): RoPE with cos/sin tables at positions pos0+s.

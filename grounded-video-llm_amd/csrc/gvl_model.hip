@@ -156,11 +156,17 @@ int clip_encode(gvl_ctx* ctx, const float* px, int n, float* out, hipStream_t st
   AALLOC(pA, bf16_t, (size_t)n * P * ctx->c_Kp); AALLOC(pO, bf16_t, (size_t)n * P * C);
   AALLOC(Q, bf16_t, (size_t)n * H * S * D); AALLOC(Kt, bf16_t, (size_t)n * tiles * H * 64 * D); AALLOC(Vt, bf16_t, (size_t)n * tiles * H * 64 * D);
 
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_patchify(px, pA, n, 1, f.clip_image, f.clip_patch, ctx->c_Kp, st));
-  { GemmArgs g = gemm(pA, ctx->c_Kp, ctx->c_patchw, pO, C, n * P, C, ctx->c_Kp);
-    // algorithmic flops use the real K = 3*p*p, not the padded one
-    RUN(GVL_PROF_GEMM, 2.0 * n * P * (double)C * 3 * f.clip_patch * f.clip_patch, gvl_launch_gemm(g, st)); }
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_clip_embed_ln(pO, ctx->c_cls, ctx->c_pos, ctx->c_prelnw, ctx->c_prelnb, x, n, P, C, 1e-5f, st));
+  if (ctx->c_patchwt && ctx->dbg.patch_fused) {   // ONE kernel: im2col in the operand loader, patch GEMM, CLS + position rows, pre_layrnorm (gvl_patch.hip)
+    PatchEmbedArgs e; memset(&e, 0, sizeof(e)); e.px = px; e.Wt = ctx->c_patchwt; e.n_img = n; e.T = 1; e.image = f.clip_image; e.patch = f.clip_patch; e.C = C;
+    e.M = n * P; e.S = S; e.mode = 0; e.cls_f32 = ctx->c_cls; e.pos_f32 = ctx->c_pos; e.lnw = ctx->c_prelnw; e.lnb = ctx->c_prelnb; e.eps = 1e-5f; e.x_f32 = x;
+    RUN(GVL_PROF_GEMM, 2.0 * n * P * (double)C * 3 * f.clip_patch * f.clip_patch, gvl_launch_patch_embed(e, st));
+  } else {
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_patchify(px, pA, n, 1, f.clip_image, f.clip_patch, ctx->c_Kp, st));
+    { GemmArgs g = gemm(pA, ctx->c_Kp, ctx->c_patchw, pO, C, n * P, C, ctx->c_Kp);
+      // algorithmic flops use the real K = 3*p*p, not the padded one
+      RUN(GVL_PROF_GEMM, 2.0 * n * P * (double)C * 3 * f.clip_patch * f.clip_patch, gvl_launch_gemm(g, st)); }
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_clip_embed_ln(pO, ctx->c_cls, ctx->c_pos, ctx->c_prelnw, ctx->c_prelnb, x, n, P, C, 1e-5f, st));
+  }
   const bool vt_pages = !ctx->dbg.vision_in_place || D == 128;     // gvl_debug_set: the round-2 path (V^T pages written by a transpose pass), bit-identical; head dims 97..128 always take it
   for (int l = 0; l < f.clip_layers_run; ++l) {
     const ClipLayerW& w = ctx->cl[l];
@@ -194,10 +200,16 @@ int iv2_encode(gvl_ctx* ctx, const float* px, int n, bf16_t* out, hipStream_t st
   AALLOC(pA, bf16_t, (size_t)n * TL * ctx->v_Kp); AALLOC(pO, bf16_t, (size_t)n * TL * C);
   AALLOC(Q, bf16_t, (size_t)n * H * S * D); AALLOC(Kt, bf16_t, (size_t)n * tiles * H * 64 * D); AALLOC(Vt, bf16_t, (size_t)n * tiles * H * 64 * D);
 
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_patchify(px, pA, n, f.iv2_frames_per_seg, f.iv2_image, f.iv2_patch, ctx->v_Kp, st));
-  { GemmArgs g = gemm(pA, ctx->v_Kp, ctx->v_patchw, pO, C, n * TL, C, ctx->v_Kp); g.bias = ctx->v_patchb;
-    RUN(GVL_PROF_GEMM, 2.0 * n * TL * (double)C * 3 * f.iv2_patch * f.iv2_patch, gvl_launch_gemm(g, st)); }
-  RUN(GVL_PROF_OTHER, 0, gvl_launch_iv2_embed(pO, ctx->v_cls, ctx->v_pos, x, n, TL, C, st));
+  if (ctx->v_patchwt && ctx->dbg.patch_fused) {   // ONE kernel: im2col in the operand loader, patch GEMM + bias, CLS + position rows (gvl_patch.hip)
+    PatchEmbedArgs e; memset(&e, 0, sizeof(e)); e.px = px; e.Wt = ctx->v_patchwt; e.n_img = n; e.T = f.iv2_frames_per_seg; e.image = f.iv2_image; e.patch = f.iv2_patch; e.C = C;
+    e.M = n * TL; e.S = S; e.mode = 1; e.bias = ctx->v_patchb; e.cls_bf = ctx->v_cls; e.pos_bf = ctx->v_pos; e.x_bf = x;
+    RUN(GVL_PROF_GEMM, 2.0 * n * TL * (double)C * 3 * f.iv2_patch * f.iv2_patch, gvl_launch_patch_embed(e, st));
+  } else {
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_patchify(px, pA, n, f.iv2_frames_per_seg, f.iv2_image, f.iv2_patch, ctx->v_Kp, st));
+    { GemmArgs g = gemm(pA, ctx->v_Kp, ctx->v_patchw, pO, C, n * TL, C, ctx->v_Kp); g.bias = ctx->v_patchb;
+      RUN(GVL_PROF_GEMM, 2.0 * n * TL * (double)C * 3 * f.iv2_patch * f.iv2_patch, gvl_launch_gemm(g, st)); }
+    RUN(GVL_PROF_OTHER, 0, gvl_launch_iv2_embed(pO, ctx->v_cls, ctx->v_pos, x, n, TL, C, st));
+  }
   const bool vt_pages = !ctx->dbg.vision_in_place || D == 128, q_in_place = ctx->dbg.vision_in_place == 1 && D == 96 && Dr == 88;
   AALLOC(qrs, float, (size_t)M);
   for (int l = 0; l < f.iv2_blocks_run; ++l) {
@@ -666,6 +678,8 @@ int gvl_destroy(gvl_ctx* ctx) {
   for (int i = 0; i < 3; ++i) if (ctx->step_ev[i]) hipEventDestroy(ctx->step_ev[i]);
   for (auto& kv : ctx->w) if (kv.second.p) hipFree(kv.second.p);
   for (void* p : ctx->dw_allocs) if (p) hipFree(p);
+  for (void* p : ctx->pw_allocs) if (p) hipFree(p);
+  ctx->pw_allocs.clear();
   if (ctx->comm) gvl_comm_destroy(ctx);
   void* ptrs[] = {ctx->d_xn, ctx->d_seq_ngen, ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_out, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -710,9 +724,23 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
 #undef CN
     }
   }
+  // fused patch embedding (gvl_patch.hip): tile-order copies of the conv weights, for the geometries the kernel is built for
+  for (void* p : ctx->pw_allocs) if (p) hipFree(p);
+  ctx->pw_allocs.clear(); ctx->c_patchwt = ctx->v_patchwt = nullptr;
+  auto patch_tiled = [&](const bf16_t* W, int C, int Kp, int p, int image, const bf16_t** out) -> int {
+    if (p != 14 || image % p || (C != 1024 && C != 1408)) return 0;
+    void* q = nullptr;
+    if (hipMalloc(&q, (size_t)(C / 16) * (3 * p / 2) * 512 * 2) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, GVL_ERR_OOM, "hipMalloc(patch weight copy) failed"); }
+    ctx->pw_allocs.push_back(q);
+    if (gvl_retile_patch_weight(W, (bf16_t*)q, C, Kp, p, nullptr)) return fail(ctx, GVL_ERR_HIP, "patch weight retile launch failed");
+    *out = (const bf16_t*)q;
+    return 0;
+  };
+  if (ctx->has_clip && f.clip_hidden == 1024) { const int rc = patch_tiled(ctx->c_patchw, f.clip_hidden, ctx->c_Kp, f.clip_patch, f.clip_image, &ctx->c_patchwt); if (rc) return rc; }
   if (ctx->has_iv2) {
     const int C = f.iv2_dim, I = f.iv2_inter;
     NEED("iv2.patch.w", GVL_BF16, (int64_t)C * ctx->v_Kp, &ctx->v_patchw); NEED("iv2.patch.b", GVL_F32, C, &ctx->v_patchb);
+    { const int rc = patch_tiled(ctx->v_patchw, C, ctx->v_Kp, f.iv2_patch, f.iv2_image, &ctx->v_patchwt); if (rc) return rc; }
     NEED("iv2.cls", GVL_BF16, C, &ctx->v_cls); NEED("iv2.pos", GVL_BF16, (int64_t)ctx->v_S * C, &ctx->v_pos);
     ctx->vb.assign(f.iv2_blocks_run, Iv2BlockW());
     for (int l = 0; l < f.iv2_blocks_run; ++l) {
@@ -1178,6 +1206,7 @@ int gvl_debug_set(gvl_ctx* ctx, const char* key, int value) {
   else if (k == "attn_ring") { if (value != 0 && value != 2 && value != 3) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: attn_ring must be 0, 2 or 3"); ctx->dbg.attn_ring = value; }
   else if (k == "prefill_group") { if (value < 1 || value > GVL_MAX_PREFILL_BATCH) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: prefill_group must be 1 .. 8"); ctx->dbg.prefill_group = value; }
   else if (k == "attn_pipe") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: attn_pipe must be 0, 1 or 2"); ctx->dbg.attn_pipe = value; }
+  else if (k == "patch_fused") ctx->dbg.patch_fused = value != 0;
   else if (k == "vision_in_place") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: vision_in_place must be 0, 1 or 2"); ctx->dbg.vision_in_place = value; }
   else return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: unknown key " + k);
   return 0;

@@ -38,6 +38,18 @@ def test_clip(name, tol_g, tol_o):
     check(got, ref, tol_o, f"{name} vs oracle (bf16 emulation)")
     eng.debug_set("vision_in_place", 0)         # the round-2 operand path (Q / K pages + V^T transpose pass): bit-identical
     assert torch.equal(eng.clip_encode(px.to(DEV)), got)
+    eng.debug_set("vision_in_place", 1)
+    # round 4: width 1024 runs the patch embedding as ONE kernel (gvl_patch.hip); the three-pass path (patchify, GEMM, embed + LayerNorm) sums the same
+    # products in another order: equal to fp32 rounding in front of the bf16 round of the conv output -- and both hold the golden bound above
+    eng.debug_set("patch_fused", 0)
+    three = eng.clip_encode(px.to(DEV))
+    if c["hidden"] == 1024:
+        nd = int((three != got).sum())
+        print(f"[parity] {name}: fused patch embedding vs the three-pass path: {nd} of {got.numel()} values differ")
+        check(got, three.float(), 6e-3, f"{name}: fused patch embedding vs the three-pass path")
+        check(three[:, ::st[0], ::st[1]], g["penultimate"], tol_g, f"{name} (three-pass patch embedding) vs reference golden (fp32)")
+    else:
+        assert torch.equal(three, got)          # other widths: the knob changes nothing
     eng.close()
 
 
@@ -68,6 +80,15 @@ def test_iv2(name, tol_g, tol_o):
     eng.debug_set("attn_pipe", 0)              # the plain tile loop (attn_fwd_kernel) instead of the pipelined one: bit-identical
     assert torch.equal(eng.iv2_encode(px.to(DEV)), got)
     eng.debug_set("attn_pipe", 1)
+    eng.debug_set("patch_fused", 0)            # round 4: width 1408 runs the patch embedding as ONE kernel; the three-pass path sums in another order
+    three = eng.iv2_encode(px.to(DEV))
+    eng.debug_set("patch_fused", 1)
+    if c["dim"] == 1408:
+        print(f"[parity] {name}: fused patch embedding vs the three-pass path: {int((three != got).sum())} of {got.numel()} values differ")
+        check(got, three.float(), 8e-3, f"{name}: fused patch embedding vs the three-pass path")
+        check(three[:, ::st[0], ::st[1]], g["out"], tol_g, f"{name} (three-pass patch embedding) vs reference golden (fp32)")
+    else:
+        assert torch.equal(three, got)
     eng.debug_set("vision_in_place", 0)
     paged = eng.iv2_encode(px.to(DEV))
     eng.debug_set("vision_in_place", 2)

@@ -519,6 +519,7 @@ __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a)
   const int qw = qb * 128 + wave * 32;
   const int S = a.S, n_tiles = (S + 63) >> 6, v_ld = a.v_ld, Dout = a.Dout;
   const bool partial = (S & 63) != 0;
+  const int tail_keys = partial ? (S & 63) : 64;                 // real keys of the last tile
   const int last_full = partial ? n_tiles - 2 : n_tiles - 1;     // -1: the only tile is partial
 
   unsigned koff[NIK], voff[NIK];
@@ -762,7 +763,9 @@ __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a)
         if (GVL_PIPE_LAB & 8) { if (i + 2 < 12) kf[i + 2] = kf[i]; } else
 #endif
         if (i + 2 < 12) kf[i + 2] = kfrag(KS, i + 2);
-        sn[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], __builtin_bit_cast(bf16x8_t, qf[i >> 1]), i < 2 ? zero16 : sn[i & 1], 0, 0, 0);
+        // (the peeled last iteration: a partial last tile of <= 32 keys -- S = 2049: one key -- has nothing but masked scores in its second key block)
+        if (!(LAST && (i & 1) && tail_keys <= 32))
+          sn[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], __builtin_bit_cast(bf16x8_t, qf[i >> 1]), i < 2 ? zero16 : sn[i & 1], 0, 0, 0);
         fill(i);
 #ifdef GVL_PIPE_LAB
         if (GVL_PIPE_LAB & 64) {                         // one piece per group (groups 1..3 K, 5..7 V) instead of two statements of three
@@ -781,7 +784,7 @@ __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a)
         if (i == 11) vf[1] = vfrag(VS, 1);
         GVL_SB();
       }
-      if constexpr (LAST) { if (partial) mask_tail(sn, t + 1); GVL_SB(); }
+      if constexpr (LAST) { if (tail_keys <= 32) sn[1] = zero16; if (partial) mask_tail(sn, t + 1); GVL_SB(); }
       // phase 2: P.V(t) MFMAs (|| row max of S(t+1) in the safe pass)
       float l1[11], a2 = 0.f, b2 = 0.f, c2 = 0.f, mx = 0.f;
 #pragma unroll
@@ -836,14 +839,17 @@ __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const int vofs = partial ? VLAST : (tl & 1) * STAGE_BYTES + TILE_BYTES;
+      const int nst = (tail_keys + 15) >> 4;             // 16-key steps that hold real keys: the others carry P = exp2(-1e30) = 0, i.e. add exact zeros
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        const int kb = st >> 1, r0 = (st & 1) * 8;
-        union { bf16x8_t v; unsigned u[4]; } pf;
+        if (st < nst) {
+          const int kb = st >> 1, r0 = (st & 1) * 8;
+          union { bf16x8_t v; unsigned u[4]; } pf;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pf.u[e] = pack2bf(__builtin_amdgcn_exp2f(sA[kb][r0 + 2 * e]), __builtin_amdgcn_exp2f(sA[kb][r0 + 2 * e + 1]));
+          for (int e = 0; e < 4; ++e) pf.u[e] = pack2bf(__builtin_amdgcn_exp2f(sA[kb][r0 + 2 * e]), __builtin_amdgcn_exp2f(sA[kb][r0 + 2 * e + 1]));
 #pragma unroll
-        for (int db = 0; db < DB; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(vofs, st * 3 + db), pf.v, o[db], 0, 0, 0);
+          for (int db = 0; db < DB; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(vofs, st * 3 + db), pf.v, o[db], 0, 0, 0);
+        }
       }
     }
   };

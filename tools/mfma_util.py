@@ -17,10 +17,10 @@ namec = "name" if "name" in kcols else [c for c in kcols if "name" in c][0]
 dur = cur.execute(f"select sum(end-start), count(*) from kernels where {namec} like '%gemm_%'").fetchone()
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 if not bz or not dur[0]:
-    print(f"{label:10s} no counters"); sys.exit(0)
+    print(f"{label:18s} no counters"); sys.exit(0)
 cyc = bz / 32.0
 util = mf / (1024.0 * cyc)
 sec = dur[0] * 1e-9
 tf = 2.0 * M * N * K * iters / sec / 1e12
-print(f"{label:10s} M={M:6d} N={N:6d} K={K:5d}  kernels/launch={dur[1] / iters:4.1f}  {1e6 * sec / iters:8.1f} us  {tf:7.1f} TFLOP/s = {tf / 2500:5.3f} of 2.5 PF  "
+print(f"{label:18s} M={M:6d} N={N:6d} K={K:5d}  kernels/launch={dur[1] / iters:4.1f}  {1e6 * sec / iters:8.1f} us  {tf:7.1f} TFLOP/s = {tf / 2500:5.3f} of 2.5 PF  "
       f"clock {cyc / (sec * 1e9) :5.2f} GHz  MFMA pipe busy {100 * util:5.1f} %  (algorithmic MFMA cycles / busy = {2.0 * M * N * K * iters / 1024.0 / mf:5.3f})")

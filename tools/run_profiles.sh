@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-N profiling passes on the GPU box (run through gpurun): kernel traces of the default and the serial bench, the two PMC
 # traffic passes, MFMA-utilisation counters per GEMM shape.  Outputs under gpurun_out/prof_$1/ ; summaries are copied to profiles/ by hand.
-R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r03}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r04}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 WHAT=${2:-all}
 db() { find "$1" -name "*.db" | head -1; }
@@ -28,6 +28,8 @@ if [[ $WHAT == all || $WHAT == mfma ]]; then
   done <<SHAPES
 clip.patch 27648 1024 640 plain
 iv2.patch 24576 1408 640 bias
+clip.patch.benchM 55296 1024 640 plain
+iv2.patch.benchM 196608 1408 640 bias
 clip.qkv 27696 3072 1024 bias
 clip.fc1 27696 4096 1024 bias_qgelu
 clip.fc2 27696 1024 4096 bias_resid32

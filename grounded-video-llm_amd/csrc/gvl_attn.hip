@@ -503,33 +503,53 @@ __device__ __forceinline__ void glds16s_masked(const void* sbase, unsigned v, un
                : "=&s"(keep), "=&s"(ex) : "v"(v), "s"(sbase), "s"(lds_dst), "s"(mask) : "memory", "scc");
 }
 
-__global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a) {
-  constexpr int D = 96, NT = 256, DK = 6, DB = 3, CPR = 12, NIK = 3, TILE_BYTES = 64 * D * 2, STAGE_BYTES = 2 * TILE_BYTES;
+__device__ __forceinline__ void glds16x2_masked(const void* sbase, const unsigned (&v)[2], const unsigned long long (&mask)[2], unsigned lds_dst0, unsigned lds_step) {
+  unsigned keep, d;
+  unsigned long long ex;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b64 %2, exec\n\t"
+      "s_mov_b32 m0, %6\n\ts_and_b64 exec, %2, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+      "s_add_u32 %1, %6, %7\n\ts_mov_b32 m0, %1\n\ts_and_b64 exec, %2, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+      "s_mov_b64 exec, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(d), "=&s"(ex)
+      : "v"(v[0]), "v"(v[1]), "s"(sbase), "s"(lds_dst0), "s"(lds_step), "s"(mask[0]), "s"(mask[1])
+      : "memory", "scc");
+}
+
+// NW = 4 (shipped): 128 query rows per block, two blocks per CU.  NW = 8 (opt-in, measured 12 % slower: see the launcher): 256 query rows per block, ONE
+// block of eight waves per CU -- every fetched K / V tile serves twice the MFMAs: 3 instead of 6 DMA pieces per wave and tile.
+// A launch covers the query rows [a.q_begin, a.q_begin + a.q_rows) of every (batch, head).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_iv2_pipe_kernel(const AttnArgs a) {
+  constexpr int D = 96, NT = NW * 64, DK = 6, DB = 3, CPR = 12, NIK = (64 * CPR + NT - 1) / NT, TILE_BYTES = 64 * D * 2, STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int QB = NW * 32;                          // query rows per block
   constexpr int VLAST = 2 * STAGE_BYTES;               // a third V slot that only ever holds the LAST key tile when it is partial
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   // XCD-aware block -> (query block, head, batch) exactly as attn_fwd_kernel (H == KV here)
-  const int nq = (a.S + 127) / 128;
+  const int q_end = a.q_begin + a.q_rows;              // this launch's query window
+  const int nq = (a.q_rows + QB - 1) / QB;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int qb = j % nq, grp = (j / nq) * 8 + xcd;
   if (grp >= a.KV * a.B) return;
   const int b = grp / a.KV, head = grp - b * a.KV;
-  const int qw = qb * 128 + wave * 32;
+  const int qw = a.q_begin + qb * QB + wave * 32;
   const int S = a.S, n_tiles = (S + 63) >> 6, v_ld = a.v_ld, Dout = a.Dout;
   const bool partial = (S & 63) != 0;
   const int tail_keys = partial ? (S & 63) : 64;                 // real keys of the last tile
   const int last_full = partial ? n_tiles - 2 : n_tiles - 1;     // -1: the only tile is partial
 
   unsigned koff[NIK], voff[NIK];
-  unsigned long long vmask[NIK];
+  unsigned long long kmask[NIK], vmask[NIK];           // lanes of piece i that carry a chunk of the tile (NW = 8: the second piece belongs to waves 0-3 only) / a non-pad chunk
 #pragma unroll
   for (int i = 0; i < NIK; ++i) {
-    const int pos = i * NT + tid, r = pos / CPR, c = pos - r * CPR;
+    const int pos0 = i * NT + tid, pos = pos0 < 64 * CPR ? pos0 : 64 * CPR - 1, r = pos / CPR, c = pos - r * CPR;
     koff[i] = (unsigned)(r * D + KSwz<D>::logical(r, c) * 8) * 2;
     voff[i] = (unsigned)(r * v_ld + c * 8) * 2;
-    vmask[i] = __ballot(c * 8 < Dout);                 // pad chunk: no DMA (VSwz<96> is the identity); never all-off within a wave
+    kmask[i] = __ballot(pos0 < 64 * CPR);
+    vmask[i] = __ballot(pos0 < 64 * CPR && c * 8 < Dout);     // pad chunk: no DMA (VSwz<96> is the identity)
   }
   // q fragments: issued here, consumed after the first tiles are requested (one memory latency for both)
   const float sc = a.scale * 1.4426950408889634f;
@@ -561,9 +581,13 @@ __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a)
   const bf16_t* kbase = a.Kt + ((size_t)b * n_tiles * a.KV + head) * (size_t)(64 * D);       // page (b, t) = b * n_tiles + t
   const size_t kstep = (size_t)a.KV * (64 * D);
   const bf16_t* vbase = a.Vrows + (size_t)b * S * v_ld + head * Dout;
-  auto stage_k = [&](int slot, int t) { glds16xn<NIK>(kbase + (size_t)t * kstep, koff, smem_base + slot * STAGE_BYTES + wave * 1024, NT * 16); };
+  auto stage_k = [&](int slot, int t) {
+    if constexpr (NIK == 3) glds16xn<NIK>(kbase + (size_t)t * kstep, koff, smem_base + slot * STAGE_BYTES + wave * 1024, NT * 16);
+    else glds16x2_masked(kbase + (size_t)t * kstep, koff, kmask, smem_base + slot * STAGE_BYTES + wave * 1024, NT * 16);
+  };
   auto stage_v = [&](int slot, int t) {                // FULL tiles only
-    glds16x3_masked(vbase + (size_t)t * 64 * v_ld, voff, vmask, smem_base + slot * STAGE_BYTES + TILE_BYTES + wave * 1024, NT * 16);
+    if constexpr (NIK == 3) glds16x3_masked(vbase + (size_t)t * 64 * v_ld, voff, vmask, smem_base + slot * STAGE_BYTES + TILE_BYTES + wave * 1024, NT * 16);
+    else glds16x2_masked(vbase + (size_t)t * 64 * v_ld, voff, vmask, smem_base + slot * STAGE_BYTES + TILE_BYTES + wave * 1024, NT * 16);
   };
 
   f32x16_t o[DB];
@@ -596,13 +620,13 @@ __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a)
       for (int i = 0; i < NIK; ++i) {
         const int pos = i * NT + tid, r = pos / CPR, c = pos - r * CPR;
         const unsigned off = r >= rows_left ? voff[i] - (unsigned)((r - rows_left + 1) * v_ld * 2) : voff[i];
-        if (c * 8 < Dout) glds16s(vr_, off, smem_base + VLAST + wave * 1024 + i * NT * 16);
+        if (pos < 64 * CPR && c * 8 < Dout) glds16s(vr_, off, smem_base + VLAST + wave * 1024 + i * NT * 16);
       }
     }
   };
   stage_first();
 #ifndef GVL_PIPE_LAB                 // (LAB builds drop barriers / the second pass from the main path: keep every wave on it)
-  if (qw >= S) {
+  if (qw >= q_end) {
     // A wave without a single real query (3 of the 4 waves of the last query block at S = 2049: 4.4 % of all wave-tiles): it owes the block its
     // share of every DMA and every barrier, nothing else -- no fragment reads, no MFMAs, no softmax.  (attn_fwd_kernel could not afford the
     // branch inside its tile body; here the idle waves run their own loop.)  The barrier sequence mirrors run() exactly.
@@ -768,9 +792,9 @@ __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a)
           sn[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], __builtin_bit_cast(bf16x8_t, qf[i >> 1]), i < 2 ? zero16 : sn[i & 1], 0, 0, 0);
         fill(i);
 #ifdef GVL_PIPE_LAB
-        if (GVL_PIPE_LAB & 64) {                         // one piece per group (groups 1..3 K, 5..7 V) instead of two statements of three
-          if (i >= 1 && i <= 3) glds16s(kbase + (size_t)tk * kstep, koff[i - 1], smem_base + PAR * STAGE_BYTES + wave * 1024 + (i - 1) * NT * 16);
-          if (i >= 5 && i <= 7) glds16s_masked(vbase + (size_t)tv * 64 * v_ld, voff[i - 5], vmask[i - 5], smem_base + (1 - PAR) * STAGE_BYTES + TILE_BYTES + wave * 1024 + (i - 5) * NT * 16);
+        if ((GVL_PIPE_LAB & 64) && NIK == 3) {                         // one piece per group (groups 1..3 K, 5..7 V) instead of two statements of three
+          if (i >= 1 && i <= 3) glds16s(kbase + (size_t)tk * kstep, koff[(i - 1) % NIK], smem_base + PAR * STAGE_BYTES + wave * 1024 + (i - 1) * NT * 16);
+          if (i >= 5 && i <= 7) glds16s_masked(vbase + (size_t)tv * 64 * v_ld, voff[(i - 5) % NIK], vmask[(i - 5) % NIK], smem_base + (1 - PAR) * STAGE_BYTES + TILE_BYTES + wave * 1024 + (i - 5) * NT * 16);
         } else
         if (!(GVL_PIPE_LAB & 1)) {
         if (i == 1 && !(GVL_PIPE_LAB & 32)) stage_k(PAR, tk);
@@ -884,7 +908,7 @@ __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a)
   // ---- epilogue (attn_fwd_kernel's ONES branch) ---------------------------------------------------------------------------------
   const float inv = 1.f / l_tot;
   {
-    const int qs = my_q < S ? my_q : S - 1;
+    const int qs = my_q < q_end ? my_q : q_end - 1;
     char* op = (char*)(a.O + ((size_t)b * S + qs) * (size_t)(a.H * Dout) + head * Dout);
 #pragma unroll
     for (int db = 0; db < DB; ++db)
@@ -896,22 +920,34 @@ __global__ __launch_bounds__(256, 2) void attn_iv2_pipe_kernel(const AttnArgs a)
         const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false); ax = rx[0]; bx = rx[1];
         const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false); ay = ry[0]; by = ry[1];
         const int cg = db * 4 + g0 + h;
-        if (my_q < S && cg * 8 < Dout) {
+        if (my_q < q_end && cg * 8 < Dout) {
           const u32x4_t w = {ax, ay, bx, by};
           *(u32x4_t*)(op + cg * 16) = w;
         }
       }
   }
 }
-static int launch_attn_iv2_pipe(const AttnArgs& a, hipStream_t st) {
-  constexpr int LDS = 2 * 2 * 64 * 96 * 2 + 64 * 96 * 2;      // the ring + the partial-last-tile V slot: 60 KB, two blocks per CU
-  static GvlDevOnce once;
-  if (gvl_set_max_lds(once, (const void*)attn_iv2_pipe_kernel, LDS)) return -3;
-  const int nq = (a.S + 127) / 128;
-  dim3 grid((unsigned)(((a.KV * a.B + 7) / 8) * 8 * nq));
-  hipLaunchKernelGGL(attn_iv2_pipe_kernel, grid, dim3(256), LDS, st, a);
+static int launch_attn_iv2_pipe(const AttnArgs& a_in, hipStream_t st) {
+  constexpr int LDS = 2 * 2 * 64 * 96 * 2 + 64 * 96 * 2;      // the ring + the partial-last-tile V slot: 60 KB
+  static GvlDevOnce once4, once8;
+  if (gvl_set_max_lds(once4, (const void*)attn_iv2_pipe_kernel<4>, LDS) || gvl_set_max_lds(once8, (const void*)attn_iv2_pipe_kernel<8>, LDS)) return -3;
+  // a.pipe_rows == 256 (gvl_debug_set "attn_pipe_rows", tests / A-B): whole 256-row query blocks go to the 8-wave form (half the DMA pieces per MFMA), the
+  // remaining rows (S = 2049: one) to the 4-wave form in a second launch.  MEASURED SLOWER and therefore not the default: 106.5-106.8 against 95.3-95.9 ms
+  // per 39 launches, same box (profiles/r04_attention_pipe_lab.txt) -- eight waves in lock-step behind one barrier and one block per CU lose more than the
+  // halved DMA issue gives back (round 2 saw the same with 6-wave blocks).  A row's arithmetic does not depend on which form computes it (asserted).
+  const int rows8 = a_in.pipe_rows == 256 ? (a_in.S / 256) * 256 : 0;
+  const int groups8 = ((a_in.KV * a_in.B + 7) / 8) * 8;
+  if (rows8 > 0) {
+    AttnArgs a = a_in; a.q_begin = 0; a.q_rows = rows8;
+    hipLaunchKernelGGL(attn_iv2_pipe_kernel<8>, dim3((unsigned)(groups8 * (rows8 / 256))), dim3(512), LDS, st, a);
+  }
+  if (rows8 < a_in.S) {
+    AttnArgs a = a_in; a.q_begin = rows8; a.q_rows = a_in.S - rows8;
+    hipLaunchKernelGGL(attn_iv2_pipe_kernel<4>, dim3((unsigned)(groups8 * ((a.q_rows + 127) / 128))), dim3(256), LDS, st, a);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
 template <int D, int NWAVES, int NS, int ONES = 0, int VROW = 0>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
   constexpr int LDS = NS * 2 * 64 * D * 2 + 1024;   // ring + page-id table (256 pages)

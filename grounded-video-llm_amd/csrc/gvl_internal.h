@@ -172,7 +172,9 @@ struct AttnArgs {
   int ones_row;         // D > Dout only: V^T pad row Dout holds 1.0 for every key (QkvPostArgs.ones_row), so the P.V MFMAs deliver the
                         // softmax row sum in O^T[Dout] for free and the kernel drops its 32 VALU adds per key tile
   int ring;             // K/V LDS ring depth: 0 = launcher's choice, 2 or 3 (paged-KV path only)
-  int pipe;             // 1: the q_rs (InternVideo2) mode takes the software-pipelined kernel attn_iv2_pipe_kernel; 0: attn_fwd_kernel (bit-identical)
+  int pipe;             // 1: the q_rs (InternVideo2) mode takes the software-pipelined kernel attn_iv2_pipe_kernel; 0: attn_fwd_kernel (bit-identical); 2: its safe pass only
+  int pipe_rows;        // 256: whole 256-row query blocks on the 8-wave form of that kernel, the rest on the 4-wave form; anything else (default): the 4-wave form for every row
+  int q_begin, q_rows;  // set by the launcher: the query rows one attn_iv2_pipe_kernel launch covers
   float lazy;           // set by the launcher: the running max (and O) of a wave's rows is only moved when some row's tile max exceeds it by
                         // more than `lazy` (log2 units; 0 = every time it grows)
 };

@@ -219,7 +219,7 @@ int iv2_encode(gvl_ctx* ctx, const float* px, int n, bf16_t* out, hipStream_t st
     { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv; q.ld = 3 * C; q.Q = Q; q.Kt = Kt; q.Vt = vt_pages ? Vt : nullptr; q.B = n; q.S = S; q.H = H; q.KV = H; q.Dr = Dr; q.D = D;
       q.mode = 1; q.qn = w.qn; q.kn = w.kn; q.eps = 1e-6f; q.ones_row = D > Dr ? 1 : 0; q.q_rs = q_in_place ? qrs : nullptr; q.k_ones = D > Dr ? 1 : 0; RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
     { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; if (!vt_pages) { a.Vrows = qkv + 2 * C; a.v_ld = 3 * C; } a.O = att; a.B = n; a.H = H; a.KV = H; a.S = S; a.D = D; a.Dout = Dr;
-      if (q_in_place) { a.Qrows = qkv; a.q_ld = 3 * C; a.q_rs = qrs; a.q_nw = w.qn; a.k_ones = 1; a.pipe = ctx->dbg.attn_pipe; }      // q read in place, normalised by the attention prologue: no Q write pass
+      if (q_in_place) { a.Qrows = qkv; a.q_ld = 3 * C; a.q_rs = qrs; a.q_nw = w.qn; a.k_ones = 1; a.pipe = ctx->dbg.attn_pipe; a.pipe_rows = ctx->dbg.attn_pipe_rows; }      // q read in place, normalised by the attention prologue: no Q write pass
       a.scale = 1.0f / sqrtf((float)Dr); a.causal = 0; a.ones_row = D > Dr ? 1 : 0;   // head dim 88 padded to 96: the pad row of V^T carries the softmax row sum
       RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
     { GemmArgs g = gemm(att, C, w.projw, x, C, M, C, C); g.bias = w.projb; g.gamma = w.ls1; g.resid = x; g.ldr = C;
@@ -1206,6 +1206,7 @@ int gvl_debug_set(gvl_ctx* ctx, const char* key, int value) {
   else if (k == "attn_ring") { if (value != 0 && value != 2 && value != 3) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: attn_ring must be 0, 2 or 3"); ctx->dbg.attn_ring = value; }
   else if (k == "prefill_group") { if (value < 1 || value > GVL_MAX_PREFILL_BATCH) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: prefill_group must be 1 .. 8"); ctx->dbg.prefill_group = value; }
   else if (k == "attn_pipe") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: attn_pipe must be 0, 1 or 2"); ctx->dbg.attn_pipe = value; }
+  else if (k == "attn_pipe_rows") { if (value != 128 && value != 256) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: attn_pipe_rows must be 128 (default) or 256"); ctx->dbg.attn_pipe_rows = value; }
   else if (k == "patch_fused") ctx->dbg.patch_fused = value != 0;
   else if (k == "vision_in_place") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: vision_in_place must be 0, 1 or 2"); ctx->dbg.vision_in_place = value; }
   else return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: unknown key " + k);

@@ -254,6 +254,8 @@ int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launche
  *   "vision_in_place"  1 (default): non-causal attention (vision towers, gvl_op_attention) reads V -- and Q, K when the head dim needs no padding
  *                      or transform; with InternVideo2's q RMSNorm applied in the kernel prologue -- straight from the fused-qkv matrix;
  *                      2: V only; 0: the round-2 path through Q / K pages and a V^T transpose pass
+ *   "attn_pipe_rows"   128 (default): that kernel's 4-wave form (128 query rows per block) for every row; 256: whole 256-row query blocks on its 8-wave form (half
+ *                      the DMA pieces per MFMA; measured 12 % slower), the remaining rows on the 4-wave form -- bit-identical
  *   "patch_fused"      1 (default): the patch embedding of a tower whose geometry the fused kernel covers (patch 14, width 1024 / 1408) runs as ONE kernel
  *                      (gvl_patch.hip: im2col in the operand loader + GEMM + CLS / position rows + CLIP's pre-LayerNorm); 0: the three-pass path (patchify, GEMM,
  *                      embed).  NOT bit-neutral: the fp32 accumulation order over k differs (agreement to fp32 rounding before the bf16 round; tests/test_gpu_towers.py)

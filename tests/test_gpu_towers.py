@@ -128,7 +128,7 @@ def test_towers_at_other_head_dims(tower, hidden, heads):
     eng.close()
 
 
-@pytest.mark.parametrize("image,frames,sharp", [(56, 2, 1), (56, 4, 1), (56, 8, 3), (56, 12, 1), (56, 16, 12), (14, 63, 1), (14, 127, 3), (14, 191, 1), (42, 71, 12), (112, 9, 3), (112, 9, 1), (56, 16, 60)])
+@pytest.mark.parametrize("image,frames,sharp", [(56, 2, 1), (56, 4, 1), (56, 8, 3), (56, 12, 1), (56, 16, 12), (14, 63, 1), (14, 127, 3), (14, 191, 1), (42, 71, 12), (112, 9, 3), (112, 9, 1), (56, 16, 60), (112, 16, 1), (14, 255, 3), (14, 511, 12)])
 def test_iv2_pipelined_attention_against_the_plain_kernel(image, frames, sharp):
     """Round 4: InternVideo2's attention runs a software-pipelined key-tile loop (attn_iv2_pipe_kernel: S^T of tile t+1 and P.V of tile t
     carry the exp2 + pack work of tile t in their shadow, every MFMA heading a fenced group of <= 3 VALU fillers).  Its normal pass keeps
@@ -168,6 +168,12 @@ def test_iv2_pipelined_attention_against_the_plain_kernel(image, frames, sharp):
     assert nf_got == 0 and nf_plain == 0, f"S = {S}, sharp x{sharp}: non-finite outputs: pipelined {nf_got}, plain {nf_plain} of {got.numel()}"
     again = eng.iv2_encode(px.to(DEV))
     assert torch.equal(got, again), f"S = {S}, sharp x{sharp}: the pipelined kernel is not reproducible ({int((got != again).sum())} values differ between two runs)"
+    # opt-in: whole 256-row query blocks on the 8-wave form of the kernel (half the DMA pieces per MFMA; measured slower), the rest on the 4-wave form;
+    # a row's arithmetic does not depend on the form
+    eng.debug_set("attn_pipe_rows", 256)
+    eight = eng.iv2_encode(px.to(DEV))
+    eng.debug_set("attn_pipe_rows", 128)
+    assert torch.equal(got, eight), f"S = {S}, sharp x{sharp}: 8-wave and 4-wave forms differ in {int((got != eight).sum())} values"
     nbad = int((got != plain).sum())
     dmax = float((got.float() - plain.float()).abs().max() / plain.float().abs().max())
     print(f"[parity] iv2 pipelined attention S = {S} ({(S + 63) // 64} key tiles), sharp x{sharp}: {nbad} of {got.numel()} values differ from the plain kernel (max {dmax:.2e} of the scale)")

@@ -101,3 +101,32 @@ def test_two_contexts_in_one_process():
         assert torch.equal(c, outs[0][0]) and torch.equal(o, outs[0][1])
     for eng in engs:
         eng.close()
+
+
+def test_model_encode_images_through_the_gvl_exchange_world1(nccl_world1):
+    """LLAVA_NEXT_VIDEO(group = the default process group, exchange = "gvl"): encode_images shards the segments (world 1: all of them), builds libgvl's own
+    communicator over the group (dist.init_gvl_comm) and all-gathers the token blocks with gvl_allgather_visual -- the product path of the C-ABI exchange.
+    Must equal the same model's un-distributed encode bit for bit, and exchange = "torch" likewise."""
+    from grounded_video_llm_amd import synth
+    from grounded_video_llm_amd.model import LLAVA_NEXT_VIDEO, SyntheticTokenizer
+    hid, vocab = 128, 640
+    short, long = synth.longrope_factors(32)
+    geo = E.TowerGeometry(llm="phi3.5", clip_hidden=64, clip_inter=128, clip_layers=3, clip_heads=4, iv2_dim=64, iv2_inter=128, iv2_depth=3, iv2_heads=4, hidden=hid,
+                          inter=256, layers=2, heads=4, kv_heads=4, vocab=vocab, rope_short=short, rope_long=long, rope_theta=10000.0, max_seq=2048, max_segs=6,
+                          kv_pages=40, max_prefill=1024)
+    sd = {"vision_tower": synth.clip_weights(64, 128, 3, seed="gen.clip"), "video_encoder": synth.iv2_weights(64, 128, 3, 2, seed="gen.iv2"),
+          "projectors": synth.projector_weights("phi3.5", hid, 64, 64, seed="gen.proj"), "language_model": synth.llm_weights("phi3", hid, 256, 2, 4, 4, vocab, True, seed="gen.llm")}
+    tok = SyntheticTokenizer(vocab, 300)
+    samples = {"spatial_pixel_values": synth.det_tensor("gen.sp", (1, 2, 3, 336, 336)).to(DEV), "temporal_pixel_values": synth.det_tensor("gen.tp", (1, 4, 3, 224, 224)).to(DEV)}
+    outs = {}
+    for exchange in ("gvl", "torch"):
+        m = LLAVA_NEXT_VIDEO(stage="sft", max_txt_len=64, num_frames=4, num_segs=2, num_temporal_tokens=300, lora=False, llm="phi3.5", geometry=geo, tokenizer=tok,
+                             state_dicts=sd, device=DEV, group=torch.distributed.group.WORLD, exchange=exchange)
+        outs[exchange] = m.encode_images(samples).clone()
+        if exchange == "gvl":
+            assert m.engine.comm_count() == 1 and getattr(m.engine, "comm_world", 0) == 1
+            m.group = None                                        # the un-distributed path of the same model
+            plain = m.engine.encode_segments(samples["spatial_pixel_values"][0], samples["temporal_pixel_values"].reshape(1, 2, 2, 3, 224, 224).permute(0, 1, 3, 2, 4, 5).flatten(0, 1).contiguous())
+            assert torch.equal(outs["gvl"][0], plain)
+        m.engine.close()
+    assert torch.equal(outs["gvl"], outs["torch"])

@@ -28,7 +28,7 @@ for rnd in range(rounds):
     for mode in VALUES:
         eng.debug_set(KEY, mode)
         for name, fn in runs.items():
-            if KEY == "attn_pipe" and name == "clip":
+            if KEY.startswith("attn_pipe") and name == "clip":
                 continue
             out = fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

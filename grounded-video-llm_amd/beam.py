@@ -90,8 +90,11 @@ def beam_search(step: Callable[[List[int], List[int]], torch.Tensor], first_logi
     if V < 2 * k:
         raise ValueError("vocabulary smaller than 2 x num_beams")
     seqs: List[List[int]] = [[] for _ in range(k)]
-    scores = torch.full((k,), -1e9, dtype=torch.float32, device=first_logits.device)
-    scores[0] = 0.0
+    # transformers 4.40.1: _beam_search starts beams 1..k-1 at -1e9 (the first step expands beam 0 only); _beam_sample starts EVERY beam at 0 -- its
+    # first draw is over k identical rows, so the same token may be drawn from two rows and the running beams may start as duplicates
+    scores = torch.zeros((k,), dtype=torch.float32, device=first_logits.device)
+    if sample is None:
+        scores[1:] = -1e9
     logits = first_logits.float().unsqueeze(0).expand(k, V)
     hyps = _Hyps(k, length_penalty, early_stopping)
     done = False
@@ -104,6 +107,10 @@ def beam_search(step: Callable[[List[int], List[int]], torch.Tensor], first_logi
         else:
             lp = warp_scores(lp, sample.get("temperature", 1.0), sample.get("top_k", 50), sample.get("top_p")) + scores[:, None]
             flat = lp.reshape(-1)
+            n_fin = int(torch.isfinite(flat).sum())
+            if n_fin < 2 * k:                                # torch.multinomial(replacement=False) would silently hand back zero-probability indices
+                raise ValueError(f"beam-sample: only {n_fin} tokens survive the warpers but 2 x num_beams = {2 * k} draws are needed "
+                                 "(raise top_p / top_k / temperature, or lower num_beams)")
             picks = torch.multinomial(torch.softmax(flat, dim=-1), 2 * k, replacement=False, generator=sample.get("generator"))
             pv, order = torch.sort(flat[picks], descending=True)
             vals, idxs = pv.tolist(), picks[order].tolist()
@@ -122,7 +129,8 @@ def beam_search(step: Callable[[List[int], List[int]], torch.Tensor], first_logi
         if len(nxt) < k:
             raise ValueError("fewer than num_beams non-eos candidates among the top 2 x num_beams")
         done = done or hyps.is_done(max(vals), cur_len)
-        parents, toks = [b for _, _, b in nxt], [t for _, t, _ in nxt]
+        # first step: every row is the prompt itself (beam-sample may have drawn from rows >= 1 of its k identical rows) -> parent 0
+        parents, toks = [0 if cur_len == 1 else b for _, _, b in nxt], [t for _, t, _ in nxt]
         seqs = [seqs[b] + [t] for _, t, b in nxt]
         scores = torch.tensor([v for v, _, _ in nxt], dtype=torch.float32, device=first_logits.device)
         if done or len(seqs[0]) >= max_new_tokens:

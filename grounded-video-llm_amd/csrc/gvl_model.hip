@@ -156,11 +156,17 @@ int clip_encode(gvl_ctx* ctx, const float* px, int n, float* out, hipStream_t st
   AALLOC(pA, bf16_t, (size_t)n * P * ctx->c_Kp); AALLOC(pO, bf16_t, (size_t)n * P * C);
   AALLOC(Q, bf16_t, (size_t)n * H * S * D); AALLOC(Kt, bf16_t, (size_t)n * tiles * H * 64 * D); AALLOC(Vt, bf16_t, (size_t)n * tiles * H * 64 * D);
 
+  bool fused_done = false;
   if (ctx->c_patchwt && ctx->dbg.patch_fused) {   // ONE kernel: im2col in the operand loader, patch GEMM, CLS + position rows, pre_layrnorm (gvl_patch.hip)
     PatchEmbedArgs e; memset(&e, 0, sizeof(e)); e.px = px; e.Wt = ctx->c_patchwt; e.n_img = n; e.T = 1; e.image = f.clip_image; e.patch = f.clip_patch; e.C = C;
     e.M = n * P; e.S = S; e.mode = 0; e.cls_f32 = ctx->c_cls; e.pos_f32 = ctx->c_pos; e.lnw = ctx->c_prelnw; e.lnb = ctx->c_prelnb; e.eps = 1e-5f; e.x_f32 = x;
-    RUN(GVL_PROF_GEMM, 2.0 * n * P * (double)C * 3 * f.clip_patch * f.clip_patch, gvl_launch_patch_embed(e, st));
-  } else {
+    int prc = 0;
+    { ProfScope ps_(ctx, GVL_PROF_GEMM, 2.0 * n * P * (double)C * 3 * f.clip_patch * f.clip_patch, st); prc = gvl_launch_patch_embed(e, st); }
+    if (prc == -3) return fail(ctx, GVL_ERR_HIP, "launch failed: gvl_launch_patch_embed (clip)");
+    fused_done = prc == 0;                         // -1: geometry outside the fused kernel (e.g. > 4 G pixel elements per call) -> the three passes below
+    if (!fused_done && ctx->prof && !ctx->recs.empty()) ctx->recs.back().work = 0;   // nothing was launched: the fallback's GEMM carries the flops
+  }
+  if (!fused_done) {
     RUN(GVL_PROF_OTHER, 0, gvl_launch_patchify(px, pA, n, 1, f.clip_image, f.clip_patch, ctx->c_Kp, st));
     { GemmArgs g = gemm(pA, ctx->c_Kp, ctx->c_patchw, pO, C, n * P, C, ctx->c_Kp);
       // algorithmic flops use the real K = 3*p*p, not the padded one
@@ -200,11 +206,17 @@ int iv2_encode(gvl_ctx* ctx, const float* px, int n, bf16_t* out, hipStream_t st
   AALLOC(pA, bf16_t, (size_t)n * TL * ctx->v_Kp); AALLOC(pO, bf16_t, (size_t)n * TL * C);
   AALLOC(Q, bf16_t, (size_t)n * H * S * D); AALLOC(Kt, bf16_t, (size_t)n * tiles * H * 64 * D); AALLOC(Vt, bf16_t, (size_t)n * tiles * H * 64 * D);
 
+  bool fused_done = false;
   if (ctx->v_patchwt && ctx->dbg.patch_fused) {   // ONE kernel: im2col in the operand loader, patch GEMM + bias, CLS + position rows (gvl_patch.hip)
     PatchEmbedArgs e; memset(&e, 0, sizeof(e)); e.px = px; e.Wt = ctx->v_patchwt; e.n_img = n; e.T = f.iv2_frames_per_seg; e.image = f.iv2_image; e.patch = f.iv2_patch; e.C = C;
     e.M = n * TL; e.S = S; e.mode = 1; e.bias = ctx->v_patchb; e.cls_bf = ctx->v_cls; e.pos_bf = ctx->v_pos; e.x_bf = x;
-    RUN(GVL_PROF_GEMM, 2.0 * n * TL * (double)C * 3 * f.iv2_patch * f.iv2_patch, gvl_launch_patch_embed(e, st));
-  } else {
+    int prc = 0;
+    { ProfScope ps_(ctx, GVL_PROF_GEMM, 2.0 * n * TL * (double)C * 3 * f.iv2_patch * f.iv2_patch, st); prc = gvl_launch_patch_embed(e, st); }
+    if (prc == -3) return fail(ctx, GVL_ERR_HIP, "launch failed: gvl_launch_patch_embed (iv2)");
+    fused_done = prc == 0;
+    if (!fused_done && ctx->prof && !ctx->recs.empty()) ctx->recs.back().work = 0;
+  }
+  if (!fused_done) {
     RUN(GVL_PROF_OTHER, 0, gvl_launch_patchify(px, pA, n, f.iv2_frames_per_seg, f.iv2_image, f.iv2_patch, ctx->v_Kp, st));
     { GemmArgs g = gemm(pA, ctx->v_Kp, ctx->v_patchw, pO, C, n * TL, C, ctx->v_Kp); g.bias = ctx->v_patchb;
       RUN(GVL_PROF_GEMM, 2.0 * n * TL * (double)C * 3 * f.iv2_patch * f.iv2_patch, gvl_launch_gemm(g, st)); }
@@ -724,7 +736,9 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
 #undef CN
     }
   }
-  // fused patch embedding (gvl_patch.hip): tile-order copies of the conv weights, for the geometries the kernel is built for
+  // fused patch embedding (gvl_patch.hip): tile-order copies of the conv weights, for the geometries the kernel is built for.
+  // A repeated finalize frees the previous copies: encodes still in flight on other streams may be reading them -- drain the device first.
+  if (!ctx->pw_allocs.empty()) HIPCHK(ctx, hipDeviceSynchronize());
   for (void* p : ctx->pw_allocs) if (p) hipFree(p);
   ctx->pw_allocs.clear(); ctx->c_patchwt = ctx->v_patchwt = nullptr;
   auto patch_tiled = [&](const bf16_t* W, int C, int Kp, int p, int image, const bf16_t** out) -> int {
@@ -827,9 +841,11 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
         if (rc) return rc;
       }
       { const int rc = tiled(ctx->l_headw, f.vocab, Hd, 0, 0, &ctx->l_headd, &ctx->l_heads); if (rc) return rc; }
-      HIPCHK(ctx, hipDeviceSynchronize());
     }
   }
+  // the retile kernels above (patch weights, decode tile copies) ran on the null stream: a first encode / decode on a NON-blocking stream (torch pool
+  // streams, the bench's sV / sL) is not ordered behind them -- finalize returns only when every derived copy is complete
+  HIPCHK(ctx, hipDeviceSynchronize());
   if (ctx->has_llm && !ctx->kpool) {          // cfg.kv_pages <= 0: size the pool from what is free NOW (weights resident)
     const char* fe = getenv("GVL_KV_FRACTION");
     const double frac = fe ? atof(fe) : 0.85;

@@ -260,8 +260,13 @@ int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launche
  *                      (gvl_patch.hip: im2col in the operand loader + GEMM + CLS / position rows + CLIP's pre-LayerNorm); 0: the three-pass path (patchify, GEMM,
  *                      embed).  NOT bit-neutral: the fp32 accumulation order over k differs (agreement to fp32 rounding before the bf16 round; tests/test_gpu_towers.py)
  *   "attn_pipe"        1 (default): InternVideo2's attention (head dim 88, q in place) runs the software-pipelined key-tile loop
- *                      (attn_iv2_pipe_kernel, round 4); 0: the plain loop of attn_fwd_kernel -- bit-identical (tests/test_gpu_towers.py)
- * None of them may change a single output bit (asserted in tests/test_gpu_llm.py) -- with ONE stated exception: "vision_in_place" = 1 on a head
+ *                      (attn_iv2_pipe_kernel, round 4); 0: the plain loop of attn_fwd_kernel; 2: the pipelined kernel's SAFE pass alone.  Bit-identical to 0
+ *                      WHILE attn_fwd_kernel's lazy rule never fires after a row's first key tile (every golden, the bench: asserted in
+ *                      tests/test_gpu_towers.py); the pipelined normal pass keeps the first tile's maximum as the softmax reference for the whole row, so on
+ *                      scores where a later tile exceeds it by more than 2^8 the two differ at P-rounding level (bounded at 1.5e-2 of the output scale by
+ *                      the sharp-score test there) -- the second stated exception below; mode 2 is bit-identical to 0 on any data
+ * None of them may change a single output bit (asserted in tests/test_gpu_llm.py) -- with TWO stated exceptions: "attn_pipe" = 1 on peaked scores
+ * (above), and "vision_in_place" = 1 on a head
  * dim that is padded (InternVideo2, 88 -> 96) folds the softmax scale and shift into q before its one rounding to bf16, a different (not larger)
  * set of rounding points: modes 0 and 2 are bit-identical to each other, mode 1 is bit-identical to them for CLIP (head dim 64) and agrees within
  * bf16 noise for InternVideo2 (one block 4.1e-3 of the output scale; 39 blocks vs the reference: the same error as the reference's own bf16,

@@ -621,6 +621,21 @@ def test_beam_sample_warpers_and_draw():
     # temperature -> 0 sharpens every beam's distribution onto its best token: the draw degenerates to the k beams' argmax candidates
     cold = run(smp(9, temperature=1e-3, top_k=2))
     assert len(cold) == 6
+    # 4.40.1's _beam_sample starts every beam at score 0: the first draw is over k identical rows, so every first-step parent is the prompt (0)
+    # whichever row a pick came from -- the caller holds ONE sequence at that point (model.beam_generate_ids) -- and duplicates are legal
+    first_parents = []
+
+    def step_rec(parents, toks):
+        if not first_parents:
+            first_parents.extend(parents)
+        return torch.stack([table[t] for t in toks])
+    beam_search(step_rec, first, k, 3, None, 1.0, False, smp(2, temperature=3.0))
+    assert first_parents == [0] * k
+    # every row keeps min_tokens_to_keep = 2 candidates, so with all k rows live from the first step (scores 0) the 2k draws always exist -- the case
+    # ADVICE r4 describes (top_p small at temperature 0.2, k >= 3: two finite candidates in the one live row) is gone with the -1e9 initialisation;
+    # beam_search still refuses to draw from fewer than 2k finite entries instead of trusting torch.multinomial's silent zero-probability picks
+    out = beam_search(step_rec, first, 4, 3, None, 1.0, False, smp(2, temperature=0.2, top_k=1, top_p=0.01))
+    assert len(out) == 3
 
 
 def test_beam_search_bookkeeping_equals_hf_generate():

@@ -82,7 +82,11 @@ __device__ __forceinline__ int kperm(int i) {
 // VROW = 2: Q and K are token rows too (a.Qrows / a.Krows; needs D == Dout and no per-token transform of q / k: CLIP) -- no qkv_post pass at all.
 // VROW: V comes as token rows of a row-major matrix (a.Vrows, row stride a.v_ld, head h at column h * Dout) instead of V^T pages; the pad
 // columns Dout..D-1 of the LDS image are written once by the kernel (1.0 in column Dout when ONES) and skipped by the DMA.
-template <int D, int NWAVES, int NS, int ONES = 0, int VROW = 0>
+// VL = 1 (paged causal prefill only): RAGGED batch in ONE grid -- the launch covers a.vl_n sequences whose rows are packed back to back
+// (sequence u: rows [vl_rows[u], vl_rows[u + 1]) of Q / O, its own block table vl_tables[u]); a workgroup id decodes to (sequence, query
+// block) through the <= 8 prefix sums, everything after that is the single-sequence kernel on that sequence's (S, Q, O, table) -- the
+// same instructions on the same values, so every row is bit-identical to a launch of its sequence alone.
+template <int D, int NWAVES, int NS, int ONES = 0, int VROW = 0, int VL = 0>
 __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int NT = NWAVES * 64;
   constexpr int DK = D / 16;          // k-steps of the QK^T contraction
@@ -103,18 +107,31 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   // natural (q-block fastest) order the 17 query blocks of one (batch, head) would pull the same K/V pages through 8 different
   // L2s (measured 2.5x fetch amplification).  Here every (batch, head) lives on ONE XCD: id = 8*j + xcd, j = local*nq + qb.
   // (With grouped-query attention the unit is the (batch, KV head) GROUP: its H/KV query heads share the pages too.)
-  const int nq = (a.S + NWAVES * 32 - 1) / (NWAVES * 32), rep = a.H / a.KV;
+  int S_ = a.S;                                       // queries of THIS block's sequence (VL: decoded below)
+  const bf16_t* Qp_ = a.Q; bf16_t* Op_ = a.O; const int* tbl_ = a.block_table;
+  int nq = (a.S + NWAVES * 32 - 1) / (NWAVES * 32);
+  const int rep = a.H / a.KV;
+  if constexpr (VL) { nq = 0; for (int u = 0; u < a.vl_n; ++u) nq += (a.vl_rows[u + 1] - a.vl_rows[u] + NWAVES * 32 - 1) / (NWAVES * 32); }   // query blocks of all sequences
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int qb_ = j % nq, t_ = j / nq, member = t_ % rep, grp = (t_ / rep) * 8 + xcd;
-  const int qb = a.causal ? nq - 1 - qb_ : qb_;     // causal: the late query blocks see the most keys -- dispatch them FIRST, the short ones fill the tail
+  int qb = a.causal ? nq - 1 - qb_ : qb_;           // causal: the late query blocks see the most keys -- dispatch them FIRST, the short ones fill the tail
   if (grp >= a.KV * a.B) return;                     // grid is padded to a multiple of 8 groups; uniform per block
   const int b = grp / a.KV, head = (grp - b * a.KV) * rep + member;
+  if constexpr (VL) {                                // flattened (sequence-major) query block -> (sequence u, block of u); wave-uniform scalar loop
+    int u = 0, nqu = (a.vl_rows[1] - a.vl_rows[0] + NWAVES * 32 - 1) / (NWAVES * 32);
+    while (qb >= nqu && u + 1 < a.vl_n) { qb -= nqu; ++u; nqu = (a.vl_rows[u + 1] - a.vl_rows[u] + NWAVES * 32 - 1) / (NWAVES * 32); }
+    const int r0 = a.vl_rows[u];
+    S_ = a.vl_rows[u + 1] - r0;
+    Qp_ = a.Q + (size_t)r0 * a.H * D;                // sequence u's [H][S_u][D] block starts at its first packed row
+    Op_ = a.O + (size_t)r0 * (size_t)(a.H * a.Dout);
+    tbl_ = a.vl_tables[u];
+  }
   const int hkv = head / (a.H / a.KV);
   const int q0 = qb * (NWAVES * 32);
   const int qw = q0 + wave * 32;
-  const int Sk = a.Sk > 0 ? a.Sk : a.S, qpos0 = a.qpos0;    // keys of the context; absolute position of query 0 (extend-prefill: the cached prefix comes first)
+  const int Sk = a.Sk > 0 ? a.Sk : S_, qpos0 = a.qpos0;    // keys of the context; absolute position of query 0 (extend-prefill: the cached prefix comes first)
   const int n_tiles_all = (Sk + 63) >> 6;
-  int last_q = q0 + NWAVES * 32 - 1; if (last_q > a.S - 1) last_q = a.S - 1;
+  int last_q = q0 + NWAVES * 32 - 1; if (last_q > S_ - 1) last_q = S_ - 1;
   const int n_tiles = a.causal ? ((qpos0 + last_q) >> 6) + 1 : n_tiles_all;
 
   // ---- DMA source offsets inside a page (elements), loop invariant --------------------------------
@@ -146,11 +163,11 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   u32x4_t qraw[DK], qw_[VROW == 3 ? DK : 1];
   float q_rs = 1.f;
   {
-    int qi = qw + l31; if (qi > a.S - 1) qi = a.S - 1;
+    int qi = qw + l31; if (qi > S_ - 1) qi = S_ - 1;
     if constexpr (VROW == 3) {                        // q in place + InternVideo2's full-width RMSNorm (qkv_post_kernel::norm_chunk, same rounding points)
-      const bf16_t* qp = a.Qrows + ((size_t)b * a.S + qi) * a.q_ld + head * a.Dout + 8 * h;
+      const bf16_t* qp = a.Qrows + ((size_t)b * S_ + qi) * a.q_ld + head * a.Dout + 8 * h;
       const bf16_t* wp = a.q_nw + head * a.Dout + 8 * h;
-      q_rs = a.q_rs[(size_t)b * a.S + qi];
+      q_rs = a.q_rs[(size_t)b * S_ + qi];
 #pragma unroll
       for (int kk = 0; kk < DK; ++kk) {
         const bool real = kk * 16 + 8 * h < a.Dout;   // Dout is a multiple of 8: a chunk is all real or all padding
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
         qw_[kk] = real ? *(const u32x4_t*)(wp + kk * 16) : u32x4_t{0u, 0u, 0u, 0u};
       }
     } else {
-      const bf16_t* qp = VROW == 2 ? a.Qrows + ((size_t)b * a.S + qi) * a.q_ld + head * D + 8 * h : a.Q + (((size_t)b * a.H + head) * a.S + qi) * D + 8 * h;
+      const bf16_t* qp = VROW == 2 ? a.Qrows + ((size_t)b * S_ + qi) * a.q_ld + head * D + 8 * h : Qp_ + (((size_t)b * a.H + head) * S_ + qi) * D + 8 * h;
 #pragma unroll
       for (int kk = 0; kk < DK; ++kk) qraw[kk] = *(const u32x4_t*)(qp + kk * 16);
     }
@@ -167,7 +184,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   // page ids of this (b) row of the block table, staged in LDS once: a per-iteration global load of the table would
   // make hipcc wait vmcnt(0) (draining the DMA ring) every tile
   int* pages_s = (int*)(smem + NS * STAGE_BYTES);
-  for (int i = tid; i < n_tiles; i += NT) pages_s[i] = a.block_table ? a.block_table[b * a.max_pages + i] : b * n_tiles_all + i;
+  for (int i = tid; i < n_tiles; i += NT) pages_s[i] = tbl_ ? tbl_[b * a.max_pages + i] : b * n_tiles_all + i;
   if constexpr (VROW) {                              // pad columns of the V image, both ring slots, once
     const int npc = CPR - (a.Dout >> 3);
     for (int i = tid; i < NS * 64 * npc; i += NT) {
@@ -186,9 +203,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
     const bf16_t* vp = a.Vt + pb;
     const unsigned base = smem_base + buf * STAGE_BYTES + wave * 1024;
     if constexpr (VROW) {
-      const int rows_left = a.S - t * 64;            // wave-uniform; < 64 only in the last tile: rows past the end re-read the last real key row (P = 0 there)
+      const int rows_left = S_ - t * 64;            // wave-uniform; < 64 only in the last tile: rows past the end re-read the last real key row (P = 0 there)
       if constexpr (VROW == 2) {
-        const bf16_t* kr_ = a.Krows + ((size_t)b * a.S + (size_t)t * 64) * a.k_ld + hkv * D;
+        const bf16_t* kr_ = a.Krows + ((size_t)b * S_ + (size_t)t * 64) * a.k_ld + hkv * D;
         if (rows_left >= 64) {
           if constexpr (NIK == 2 || NIK == 3) glds16xn<NIK>(kr_, koff, base, NT * 16);
           else {
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
       } else {
         glds16xn<NIK>(kp, koff, base, NT * 16);
       }
-      const bf16_t* vr_ = a.Vrows + ((size_t)b * a.S + (size_t)t * 64) * a.v_ld + hkv * a.Dout;
+      const bf16_t* vr_ = a.Vrows + ((size_t)b * S_ + (size_t)t * 64) * a.v_ld + hkv * a.Dout;
       if (rows_left >= 64) {                         // wave-uniform
 #pragma unroll
         for (int i = 0; i < NIK; ++i)
@@ -436,8 +453,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
   // one v_permlane32_swap per dword pairs the column groups (g, g+1): afterwards the lower half-wave owns all 8 columns of
   // group g and the upper half-wave those of group g+1 -> one 16-byte store per lane per pair instead of two 8-byte ones.
   {
-    const int qs = my_q < a.S ? my_q : a.S - 1;
-    char* op = (char*)(a.O + ((size_t)b * a.S + qs) * (size_t)(a.H * a.Dout) + head * a.Dout);
+    const int qs = my_q < S_ ? my_q : S_ - 1;
+    char* op = (char*)(Op_ + ((size_t)b * S_ + qs) * (size_t)(a.H * a.Dout) + head * a.Dout);
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -448,7 +465,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnArgs a)
         const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false); ax = rx[0]; bx = rx[1];
         const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false); ay = ry[0]; by = ry[1];
         const int grp = db * 4 + g0 + h;           // column group this lane now owns entirely
-        if (my_q < a.S && grp * 8 < a.Dout) {
+        if (my_q < S_ && grp * 8 < a.Dout) {
           const u32x4_t w = {ax, ay, bx, by};
           *(u32x4_t*)(op + grp * 16) = w;
         }
@@ -948,13 +965,14 @@ static int launch_attn_iv2_pipe(const AttnArgs& a_in, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-template <int D, int NWAVES, int NS, int ONES = 0, int VROW = 0>
+template <int D, int NWAVES, int NS, int ONES = 0, int VROW = 0, int VL = 0>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
   constexpr int LDS = NS * 2 * 64 * D * 2 + 1024;   // ring + page-id table (256 pages)
   static GvlDevOnce once;
-  auto kern = attn_fwd_kernel<D, NWAVES, NS, ONES, VROW>;
+  auto kern = attn_fwd_kernel<D, NWAVES, NS, ONES, VROW, VL>;
   if (gvl_set_max_lds(once, (const void*)kern, LDS)) return -3;
-  const int nq = (a.S + NWAVES * 32 - 1) / (NWAVES * 32);
+  int nq = (a.S + NWAVES * 32 - 1) / (NWAVES * 32);
+  if (VL) { nq = 0; for (int u = 0; u < a.vl_n; ++u) nq += (a.vl_rows[u + 1] - a.vl_rows[u] + NWAVES * 32 - 1) / (NWAVES * 32); }
   dim3 grid((unsigned)(((a.KV * a.B + 7) / 8) * 8 * (a.H / a.KV) * nq));
   hipLaunchKernelGGL(kern, grid, dim3(NWAVES * 64), LDS, st, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
@@ -978,6 +996,16 @@ int gvl_launch_attention(const AttnArgs& a_in, hipStream_t st) {
                                                               (((uintptr_t)a.Krows | (uintptr_t)a.Qrows) & 15) || (size_t)64 * a.k_ld * 2 >= 0xffffffffull))) return -1;
   if (a.B <= 0 || a.S <= 0 || a.S > 256 * 64 || a.Sk > 256 * 64 || a.H % a.KV != 0 || a.Dout > a.D || (a.Dout & 7) || ((uintptr_t)a.O & 15)) return -1;   // 16-byte O stores
   const int ring = a.ring == 3 && !a.Vrows ? 3 : 2;
+  if (a.vl_n) {                                                  // ragged causal prefill: one grid for all sequences of the group
+    if (a.vl_n < 1 || a.vl_n > GVL_MAX_PREFILL_BATCH || a.B != 1 || !a.causal || a.Sk || a.qpos0 || a.Vrows || a.Qrows || a.Krows || a.q_rs || a.block_table) return -1;
+    for (int u = 0; u < a.vl_n; ++u) if (!a.vl_tables[u] || a.vl_rows[u + 1] <= a.vl_rows[u] || a.vl_rows[u + 1] - a.vl_rows[u] > a.S) return -1;
+    switch (a.D) {
+      case 64: return launch_attn<64, 4, 2, 0, 0, 1>(a, st);
+      case 96: return launch_attn<96, 4, 2, 0, 0, 1>(a, st);
+      case 128: return launch_attn<128, 4, 2, 0, 0, 1>(a, st);
+      default: return -1;
+    }
+  }
   switch (a.D) {
     // ring depth 2: 48 KB (D=96) -> 3 blocks / CU at 151 VGPRs (measured 427 us vs 461 us for the 73 KB depth-3 ring, which
     // caps residency at 2 blocks / CU; DMA latency is not the limiter -- PMC shows the kernel is VALU-issue-bound)

@@ -589,6 +589,33 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
   setup(xbase + it, m0, n0);
   stage_half(0, 0, 0); stage_half(0, 0, 1);
   for (; it < xcnt; it += wpx) {
+    // DEAD wave: every output column (N = 1408 = 5.5 tile columns: the wn = 1 waves of the last column) or row of its 64 x 128 sub-tile lies outside the
+    // matrix.  It used to run the full MFMA + fragment-read stream on clamped (repeated) operand rows -- 8.3 % of InternVideo2's proj / fc2 MFMA work, results
+    // dropped by the bounds check.  The board runs this kernel AT its power cap, so work that produces nothing is clock taken from the
+    // CUs that do: a dead wave now only keeps its place in the protocol -- its share of the DMA, the waits and all 8 barriers of every k-tile -- and
+    // issues no MFMA, no LDS read, no epilogue.  (wn is the same for the two waves of a SIMD: SIMDs 1 and 3 idle through such a tile.)  Kept as ONE early
+    // block of the tile loop so that the live path's register allocation is untouched (the bias + gamma + residual epilogue sits 11 VGPRs under the limit).
+    if ((n0 + wn * TN >= a.N) || (m0 + wm * TM >= a.M)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      if (grp == 1) PP_BARRIER();
+      for (int t = 0; t < nk; ++t) {
+        const bool more = t + 1 < nk;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+          if (ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
+          if (ph == 3 && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          PP_BARRIER();
+          PP_BARRIER();
+        }
+      }
+      if (grp == 0) PP_BARRIER();
+      if (it + wpx < xcnt) {                        // the next tile's first k-tile still needs this wave's DMA pieces
+        if constexpr (STG != 0 && EPI >= 0 && !(STG != 0 && EPI >= 0 && !(EPI & 4))) __syncthreads();   // = STAGED && !OVERLAP: the live waves' staging slices overlap ring slot 0
+        setup(xbase + it + wpx, m0, n0); stage_half(0, 0, 0); stage_half(0, 0, 1);
+      }
+      continue;
+    }
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
     if (a.dbg) ts0 = __builtin_readcyclecounter();
     f32x16_t acc[NB][MB];

@@ -124,6 +124,9 @@ struct Rccl {
   int (*CommDestroy)(void*) = nullptr;
   int (*CommCount)(void*, int*) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;     // ncclBroadcast(send, recv, count, type, root, comm, stream)
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 } g_rccl;
 bool rccl_load() {
@@ -149,6 +152,9 @@ bool rccl_load() {
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.h, "ncclCommDestroy");
   g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.h, "ncclAllGather");
   g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(g_rccl.h, "ncclCommCount");
+  g_rccl.Broadcast = (decltype(g_rccl.Broadcast))dlsym(g_rccl.h, "ncclBroadcast");        // optional: gvl_allgatherv_visual only
+  g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(g_rccl.h, "ncclGroupStart");
+  g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(g_rccl.h, "ncclGroupEnd");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.h, "ncclGetErrorString");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) { g_rccl.err = "librccl lacks a required symbol"; dlclose(g_rccl.h); g_rccl.h = nullptr; return false; }
   return true;
@@ -201,6 +207,39 @@ int gvl_allgather_visual(gvl_ctx* ctx, void* comm, const uint16_t* local, int ro
   if (!rccl_load()) return fail(ctx, GVL_ERR_STATE, g_rccl.err);
   const int rc = g_rccl.AllGather(local, all, count, kNcclBfloat16, cm, st);
   if (rc) return fail(ctx, GVL_ERR_HIP, rccl_msg("ncclAllGather", rc));
+  return 0;
+}
+
+// Uneven blocks (12 segments over 8 ranks: 2,2,2,2,1,1,1,1) straight into the segment-ordered prefix: rank r's rows land at row offset sum(rows[0..r)) of
+// `all` -- no padding to the largest block, no re-assembly copy afterwards.  One ncclGroup of `world` broadcasts (root r sends its block, everybody
+// receives it in place): the standard all-gather-v; on xGMI every root pushes to all peers at once.
+int gvl_allgatherv_visual(gvl_ctx* ctx, void* comm, const uint16_t* local, const int* rows_per_rank, int hidden, uint16_t* all, void* stream) {
+  if (!ctx || !all || !rows_per_rank || hidden <= 0) return fail(ctx, GVL_ERR_ARG, "gvl_allgatherv_visual: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  void* cm = comm ? comm : ctx->comm;
+  const int world = cm ? ctx->comm_world : 1, rank = cm ? ctx->comm_rank : 0;
+  if (comm && comm != ctx->comm) return fail(ctx, GVL_ERR_ARG, "gvl_allgatherv_visual: a foreign communicator's rank / size are unknown here -- pass NULL (the ctx's own)");
+  size_t off = 0, my_off = 0;
+  for (int r = 0; r < world; ++r) { if (rows_per_rank[r] < 0) return fail(ctx, GVL_ERR_ARG, "gvl_allgatherv_visual: negative block"); if (r == rank) my_off = off; off += (size_t)rows_per_rank[r] * hidden; }
+  if (rows_per_rank[rank] > 0 && !local) return fail(ctx, GVL_ERR_ARG, "gvl_allgatherv_visual: null local block");
+  if (!cm) {
+    if (rows_per_rank[0] > 0 && local != all) HIPCHK(ctx, hipMemcpyAsync(all, local, (size_t)rows_per_rank[0] * hidden * 2, hipMemcpyDeviceToDevice, st));
+    return 0;
+  }
+  if (!rccl_load()) return fail(ctx, GVL_ERR_STATE, g_rccl.err);
+  if (!g_rccl.Broadcast || !g_rccl.GroupStart || !g_rccl.GroupEnd) return fail(ctx, GVL_ERR_STATE, "librccl lacks ncclBroadcast / ncclGroupStart / ncclGroupEnd");
+  int rc = g_rccl.GroupStart();
+  if (rc) return fail(ctx, GVL_ERR_HIP, rccl_msg("ncclGroupStart", rc));
+  size_t o = 0;
+  for (int r = 0; r < world && !rc; ++r) {
+    const size_t cnt = (size_t)rows_per_rank[r] * hidden;
+    if (cnt) rc = g_rccl.Broadcast(r == rank ? (const void*)local : (const void*)(all + o), all + o, cnt, kNcclBfloat16, r, cm, st);
+    o += cnt;
+  }
+  const int rc2 = g_rccl.GroupEnd();
+  (void)my_off;
+  if (rc) return fail(ctx, GVL_ERR_HIP, rccl_msg("ncclBroadcast", rc));
+  if (rc2) return fail(ctx, GVL_ERR_HIP, rccl_msg("ncclGroupEnd", rc2));
   return 0;
 }
 

@@ -177,6 +177,11 @@ struct AttnArgs {
   int q_begin, q_rows;  // set by the launcher: the query rows one attn_iv2_pipe_kernel launch covers
   float lazy;           // set by the launcher: the running max (and O) of a wave's rows is only moved when some row's tile max exceeds it by
                         // more than `lazy` (log2 units; 0 = every time it grows)
+  // RAGGED causal prefill in one grid (paged K/V, B == 1, Sk == qpos0 == 0): vl_n > 0 sequences packed back to back -- sequence u owns rows
+  // [vl_rows[u], vl_rows[u + 1]) of Q ([H][S_u][D] per sequence, at row offset vl_rows[u]) and O, and the block table vl_tables[u]; S = longest sequence
+  int vl_n;
+  int vl_rows[GVL_MAX_PREFILL_BATCH + 1];
+  const int* vl_tables[GVL_MAX_PREFILL_BATCH];
 };
 int gvl_launch_attention(const AttnArgs& a, hipStream_t st);
 double gvl_attn_flops(const AttnArgs& a);

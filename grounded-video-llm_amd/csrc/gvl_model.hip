@@ -322,6 +322,9 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
     bf16_t* Kt = ctx->kpool + (size_t)l * ctx->layer_stride; bf16_t* Vt = ctx->vpool + (size_t)l * ctx->layer_stride;
     RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln1, h, M, Hd, f.rms_eps, st));
     { GemmArgs g = gemm(h, Hd, w.qkvw, qkv, qkvw, M, qkvw, Hd); RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    // ragged group: RoPE / KV append per sequence (HBM-bound passes), then ONE causal-attention grid over the query blocks of all sequences
+    // (AttnArgs.vl_*; 8 launches of ~900 blocks on 768 block slots each -> one of ~7 000: the causal tail is paid once) -- bit-identical per row
+    const bool vl_attn = n_att > 1 && ctx->dbg.varlen_attn && pos0 == 0;
     for (int u = 0; u < n_att; ++u) {
       const int S = lens[u], B = n_att == 1 ? nb : 1;
       const int* tbl = n_att == 1 ? table : sqs[u]->d_block_table;
@@ -332,11 +335,21 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
       { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv + (size_t)off[u] * qkvw; q.ld = qkvw; q.Q = Qu; q.Kt = Kt; q.Vt = Vt; q.block_table = tbl; q.max_pages = tstride;
         q.B = B; q.S = S; q.H = H; q.KV = KV; q.Dr = Dr; q.D = D; q.mode = 2; q.cos = use_long ? ctx->cos_l : ctx->cos_s; q.sin = use_long ? ctx->sin_l : ctx->sin_s; q.pos0 = pos0;
         RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
+      if (vl_attn) continue;
       { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Qu; a.Kt = Kt; a.Vt = Vt; a.O = att + (size_t)off[u] * H * Dr; a.block_table = tbl; a.max_pages = tstride;
         a.B = B; a.H = H; a.KV = KV; a.S = S; a.D = D; a.Dout = Dr; a.scale = 1.0f / sqrtf((float)Dr); a.causal = 1;
         if (pos0) { a.Sk = pos0 + S; a.qpos0 = pos0; }
         a.ring = ctx->dbg.attn_ring;
         RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
+    }
+    if (vl_attn) {
+      AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; a.O = att; a.B = 1; a.H = H; a.KV = KV; a.D = D; a.Dout = Dr;
+      a.scale = 1.0f / sqrtf((float)Dr); a.causal = 1; a.vl_n = nb;
+      double fl = 0;
+      for (int u = 0; u < nb; ++u) { a.vl_rows[u] = off[u]; a.vl_tables[u] = sqs[u]->d_block_table; a.S = lens[u] > a.S ? lens[u] : a.S;
+        AttnArgs one = a; one.S = lens[u]; one.vl_n = 0; fl += gvl_attn_flops(one); }
+      a.vl_rows[nb] = off[nb]; a.max_pages = 0;
+      RUN(GVL_PROF_ATTN, fl, gvl_launch_attention(a, st));
     }
     { GemmArgs g = gemm(att, H * Dr, w.ow, x, Hd, M, Hd, H * Dr); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
     RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln2, h, M, Hd, f.rms_eps, st));
@@ -1224,6 +1237,7 @@ int gvl_debug_set(gvl_ctx* ctx, const char* key, int value) {
   else if (k == "attn_pipe") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: attn_pipe must be 0, 1 or 2"); ctx->dbg.attn_pipe = value; }
   else if (k == "attn_pipe_rows") { if (value != 128 && value != 256) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: attn_pipe_rows must be 128 (default) or 256"); ctx->dbg.attn_pipe_rows = value; }
   else if (k == "patch_fused") ctx->dbg.patch_fused = value != 0;
+  else if (k == "varlen_attn") ctx->dbg.varlen_attn = value != 0;
   else if (k == "vision_in_place") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: vision_in_place must be 0, 1 or 2"); ctx->dbg.vision_in_place = value; }
   else return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: unknown key " + k);
   return 0;

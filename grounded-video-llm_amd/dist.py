@@ -33,19 +33,25 @@ def my_shard(n_units: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def allgather_visual(local: torch.Tensor, n_units: int, rows_per_unit: int, group: Optional[dist.ProcessGroup] = None,
-                     force_collective: bool = False, gather=None) -> torch.Tensor:
+                     force_collective: bool = False, gather=None, gatherv=None) -> torch.Tensor:
     """local: [n_local * rows_per_unit, D] for this rank's block -> full [n_units * rows_per_unit, D] on every rank.
 
     Blocks are padded to the largest block so that a single fixed-size all_gather_into_tensor is used
     (12 segments over 8 ranks is uneven: 2,2,2,2,1,1,1,1).
     gather: None = torch.distributed.all_gather_into_tensor; or a callable send [rows, D] -> recv [world * rows, D] in rank order --
     Engine.allgather_visual, i.e. libgvl's own RCCL communicator behind the C ABI (gvl_comm_init / gvl_allgather_visual): the exchange a
-    non-Python host of the library performs."""
+    non-Python host of the library performs.
+    gatherv: Engine.allgatherv_visual (gvl_allgatherv_visual): the uneven blocks go STRAIGHT into the segment-ordered result -- no padded send buffer,
+    no re-assembly (VERDICT r4 #10: at <= 3.5 MB per rank the pad / copy / cat kernels cost more than the wire); takes precedence over `gather`."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1 and not force_collective:       # force_collective: run the (degenerate) collective anyway -- RCCL smoke test on one GPU
         return local
     bounds = shard_bounds(n_units, world)
+    if gatherv is not None:
+        lo, hi = bounds[rank]
+        assert local.shape[0] == (hi - lo) * rows_per_unit, (local.shape, lo, hi)
+        return gatherv(local, [(h - l) * rows_per_unit for l, h in bounds])
     max_units = max(hi - lo for lo, hi in bounds)
     D = local.shape[1]
     lo, hi = bounds[rank]

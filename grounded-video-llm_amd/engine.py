@@ -217,6 +217,20 @@ class Engine:
         self._chk(self.lib.gvl_allgather_visual(self.ctx, None, _ptr(local), local.shape[0], local.shape[1], _ptr(out), self.stream), "gvl_allgather_visual")
         return out
 
+    def allgatherv_visual(self, local: torch.Tensor, rows_per_rank, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Uneven blocks straight into the segment-ordered prefix: rank r's `rows_per_rank[r]` rows land at row offset sum(rows_per_rank[:r]) of the result on
+        every rank (gvl_allgatherv_visual: one ncclGroup of per-rank broadcasts on the current stream; no padding, no re-assembly copy).  `out`: a
+        preallocated [sum(rows), hidden] bf16 buffer (the step's prefix) to gather into."""
+        local = local.contiguous()
+        rows = [int(r) for r in rows_per_rank]
+        hidden = local.shape[1]
+        if out is None:
+            out = torch.empty((sum(rows), hidden), dtype=bf, device=self.device)
+        assert out.is_contiguous() and out.shape == (sum(rows), hidden) and out.dtype == bf
+        arr = (C.c_int * len(rows))(*rows)
+        self._chk(self.lib.gvl_allgatherv_visual(self.ctx, None, _ptr(local) if local.numel() else None, arr, hidden, _ptr(out), self.stream), "gvl_allgatherv_visual")
+        return out
+
     # ---- vision ----------------------------------------------------------------------------------
     def clip_encode(self, px: torch.Tensor) -> torch.Tensor:
         """vision_tower(px, output_hidden_states=True).hidden_states[-2][:, 1:] (llava_next_video.py:504-505)."""

@@ -224,7 +224,7 @@ class LLAVA_NEXT_VIDEO:
             # communicator through the C ABI (gvl_comm_init / gvl_allgather_visual), what a non-Python host of the library calls
             if self.exchange == "gvl" and getattr(self.engine, "comm_world", 0) != world:
                 gdist.init_gvl_comm(self.engine, self.group)
-            vis = gdist.allgather_visual(local, n, L, self.group, gather=self.engine.allgather_visual if self.exchange == "gvl" else None)
+            vis = gdist.allgather_visual(local, n, L, self.group, gatherv=self.engine.allgatherv_visual if self.exchange == "gvl" else None)
         else:
             ms = self.geo.max_segs
             if bs > 1 and S <= ms:

@@ -215,6 +215,11 @@ int gvl_comm_destroy(gvl_ctx* ctx);
 int gvl_comm_count(gvl_ctx* ctx, int* n_ranks);
 int gvl_allgather_visual(gvl_ctx* ctx, void* comm, const uint16_t* local, int rows_per_rank, int hidden, uint16_t* all,
                          void* stream);
+/* The same exchange for UNEVEN blocks, written straight into the segment-ordered prefix (llava_next_video.py:563: the per-segment blocks in segment
+ * order): rank r contributes rows_per_rank[r] rows ([world] ints, host memory, the same on every rank) and they land at row offset
+ * sum(rows_per_rank[0..r)) of `all` on every rank -- no padding to the largest block, no re-assembly copy.  One ncclGroup of per-rank broadcasts on
+ * the caller's stream; `comm` must be NULL (the ctx's communicator).  Without a communicator: one device copy (or nothing when local == all). */
+int gvl_allgatherv_visual(gvl_ctx* ctx, void* comm, const uint16_t* local, const int* rows_per_rank, int hidden, uint16_t* all, void* stream);
 
 /* ---- training forward ---------------------------------------------------------- */
 /* LLAVA_NEXT_VIDEO.forward(samples)["loss"] for ONE sample (llava_next_video.py:598-614): the causal-LM loss of
@@ -256,6 +261,8 @@ int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launche
  *                      2: V only; 0: the round-2 path through Q / K pages and a V^T transpose pass
  *   "attn_pipe_rows"   128 (default): that kernel's 4-wave form (128 query rows per block) for every row; 256: whole 256-row query blocks on its 8-wave form (half
  *                      the DMA pieces per MFMA; measured 12 % slower), the remaining rows on the 4-wave form -- bit-identical
+ *   "varlen_attn"      1 (default): the causal attention of a ragged prefill group (gvl_prefill_varlen) runs as ONE grid over the query blocks of all its sequences;
+ *                      0: one launch per sequence (rounds 2-4) -- bit-identical
  *   "patch_fused"      1 (default): the patch embedding of a tower whose geometry the fused kernel covers (patch 14, width 1024 / 1408) runs as ONE kernel
  *                      (gvl_patch.hip: im2col in the operand loader + GEMM + CLS / position rows + CLIP's pre-LayerNorm); 0: the three-pass path (patchify, GEMM,
  *                      embed).  NOT bit-neutral: the fp32 accumulation order over k differs (agreement to fp32 rounding before the bf16 round; tests/test_gpu_towers.py)

@@ -49,6 +49,41 @@ def test_allgather_visual_gloo_world2(n_units, rows):
     assert res == [(0, True), (1, True)]
 
 
+def _worker_v(rank, world, port, n_units, rows, q):
+    """dist.allgather_visual(gatherv=...): the routing of the uneven-block exchange (Engine.allgatherv_visual = gvl_allgatherv_visual on a GPU box) -- the
+    callable gets this rank's block and the per-rank row counts in rank order and must return the segment-ordered whole; emulated with gloo here."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(n_units * rows * 4, dtype=torch.float32).view(n_units * rows, 4)
+        lo, hi = gdist.my_shard(n_units, rank, world)
+        seen = {}
+
+        def fake_gatherv(local, rows_per_rank):
+            seen["rows"] = list(rows_per_rank)
+            parts = [None] * world
+            dist.all_gather_object(parts, local)
+            assert [p.shape[0] for p in parts] == seen["rows"]
+            return torch.cat(parts, 0)
+        got = gdist.allgather_visual(full[lo * rows: hi * rows].clone(), n_units, rows, gatherv=fake_gatherv)
+        want_rows = [(h - l) * rows for l, h in gdist.shard_bounds(n_units, world)]
+        q.put((rank, bool(torch.equal(got, full)) and seen["rows"] == want_rows))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_units,rows", [(3, 7), (12, 5)])
+def test_allgatherv_routing_gloo_world2(n_units, rows):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_v, args=(r, 2, port, n_units, rows, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(60) for p in ps]
+    assert res == [(0, True), (1, True)]
+
+
 def test_rotated_plan_balances_and_reassembles():
     """bench.py's N-clips-in-flight plan: every rank encodes exactly n units, and after the all-gather every rank can
     rebuild ITS clip's units in order (simulated without processes)."""

@@ -75,6 +75,12 @@ def test_c_abi_rccl_communicator_world1():
     assert out.shape == local.shape and torch.equal(out, local)
     with pytest.raises(E.L.GvlError):
         eng.comm_init(uid, 0, 1)                                      # already initialised
+    # gvl_allgatherv_visual (uneven blocks straight into the segment-ordered buffer): world 1 = one ncclBroadcast inside a group, into a caller-owned prefix
+    pre = torch.zeros((9, 64), device=DEV, dtype=bf)
+    with torch.cuda.stream(s):
+        got = eng.allgatherv_visual(local, [7], out=pre[:7])
+    torch.cuda.current_stream().wait_stream(s)
+    assert got.data_ptr() == pre.data_ptr() and torch.equal(pre[:7], local) and float(pre[7:].abs().max()) == 0.0
     eng.close()
 
 
@@ -130,3 +136,21 @@ def test_model_encode_images_through_the_gvl_exchange_world1(nccl_world1):
             assert torch.equal(outs["gvl"][0], plain)
         m.engine.close()
     assert torch.equal(outs["gvl"], outs["torch"])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs: the first N > 1 run of RCCL on real devices happens on the driver's multi-GPU lease")
+def test_two_ranks_over_rccl():
+    """torchrun-spawned world of 2 on backend nccl (= RCCL over xGMI): tests/nccl_worker.py shards a 3-segment clip 2 + 1, exchanges the token
+    blocks through libgvl's own communicator (gvl_allgatherv_visual, straight into the segment-ordered prefix), through torch.distributed, and through
+    bench.py's per-step exchange; every result must equal the un-distributed encode bit for bit and ncclCommCount must say 2.  Auto-skipped on a 1-GPU box."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(os.path.dirname(os.path.abspath(__file__)), "nccl_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "NCCL2_OK rank 0 of 2" in r.stdout and "NCCL2_OK rank 1 of 2" in r.stdout, r.stdout[-2000:]

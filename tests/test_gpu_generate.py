@@ -52,7 +52,7 @@ def test_generate_matches_oracle(llm):
             # ids may part ways only where the oracle's top-1 margin is inside twice the bf16-class logit tolerance (2e-2 of the logit scale,
             # the bound every logit test of these small models uses) -- relative to the scale, as tests/test_gpu_c0.py does at full size
             print(f"[parity] generate({llm}): ids part ways at token {i} ({a} vs {b}); oracle margin {margins[i] / scales[i]:.3e} of the logit scale")
-            assert margins[i] < 2 * 2e-2 * scales[i], f"token {i}: {a} vs {b}, oracle margin {margins[i]} = {margins[i] / scales[i]:.3e} of the scale {scales[i]}"
+            assert margins[i] < min(2 * 2e-2 * scales[i], 0.25), f"token {i}: {a} vs {b}, oracle margin {margins[i]} = {margins[i] / scales[i]:.3e} of the scale {scales[i]}"
             break
     else:
         assert len(got) == len(ref_ids)

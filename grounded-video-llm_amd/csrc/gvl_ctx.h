@@ -24,8 +24,10 @@ std::string& gvl_create_error();
 struct Tensor { void* p = nullptr; int dtype = 0; int64_t numel = 0; std::vector<int64_t> shape; };
 
 struct ClipLayerW { const float *ln1w, *ln1b, *ln2w, *ln2b, *qkvb, *outb, *fc1b, *fc2b; const bf16_t *qkvw, *outw, *fc1w, *fc2w; };
-struct Iv2BlockW { const bf16_t *n1, *n2, *qkvw, *qn, *kn, *projw, *fc1w, *fc2w; const float *projb, *ls1, *ls2, *fc1b, *fc2b; };
+struct Iv2BlockW { const bf16_t *n1, *n2, *qkvw, *qn, *kn, *projw, *fc1w, *fc2w; const float *projb, *ls1, *ls2, *fc1b, *fc2b;
+                   const bf16_t *qkvw_f = nullptr, *fc1w_f = nullptr; };   // fused RMSNorm: qkv.w diag(n1), fc1.w diag(n2) (gvl_launch_fold_gamma at finalize)
 struct LlmLayerW { const bf16_t *ln1, *ln2, *qkvw, *ow, *guw, *downw;
+                   const bf16_t *qkvw_f = nullptr, *guw_f = nullptr;   // fused RMSNorm (prefill): qkv.w diag(ln1), gate_up.w diag(ln2)
                    const bf16_t *qkvd, *od, *gud, *downd;      // decode copies in MFMA tile order (gvl_decode.hip; bf16, or FP8 e4m3 when cfg.decode_fp8); null on the VALU fallback
                    const float *qkvs, *os, *gus, *downs; };    // FP8 variant: per-row power-of-two scales
 
@@ -80,6 +82,7 @@ struct gvl_ctx {
   int fp8 = 0;                       // format of the decode copies: 0 bf16, 1 FP8 e4m3 + row scales, 2 MXFP4 (cfg.decode_fp8 and the geometry allows it)
   std::vector<void*> dw_allocs;      // tile-order weight copies owned by the ctx
   std::vector<void*> pw_allocs;      // tile-order patch-conv weights (gvl_patch.hip)
+  std::vector<void*> nf_allocs;      // norm-folded projection weights (fused RMSNorm)
   const bf16_t *c_patchwt = nullptr, *v_patchwt = nullptr;   // null: the tower's geometry takes the three-pass patch embedding
   // (all decode work buffers hold GVL_MAX_DECODE_BATCH rows: one per sequence of a batched decode step)
   float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_seq_tok = nullptr, *d_seq_out = nullptr;
@@ -94,7 +97,7 @@ struct gvl_ctx {
   struct { bool on = false; float inv_temp = 1.f, top_p = 0.f; int top_k = 0; unsigned long long seed = 0; unsigned next_stream = 0; } sample;
   // result-neutral launch parameters (gvl_debug_set): 0 = the launcher's own choice.  decode_graph: a decode group's step is captured once and
   // replayed (hipGraph) for the following tokens -- the host pays one graph launch per token instead of ~165 kernel launches
-  struct { int decode_attn_cpb = 0, decode_attn_hpb = 0; bool decode_graph = true; int vision_in_place = 1, prefill_group = 4, attn_ring = 0, attn_pipe = 1, attn_pipe_rows = 128, patch_fused = 1, varlen_attn = 1; } dbg;
+  struct { int decode_attn_cpb = 0, decode_attn_hpb = 0; bool decode_graph = true; int vision_in_place = 1, prefill_group = 4, attn_ring = 0, attn_pipe = 1, attn_pipe_rows = 128, patch_fused = 1, varlen_attn = 1, norm_fused = 1; } dbg;
   // RCCL communicator owned by the ctx (gvl_comm_init); the library is dlopen'ed on first use
   void* comm = nullptr; int comm_rank = 0, comm_world = 1;
   // profiling

@@ -98,6 +98,48 @@ int gvl_launch_rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int row
 }
 
 // =====================================================================================================
+// Fused RMSNorm (round 5), the two small kernels around the GEMM epilogues (GemmArgs.rowscale / rowsq):
+//   fold_gamma:    W'[n][k] = bf16(W[n][k] * gamma[k])   once, at gvl_finalize_weights -- the norm weight rides in the projection that consumes the norm
+//   rowsq_finish:  rs[m] = rsqrt((sum_b rowsq[m][b]) / cols + eps), blocks added in index order (fixed): M x nblk floats in, M floats out
+// RMSNorm(x) . W^T == rs[m] * (x . W'^T) up to where the roundings sit: the reference rounds x * rs and the gamma product to bf16 before the GEMM
+// (internvideo2.py:443-448, modeling_phi3.py:319-324); here those two roundings are gone and gamma * W is rounded once per weight instead -- a different,
+// not larger, set of rounding points (tests/test_gpu_ops.py bounds the difference against the unfused pair; the tower / end-to-end goldens hold both).
+// =====================================================================================================
+__global__ __launch_bounds__(256) void fold_gamma_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ g, bf16_t* __restrict__ Wo, long rows, int cols) {
+  const long total = rows * (cols / 8);
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % (cols / 8)) * 8;
+    const long r = idx / (cols / 8);
+    const u32x4_t w = *(const u32x4_t*)(W + r * cols + c), gv = *(const u32x4_t*)(g + c);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2bf(lo_bf(w[e]) * lo_bf(gv[e]), hi_bf(w[e]) * hi_bf(gv[e]));
+    *(u32x4_t*)(Wo + r * cols + c) = o;
+  }
+}
+int gvl_launch_fold_gamma(const bf16_t* W, const bf16_t* gamma, bf16_t* Wo, long rows, int cols, hipStream_t st) {
+  if (cols % 8 || rows <= 0) return -1;
+  const long total = rows * (cols / 8);
+  int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(fold_gamma_kernel, dim3(blocks), dim3(256), 0, st, W, gamma, Wo, rows, cols);
+  return CHECK_LAUNCH();
+}
+__global__ __launch_bounds__(256) void rowsq_finish_kernel(const float* __restrict__ sq, int ld, int b0, int nblk, float* __restrict__ rs, int rows, float inv_cols, float eps) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= rows) return;
+  const float* p = sq + (size_t)m * ld + b0;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += p[b];
+  rs[m] = rsqrtf(s * inv_cols + eps);
+}
+// blocks [b0, b0 + nblk) of every row (b0 > 0: a column range of a fused output, e.g. the k part of a qkv row)
+int gvl_launch_rowsq_finish(const float* sq, int ld, int b0, int nblk, float* rs, int rows, int cols, float eps, hipStream_t st) {
+  if (rows <= 0 || nblk <= 0 || b0 < 0 || b0 + nblk > ld || cols <= 0) return -1;
+  hipLaunchKernelGGL(rowsq_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, sq, ld, b0, nblk, rs, rows, 1.0f / (float)cols, eps);
+  return CHECK_LAUNCH();
+}
+
+// =====================================================================================================
 // patch im2col for conv with stride == kernel (models/modeling_clip.py:185, models/internvideo2.py:714-722)
 // px f32 [n][3][T][HW][HW] -> A bf16 [n*T*g*g][Kp], k = c*p*p + py*p + px, zero padded to Kp
 // =====================================================================================================
@@ -246,6 +288,13 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
   constexpr int RC = 3;
   u32x4_t qreg[RC], kreg[RC];
   const bool in_regs = WPR == 1 && a.mode == 1 && nq <= RC * 64 && nk <= RC * 64;
+  if (a.mode == 1 && a.k_rs_in) {                   // statistics given (GEMM-epilogue row sums): k only, no reduction
+    k_rs = a.k_rs_in[row];
+    if (in_regs) {
+#pragma unroll
+      for (int i = 0; i < RC; ++i) { const int c = lane + 64 * i; kreg[i] = c < nk ? *(const u32x4_t*)(kr + c * 8) : u32x4_t{0u, 0u, 0u, 0u}; }
+    }
+  } else
   if (a.mode == 1) {
     float sq = 0.f, sk = 0.f;
     if (in_regs) {
@@ -398,6 +447,7 @@ int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st) {
   if ((a.Dr & 7) || (a.mode == 2 && (a.Dr & 15)) || (a.D & 7) || a.D < a.Dr || a.Dr > 128 || (a.ld & 7)) return -1;   // 16-byte chunks; rotate_half partner chunk-aligned
   const int rows = a.B * a.S;
   if (a.q_rs && (a.mode != 1 || a.pos_ptr)) return -1;
+  if (a.k_rs_in && (!a.q_rs || a.mode != 1)) return -1;
   if (a.pos_ptr) {
     if (rows != 1 || a.mode != 2) return -1;
     hipLaunchKernelGGL(qkv_post_kernel<4>, dim3(1), dim3(256), 0, st, a);

@@ -146,6 +146,7 @@ template <int NB, int EPI>
 struct StgGeom {                                   // compile-time geometry of one wave's staged read-back
   static constexpr int act = EPI & 3;
   static constexpr bool out_f32 = (EPI >> 2) & 1, has_resid = (EPI >> 3) & 1, has_gamma = (EPI >> 4) & 1, has_bias = (EPI >> 5) & 1;
+  static constexpr bool has_rowscale = (EPI >> 6) & 1, has_rowsq = (EPI >> 7) & 1;   // fused RMSNorm: consumer / producer side (GemmArgs)
   static constexpr bool silu = act == GVL_ACT_SILU_MUL;
   static constexpr int TN = NB * 32, OUTC = silu ? TN / 2 : TN, ES = out_f32 ? 4 : 2;
   static constexpr int LPR = OUTC * ES / 16, RPI = 64 / LPR, KI = 32 / RPI;   // lanes / row, rows / instruction, instructions / 32-row block
@@ -199,15 +200,39 @@ __device__ __forceinline__ void stg_store_bias(char* bg, int lane, const u32x2_t
   }
 }
 
+// rowscale[m] of the MB rows this lane owns (row mw + 32 j + (lane & 31), clamped to the last row: overhanging rows are never stored)
+template <int MB>
+__device__ __forceinline__ void stg_request_rowscale(const GemmArgs& a, int mw, int lane, float (&rsc)[MB]) {
+#pragma unroll
+  for (int j = 0; j < MB; ++j) { int r = mw + j * 32 + (lane & 31); r = r < a.M ? r : a.M - 1; rsc[j] = a.rowscale[r]; }
+}
+// sum of squares of the 8 bf16 values of a 16-byte piece, then over the 8 lanes that hold one aligned 64-column block of a row.  The order is FIXED
+// (v_dot2c per dword in order; lane pairs, quads, the two quads) and depends only on the column -> lane map of the staged read-back, which every kernel
+// shares: a row's partial sums are the same whichever kernel of the launch plan stored it.
+__device__ __forceinline__ float stg_sumsq8(const u32x4_t& v) {
+  // v_dot2c_f32_bf16: d += a.lo * b.lo + a.hi * b.hi.  Spelled in asm: hipcc's own lowering of __builtin_amdgcn_fdot2_f32_bf16 on the elements of a
+  // 4-dword vector reads element 0 four times (ROCm 7.2 clang; found by tests/test_gpu_ops.py::test_gemm_row_sums_of_squares).  s_nop 1: the DPP
+  // reads below need two wait states behind a VALU write of the same register, and the hazard recogniser does not look inside asm.
+  float s = 0.f;
+  const unsigned a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+  asm("v_dot2c_f32_bf16 %0, %1, %1\n\tv_dot2c_f32_bf16 %0, %2, %2\n\tv_dot2c_f32_bf16 %0, %3, %3\n\tv_dot2c_f32_bf16 %0, %4, %4\n\ts_nop 1" : "+v"(s) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+  s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]: lane ^ 1
+  s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]: lane ^ 2
+  s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, false));   // row_half_mirror: lane i <-> 7 - i of its 8
+  return s;
+}
+
 // PRE bit 0: the caller has already put bias/gamma into `bg`; bit 1: it has requested residual block 0 into rv (ping-pong
-// kernel: both are issued inside the main loop, so the epilogue starts with its operands on chip).
+// kernel: both are issued inside the main loop, so the epilogue starts with its operands on chip); bit 2: rowscale is in rsc.
 template <int MB, int NB, int EPI, int SWZ = 0, int PRE = 0, int TABLE = 0, typename Hook = NoHook>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x16_t (&acc)[NB][MB], char* stg, char* bg, int mw, int nw, int lane,
-                                                     u32x4_t (&rv)[StgGeom<NB, EPI>::KI], Hook&& after_requests = NoHook(), const char* tab = nullptr) {
+                                                     u32x4_t (&rv)[StgGeom<NB, EPI>::KI], float (&rsc)[MB], Hook&& after_requests = NoHook(), const char* tab = nullptr) {
   static_assert(EPI >= 0, "staged epilogue is compile-time specialised");
   using G = StgGeom<NB, EPI>;
   constexpr int act = G::act;
   constexpr bool out_f32 = G::out_f32, has_resid = G::has_resid, has_gamma = G::has_gamma, has_bias = G::has_bias, silu = G::silu;
+  constexpr bool has_rowscale = G::has_rowscale, has_rowsq = G::has_rowsq;
+  static_assert(!has_rowsq || (!out_f32 && !silu), "row sums of squares: bf16 outputs of the full tile width");
   constexpr int TN = G::TN, OUTC = G::OUTC, ES = G::ES, LPR = G::LPR, RPI = G::RPI, KI = G::KI;
   static_assert(SWZ == 0 || (OUTC * ES == 256 && !out_f32 && !silu), "swizzled staging: 256-byte bf16 rows");
   constexpr int ROWB = OUTC * ES + (SWZ ? 0 : 16); // +16: the column-of-rows writes spread over the banks
@@ -224,6 +249,19 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x16_t
     stg_store_bias<NB, EPI>(bg, lane, bv, gv);
   }
   if constexpr ((PRE & 2) == 0 && has_resid) stg_request_resid<MB, NB, EPI>(a, mw, nw, lane, 0, rv);
+  if constexpr ((PRE & 4) == 0 && has_rowscale) stg_request_rowscale<MB>(a, mw, lane, rsc);
+  // row statistics: one f32 per (row, aligned 64-column block), stored by the first of the 8 lanes that hold the block; rows >= M and blocks >= N fall
+  // outside the descriptor / take the dropped offset
+  __amdgpu_buffer_rsrc_t qrs;
+  unsigned qoff = 0x80000000u;
+  if constexpr (has_rowsq) {
+    const unsigned long long qp = (unsigned long long)a.rowsq;
+    const unsigned qlo = __builtin_amdgcn_readfirstlane((unsigned)qp), qhi = __builtin_amdgcn_readfirstlane((unsigned)(qp >> 32));
+    const long long qbytes = (long long)a.M * a.rowsq_ld * 4;
+    qrs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)qhi << 32) | qlo), 0, __builtin_amdgcn_readfirstlane((unsigned)(qbytes > 0xffffffffll ? 0xffffffffll : qbytes)), 0x00020000);
+    const int blk = (nw >> 6) + (chunk >> 3);                    // aligned 64-column block of this lane's piece
+    if ((lane & 7) == 0 && blk * 64 < a.N) qoff = (unsigned)(((mw + rrow_l) * a.rowsq_ld + blk) * 4);
+  }
   // output addressing: straight-line buffer stores (no exec-masked branches into which hipcc would sink the residual adds)
   const size_t ldcb = (size_t)a.ldc * ES;
   const __amdgpu_buffer_rsrc_t crs = stg_rsrc(a, a.C, ldcb, mw, MB * 32);
@@ -253,7 +291,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x16_t
       for (int q = 0; q < 2; ++q) {
         const int b = 2 * hb + q;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) vv[q][e] = acc[i][j][4 * b + e] + (has_bias ? bv4[b][e] : 0.f);
+        for (int e = 0; e < 4; ++e) vv[q][e] = (has_rowscale ? acc[i][j][4 * b + e] * rsc[j] : acc[i][j][4 * b + e]) + (has_bias ? bv4[b][e] : 0.f);
       }
       if constexpr (act == GVL_ACT_GELU && TABLE != 0) {
         // Phi table resident in LDS: 8 offsets, 8 reads in flight, 8 products -- one LDS latency per 8 elements
@@ -327,6 +365,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x16_t
         }
       }
       ov[k] = sv;
+      if constexpr (has_rowsq) {
+        const float ssq = stg_sumsq8(sv);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ssq), qrs, (int)(qoff + (unsigned)((j * 32 + k * RPI) * a.rowsq_ld * 4)), 0, 0);
+      }
     }
     if constexpr (has_resid) {
       __builtin_amdgcn_sched_barrier(0);
@@ -481,7 +523,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(const 
     constexpr int BG_OFF = NS * STAGE_BYTES - NWAVES * TN * 8;   // bias/gamma scratch: TN floats each per wave, top of the ring
     static_assert(NWAVES * STG_BYTES <= BG_OFF, "staging overlaps the bias scratch");
     u32x4_t rv[StgGeom<NB, EPI>::KI];
-    gemm_epilogue_staged<MB, NB, EPI>(a, acc, smem + wave * STG_BYTES, smem + BG_OFF + wave * TN * 8, m0 + wm * TM, n0 + wn * TN, lane, rv);
+    float rsc[MB];
+    gemm_epilogue_staged<MB, NB, EPI>(a, acc, smem + wave * STG_BYTES, smem + BG_OFF + wave * TN * 8, m0 + wm * TM, n0 + wn * TN, lane, rv, rsc);
   } else {
     gemm_epilogue<TM, TN, MB, NB, EPI>(a, acc, m0, n0, wm, wn, l31, h);
   }
@@ -640,9 +683,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
     constexpr int EPI_G = STAGED ? EPI : 0;
     using G = StgGeom<NB, EPI_G>;
     constexpr bool PRE_RES = G::has_resid && G::KI <= 8;           // 32 VGPRs across the last k-tile; the f32 residual (64) would spill
-    constexpr int PRE = 1 | (PRE_RES ? 2 : 0);
+    constexpr int PRE = 1 | (PRE_RES ? 2 : 0) | 4;
     u32x4_t rv[G::KI];
     u32x2_t ebv, egv;
+    float rsc[MB];                                  // fused RMSNorm, consumer side: the row scale of this lane's MB rows, requested with the first k-tile
     char* bgw = smem + PP_BG_OFF + wave * TN * 8;   // bias / gamma scratch of this wave (above the ring and the staging slices)
 #ifdef GVL_PP_ENERGY_LAB
     bf16x8_t wf[NB], af[MB];
@@ -657,6 +701,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
       for (int ph = 0; ph < 4; ++ph) {
         if constexpr (STAGED) {
           if (ph == 0 && t == 0 && (G::has_bias || G::has_gamma)) stg_request_bias<NB, EPI_G>(a, n0 + wn * TN, lane, ebv, egv);
+          if (ph == 0 && t == 0 && G::has_rowscale) stg_request_rowscale<MB>(a, m0 + wm * TM, lane, rsc);
           if (ph == 0 && !more && PRE_RES) stg_request_resid<MB, NB, EPI_G>(a, m0 + wm * TM, n0 + wn * TN, lane, 0, rv);
         }
 #ifndef GVL_PP_ENERGY_LAB
@@ -710,7 +755,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
     const int em0 = m0, en0 = n0;
     const bool has_next = it + wpx < xcnt;
     if constexpr (OVERLAP) {
-      gemm_epilogue_staged<MB, NB, EPI, SWZ, PRE, GELU_TAB ? 1 : 0>(a, acc, smem + STAGE_BYTES + wave * STG_BYTES, bgw, em0 + wm * TM, en0 + wn * TN, lane, rv, [&]() {
+      gemm_epilogue_staged<MB, NB, EPI, SWZ, PRE, GELU_TAB ? 1 : 0>(a, acc, smem + STAGE_BYTES + wave * STG_BYTES, bgw, em0 + wm * TM, en0 + wn * TN, lane, rv, rsc, [&]() {
         if (has_next) { setup(xbase + it + wpx, m0, n0); stage_half(0, 0, 0); stage_half(0, 0, 1); }
       }, tabp);
       if (has_next) {
@@ -720,7 +765,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         setup(vnext, m0, n0);
       }
     } else {
-      if constexpr (STAGED) gemm_epilogue_staged<MB, NB, EPI, 0, PRE>(a, acc, smem + wave * STG_BYTES, bgw, em0 + wm * TM, en0 + wn * TN, lane, rv);
+      if constexpr (STAGED) gemm_epilogue_staged<MB, NB, EPI, 0, PRE>(a, acc, smem + wave * STG_BYTES, bgw, em0 + wm * TM, en0 + wn * TN, lane, rv, rsc);
       else gemm_epilogue<TM, TN, MB, NB, EPI>(a, acc, em0, en0, wm, wn, l31, h);
       if (has_next) {
         if constexpr (STAGED) __syncthreads();      // staging slices overlap ring slot 0
@@ -841,7 +886,9 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     cfg = (a.K >= 1024 && t256 >= 128) ? 82 : 21;   // CLIP qkv / fc1 (K = 1024, 336 / 448 tiles): 82 measured +8...17 % over 21
   }
   if ((cfg == 82 || cfg == 85) && ((size_t)a.N * a.ldw * 2 >= (1ull << 32) || (size_t)a.M * a.lda * 2 >= (1ull << 32))) cfg = 21;   // 32-bit DMA offsets
-  const int epi = (a.act & 3) | ((a.out_f32 ? 1 : 0) << 2) | ((a.resid ? 1 : 0) << 3) | ((a.gamma ? 1 : 0) << 4) | ((a.bias ? 1 : 0) << 5);
+  const int epi = (a.act & 3) | ((a.out_f32 ? 1 : 0) << 2) | ((a.resid ? 1 : 0) << 3) | ((a.gamma ? 1 : 0) << 4) | ((a.bias ? 1 : 0) << 5) |
+                  ((a.rowscale ? 1 : 0) << 6) | ((a.rowsq ? 1 : 0) << 7);
+  if (a.rowsq && (a.N % 64 != 0 || a.out_f32 || a.act == GVL_ACT_SILU_MUL || a.rowsq_ld < a.N / 64 || a.grp_rows)) return -1;
   if (cfg == 82 && a.tile_cfg == 0 && env_cfg == 0 && a.m_begin == 0) {
     // Wave-quantisation planner.  The persistent 256x256 kernel runs one block per CU, so a launch costs ceil(tiles / CUs)
     // tile times, and a partial last tile column (N = 1408 = 5.5 x 256) wastes half of its MFMA work.  Candidate plans, costed
@@ -889,6 +936,7 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
         if (g.resid) r.resid = (const char*)g.resid + (size_t)n0 * es_;
         if (g.bias) r.bias = g.bias + n0;
         if (g.gamma) r.gamma = g.gamma + n0;
+        if (g.rowsq) r.rowsq = g.rowsq + n0 / 64;    // n0 is a multiple of 256: whole 64-column blocks
         return r;
       };
       GemmArgs left = cols(a, 0, n_big);
@@ -909,6 +957,7 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
   const int es = a.out_f32 ? 4 : 2;
   const bool stg_ok = a.N % 16 == 0 && a.grp_rows == 0 && ((size_t)a.ldc * es) % 16 == 0 && ((uintptr_t)a.C & 15) == 0 &&
                       (!a.resid || (((size_t)a.ldr * es) % 16 == 0 && ((uintptr_t)a.resid & 15) == 0));
+  if ((a.rowscale || a.rowsq) && (!stg_ok || cfg == 1 || cfg == 85)) return -1;   // the fused-RMSNorm epilogues exist in the staged (whole-row) form only
   if (cfg == 21 && a.tile_cfg == 21 && env_cfg == 0) {   // planner remainder / tail launches only
     static const int small64 = [] { const char* e = gvl_lab_env("GVL_GEMM_SMALL64"); return e ? atoi(e) : 3; }();   // 0 = off (A/B); measured -0.6 ms of GEMM time per clip
     static const int n_cu2 = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
@@ -923,9 +972,11 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
       if (stg_ok) switch (epi) {
 #define S_CASE(E) case E: return launch_cfg<128, 128, 2, 2, 1, E, 1>(a, st);
         S_CASE(0) S_CASE(32) S_CASE(33) S_CASE(34) S_CASE(3) S_CASE(44) S_CASE(56) S_CASE(8) S_CASE(4) S_CASE(36)
+        S_CASE(64) S_CASE(67) S_CASE(98) S_CASE(128) S_CASE(136) S_CASE(184) S_CASE(192)     // fused RMSNorm: +64 row scale (consumer), +128 row sums of squares (producer)
 #undef S_CASE
         default: break;
       }
+      if (a.rowscale || a.rowsq) return -1;
       return launch_cfg<128, 128, 2, 2, 1, -1>(a, st);
     }
     // cfg 22 = 64x128 tiles, same kernel (wave tile 32x64): twice the blocks of cfg 21 for launches that would leave most CUs with
@@ -936,18 +987,22 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
       if (stg_ok) switch (epi) {
 #define S_CASE(E) case E: return launch_cfg<64, 128, 2, 2, 1, E, 1, 3>(a, st);
         S_CASE(0) S_CASE(32) S_CASE(33) S_CASE(34) S_CASE(3) S_CASE(44) S_CASE(56) S_CASE(8) S_CASE(4) S_CASE(36)
+        S_CASE(64) S_CASE(67) S_CASE(98) S_CASE(128) S_CASE(136) S_CASE(184) S_CASE(192)
 #undef S_CASE
         default: break;
       }
+      if (a.rowscale || a.rowsq) return -1;
       return launch_cfg<64, 128, 2, 2, 1, -1>(a, st);
     }
     case 82: {
       if (stg_ok) switch (epi) {
 #define PP_CASE(E) case E: return launch_pp<E, 1>(a, st);
         PP_CASE(0) PP_CASE(32) PP_CASE(33) PP_CASE(34) PP_CASE(3) PP_CASE(44) PP_CASE(56) PP_CASE(8) PP_CASE(4) PP_CASE(36)
+        PP_CASE(64) PP_CASE(67) PP_CASE(98) PP_CASE(128) PP_CASE(136) PP_CASE(184) PP_CASE(192)
 #undef PP_CASE
         default: break;
       }
+      if (a.rowscale || a.rowsq) return -1;
       return launch_pp<-1>(a, st);
     }
     case 85: return launch_pp<-1>(a, st);                   // ping-pong with the per-lane epilogue (A/B only)

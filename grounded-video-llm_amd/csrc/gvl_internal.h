@@ -144,6 +144,12 @@ struct GemmArgs {
   int grp_rows, grp_stride, row_off;
   int tile_cfg;                  // 0 auto; see gvl_launch_gemm
   int m_begin;                   // launch covers rows [m_begin, M) -- set internally by the wave-quantisation split
+  // Fused RMSNorm (round 5).  CONSUMER side: rowscale[m] (f32, [M]) multiplies row m of the accumulator BEFORE bias / activation -- RMSNorm(x) . W^T =
+  // rs[m] * (x . (W diag(gamma))^T): A is the RAW residual stream, W carries the norm weight (gvl_fold_gamma), rs = rsqrt(mean x^2 + eps).
+  // PRODUCER side: rowsq[m * rowsq_ld + n / 64] (f32) receives the sum of squares of the bf16-ROUNDED outputs of row m over each aligned block of 64
+  // columns -- the statistics the NEXT norm needs, taken while the row piece is in registers (N % 64 == 0; bf16 output; staged epilogue only).
+  const float* rowscale;
+  float* rowsq; int rowsq_ld;
   const float* act_table;        // set by the launcher: Phi(x) table for the erf-GELU epilogue of the ping-pong kernel (see gvl_gemm.hip)
   unsigned long long* dbg;       // null, or [grid][8 waves][4] s_memtime stamps of the LAST tile (GVL_GEMM_TIMING=1, ping-pong kernel)
 };
@@ -207,6 +213,8 @@ int gvl_launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st);
 // ---- elementwise / norm / glue kernels (gvl_elem.hip) ----------------------------------------------
 int gvl_launch_layernorm_f32(const float* x, const float* w, const float* b, bf16_t* y, int rows, int cols, float eps, hipStream_t st);
 int gvl_launch_rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, float eps, hipStream_t st);
+int gvl_launch_fold_gamma(const bf16_t* W, const bf16_t* gamma, bf16_t* Wo, long rows, int cols, hipStream_t st);   // W' = bf16(W diag(gamma)): fused RMSNorm, consumer weights
+int gvl_launch_rowsq_finish(const float* sq, int ld, int b0, int nblk, float* rs, int rows, int cols, float eps, hipStream_t st);   // partial sums of squares -> rsqrt(mean + eps)
 // im2col for a stride==kernel patch conv.  px f32 [n_img][3][T][HW][HW] (T==1 for CLIP) -> A bf16 [n_img*T*g*g][Kp]
 int gvl_launch_patchify(const float* px, bf16_t* A, int n_img, int T, int image, int patch, int Kp, hipStream_t st);
 // CLIP embeddings + pre-LN: x[n,0]=cls+pos0, x[n,1+p]=bf16r(patch)+pos -> LN -> f32 [n,1+P,C]
@@ -245,6 +253,9 @@ struct QkvPostArgs {
   int k_ones;                      // K pad column Dr (needs D > Dr) is 1.0 instead of 0 (harmless while q's pad is 0; see AttnArgs.k_ones)
   float* q_rs;                     // mode 1, or null: [B*S] -- the q rows are NOT written; their RMS factor rsqrt(mean q^2 + eps) is, and the attention
                                    //   kernel normalises the q fragments it loads from the qkv matrix itself (AttnArgs.q_rs / q_nw)
+  const float* k_rs_in;            // mode 1 with q_rs, or null: [B*S] RMS factor of the k rows, ALREADY computed (round 5: from the row statistics the qkv
+                                   //   GEMM's epilogue left, GemmArgs.rowsq -> gvl_launch_rowsq_finish) -- then q_rs is an input too (same source) and this pass
+                                   //   neither reads q nor reduces anything: it reads k, scales, writes the K pages
 };
 int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st);
 // HD 2x2 merge + sub_GN newline (Phi): f32 [n,576,C] -> bf16 [n,156,4C]

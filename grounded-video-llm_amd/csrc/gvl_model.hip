@@ -118,6 +118,8 @@ size_t iv2_bytes(const gvl_ctx* c, int n) {
   b += al256((size_t)n * c->v_TL * c->v_Kp * 2) + al256((size_t)n * c->v_TL * C * 2);
   b += al256((size_t)n * f.iv2_heads * c->v_S * c->v_D * 2) + 2 * al256((size_t)n * tiles * f.iv2_heads * 64 * c->v_D * 2);
   b += al256(M * 4);                                   // per-token RMS factor of q (iv2_encode: qrs)
+  b += al256(M * ((C + 63) / 64) * 4) + al256(M * 4);  // fused RMSNorm: row sums of squares per 64-column block + the row scale
+  b += al256(M * ((3 * C + 63) / 64) * 4) + al256(M * 4);   // ... of the qkv rows (q / k RMSNorm statistics) + the k row scale
   return b + 4096;
 }
 size_t visual_bytes(const gvl_ctx* c, int n) {
@@ -139,6 +141,7 @@ size_t prefill_bytes(const gvl_ctx* c, int S) {
   b += 2 * al256((size_t)S * f.hidden * 2) + al256((size_t)S * qkvw * 2) + al256((size_t)S * f.heads * c->l_Dr * 2);
   b += al256((size_t)S * f.inter * 2) + al256((size_t)f.heads * S * c->l_D * 2);
   b += al256((size_t)kLossChunk * f.vocab * 2) + al256((size_t)kLossChunk * f.hidden * 2) + 3 * al256((size_t)S * 4);   // loss tail (gvl_forward_loss)
+  b += al256((size_t)S * ((f.hidden + 63) / 64) * 4) + al256((size_t)S * 4);                                          // fused RMSNorm: row statistics + row scale
   return b + 4096;
 }
 size_t feats_bytes(const gvl_ctx* c, int n) {
@@ -224,21 +227,54 @@ int iv2_encode(gvl_ctx* ctx, const float* px, int n, bf16_t* out, hipStream_t st
   }
   const bool vt_pages = !ctx->dbg.vision_in_place || D == 128, q_in_place = ctx->dbg.vision_in_place == 1 && D == 96 && Dr == 88;
   AALLOC(qrs, float, (size_t)M);
+  // Fused RMSNorm (gvl_debug_set("norm_fused"), default on): the two norm passes of a block (read x, write h: 1.1 GB each at 96 segments) are gone.  The
+  // GEMM that writes the residual stream (proj / fc2) leaves the row sums of squares of its bf16 outputs per 64-column block (GemmArgs.rowsq), a tiny
+  // kernel turns them into rs[m] = rsqrt(mean + eps), and the consuming GEMM (qkv / fc1) reads the RAW stream x with the norm weight folded into its
+  // weight and multiplies its accumulator rows by rs (GemmArgs.rowscale).  Block 0's first norm has no producer GEMM and keeps the pass.
+  const int NBLK = C / 64;
+  const bool nf = ctx->dbg.norm_fused && C % 64 == 0 && !ctx->vb.empty() && ctx->vb[0].qkvw_f;
+  AALLOC(sq, float, (size_t)M * (nf ? NBLK : 1)); AALLOC(nrs, float, (size_t)M);
+  // the q / k RMSNorm statistics (over the full width C, internvideo2.py:590-598) come the same way when q is read in place: the qkv GEMM leaves the row
+  // sums of squares of its 3 C outputs, two finish launches make q_rs (blocks 0 .. NBLK) and k_rs (NBLK .. 2 NBLK), and qkv_post no longer reads q at all
+  // MEASURED AND SWITCHED OFF (profiles/r05_ab_norm_fused.json, same box): the statistics cost the qkv GEMM +0.8 ms per clip (66 blocks of row sums per row)
+  // and two more small launches per block, and qkv_post did not get faster without its q read (it is bound by the K-page write, not by that read): a net loss.
+  const bool qk_stats = false && nf && q_in_place;
+  AALLOC(sq3, float, (size_t)M * (qk_stats ? 3 * NBLK : 1)); AALLOC(krs, float, (size_t)M);
   for (int l = 0; l < f.iv2_blocks_run; ++l) {
     const Iv2BlockW& w = ctx->vb[l];
-    RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.n1, h, M, C, 1e-6f, st));
-    { GemmArgs g = gemm(h, C, w.qkvw, qkv, 3 * C, M, 3 * C, C); RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    if (nf && l > 0) {
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_rowsq_finish(sq, NBLK, 0, NBLK, nrs, M, C, 1e-6f, st));
+      GemmArgs g = gemm(x, C, w.qkvw_f, qkv, 3 * C, M, 3 * C, C); g.rowscale = nrs; if (qk_stats) { g.rowsq = sq3; g.rowsq_ld = 3 * NBLK; }
+      RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
+    } else {
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.n1, h, M, C, 1e-6f, st));
+      GemmArgs g = gemm(h, C, w.qkvw, qkv, 3 * C, M, 3 * C, C); if (qk_stats) { g.rowsq = sq3; g.rowsq_ld = 3 * NBLK; }
+      RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
+    }
+    if (qk_stats) {
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_rowsq_finish(sq3, 3 * NBLK, 0, NBLK, qrs, M, C, 1e-6f, st));
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_rowsq_finish(sq3, 3 * NBLK, NBLK, NBLK, krs, M, C, 1e-6f, st));
+    }
     { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv; q.ld = 3 * C; q.Q = Q; q.Kt = Kt; q.Vt = vt_pages ? Vt : nullptr; q.B = n; q.S = S; q.H = H; q.KV = H; q.Dr = Dr; q.D = D;
-      q.mode = 1; q.qn = w.qn; q.kn = w.kn; q.eps = 1e-6f; q.ones_row = D > Dr ? 1 : 0; q.q_rs = q_in_place ? qrs : nullptr; q.k_ones = D > Dr ? 1 : 0; RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
+      q.mode = 1; q.qn = w.qn; q.kn = w.kn; q.eps = 1e-6f; q.ones_row = D > Dr ? 1 : 0; q.q_rs = q_in_place ? qrs : nullptr; q.k_ones = D > Dr ? 1 : 0;
+      if (qk_stats) q.k_rs_in = krs;
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
     { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; if (!vt_pages) { a.Vrows = qkv + 2 * C; a.v_ld = 3 * C; } a.O = att; a.B = n; a.H = H; a.KV = H; a.S = S; a.D = D; a.Dout = Dr;
       if (q_in_place) { a.Qrows = qkv; a.q_ld = 3 * C; a.q_rs = qrs; a.q_nw = w.qn; a.k_ones = 1; a.pipe = ctx->dbg.attn_pipe; a.pipe_rows = ctx->dbg.attn_pipe_rows; }      // q read in place, normalised by the attention prologue: no Q write pass
       a.scale = 1.0f / sqrtf((float)Dr); a.causal = 0; a.ones_row = D > Dr ? 1 : 0;   // head dim 88 padded to 96: the pad row of V^T carries the softmax row sum
       RUN(GVL_PROF_ATTN, gvl_attn_flops(a), gvl_launch_attention(a, st)); }
     { GemmArgs g = gemm(att, C, w.projw, x, C, M, C, C); g.bias = w.projb; g.gamma = w.ls1; g.resid = x; g.ldr = C;
+      if (nf) { g.rowsq = sq; g.rowsq_ld = NBLK; }
       RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
-    RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.n2, h, M, C, 1e-6f, st));
-    { GemmArgs g = gemm(h, C, w.fc1w, mlp, I, M, I, C); g.bias = w.fc1b; g.act = GVL_ACT_GELU; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    if (nf) {
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_rowsq_finish(sq, NBLK, 0, NBLK, nrs, M, C, 1e-6f, st));
+      GemmArgs g = gemm(x, C, w.fc1w_f, mlp, I, M, I, C); g.bias = w.fc1b; g.act = GVL_ACT_GELU; g.rowscale = nrs; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
+    } else {
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.n2, h, M, C, 1e-6f, st));
+      GemmArgs g = gemm(h, C, w.fc1w, mlp, I, M, I, C); g.bias = w.fc1b; g.act = GVL_ACT_GELU; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
+    }
     { GemmArgs g = gemm(mlp, I, w.fc2w, x, C, M, C, I); g.bias = w.fc2b; g.gamma = w.ls2; g.resid = x; g.ldr = C;
+      if (nf && l + 1 < f.iv2_blocks_run) { g.rowsq = sq; g.rowsq_ld = NBLK; }
       RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
   }
   RUN(GVL_PROF_OTHER, 0, gvl_launch_strip_cls(x, out, n, S, C, 2, st));
@@ -315,13 +351,23 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
     table = tb; table_stride = P0;
   }
   for (int b = 0; b < nb; ++b) HIPCHK(ctx, hipMemcpyAsync(x + (size_t)off[b] * Hd, embeds[b], (size_t)lens[b] * Hd * 2, hipMemcpyDeviceToDevice, st));
+  // fused RMSNorm (see iv2_encode): o_proj / down_proj leave the row statistics of the new residual stream, qkv_proj / gate_up_proj consume the raw
+  // stream with the norm weight folded in and scale their accumulator rows; layer 0's input norm keeps the pass
+  const int NBLK = Hd / 64;
+  const bool nf = ctx->dbg.norm_fused && Hd % 64 == 0 && !ctx->ll.empty() && ctx->ll[0].qkvw_f;
+  LALLOC(sq, float, (size_t)M * (nf ? NBLK : 1)); LALLOC(nrs, float, (size_t)M);
   // one (RoPE + KV append, attention) launch for the whole batch when the lengths agree, one per sequence otherwise
   const int n_att = (nb == 1 || uniform) ? 1 : nb;
   for (int l = 0; l < f.layers; ++l) {
     const LlmLayerW& w = ctx->ll[l];
     bf16_t* Kt = ctx->kpool + (size_t)l * ctx->layer_stride; bf16_t* Vt = ctx->vpool + (size_t)l * ctx->layer_stride;
-    RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln1, h, M, Hd, f.rms_eps, st));
-    { GemmArgs g = gemm(h, Hd, w.qkvw, qkv, qkvw, M, qkvw, Hd); RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    if (nf && l > 0) {
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_rowsq_finish(sq, NBLK, 0, NBLK, nrs, M, Hd, f.rms_eps, st));
+      GemmArgs g = gemm(x, Hd, w.qkvw_f, qkv, qkvw, M, qkvw, Hd); g.rowscale = nrs; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
+    } else {
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln1, h, M, Hd, f.rms_eps, st));
+      GemmArgs g = gemm(h, Hd, w.qkvw, qkv, qkvw, M, qkvw, Hd); RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
+    }
     // ragged group: RoPE / KV append per sequence (HBM-bound passes), then ONE causal-attention grid over the query blocks of all sequences
     // (AttnArgs.vl_*; 8 launches of ~900 blocks on 768 block slots each -> one of ~7 000: the causal tail is paid once) -- bit-identical per row
     const bool vl_attn = n_att > 1 && ctx->dbg.varlen_attn && pos0 == 0;
@@ -351,10 +397,17 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
       a.vl_rows[nb] = off[nb]; a.max_pages = 0;
       RUN(GVL_PROF_ATTN, fl, gvl_launch_attention(a, st));
     }
-    { GemmArgs g = gemm(att, H * Dr, w.ow, x, Hd, M, Hd, H * Dr); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
-    RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln2, h, M, Hd, f.rms_eps, st));
-    { GemmArgs g = gemm(h, Hd, w.guw, act, I, M, 2 * I, Hd); g.act = GVL_ACT_SILU_MUL; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
-    { GemmArgs g = gemm(act, I, w.downw, x, Hd, M, Hd, I); g.resid = x; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    { GemmArgs g = gemm(att, H * Dr, w.ow, x, Hd, M, Hd, H * Dr); g.resid = x; g.ldr = Hd; if (nf) { g.rowsq = sq; g.rowsq_ld = NBLK; }
+      RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    if (nf) {
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_rowsq_finish(sq, NBLK, 0, NBLK, nrs, M, Hd, f.rms_eps, st));
+      GemmArgs g = gemm(x, Hd, w.guw_f, act, I, M, 2 * I, Hd); g.act = GVL_ACT_SILU_MUL; g.rowscale = nrs; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
+    } else {
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.ln2, h, M, Hd, f.rms_eps, st));
+      GemmArgs g = gemm(h, Hd, w.guw, act, I, M, 2 * I, Hd); g.act = GVL_ACT_SILU_MUL; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
+    }
+    { GemmArgs g = gemm(act, I, w.downw, x, Hd, M, Hd, I); g.resid = x; g.ldr = Hd; if (nf && l + 1 < f.layers) { g.rowsq = sq; g.rowsq_ld = NBLK; }
+      RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
   }
   if (loss && loss->n > 0) {
     // training forward (llava_next_video.py:598-614 -> Phi3ForCausalLM.forward labels branch, modeling_phi3.py:1512-1539): only rows
@@ -705,6 +758,8 @@ int gvl_destroy(gvl_ctx* ctx) {
   for (void* p : ctx->dw_allocs) if (p) hipFree(p);
   for (void* p : ctx->pw_allocs) if (p) hipFree(p);
   ctx->pw_allocs.clear();
+  for (void* p : ctx->nf_allocs) if (p) hipFree(p);
+  ctx->nf_allocs.clear();
   if (ctx->comm) gvl_comm_destroy(ctx);
   void* ptrs[] = {ctx->d_xn, ctx->d_seq_ngen, ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_out, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -749,6 +804,20 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
 #undef CN
     }
   }
+  // fused RMSNorm (round 5): the norm weight is folded into the projection that consumes the norm -- W' = bf16(W diag(gamma)), a second copy beside the
+  // original (the unfused path, gvl_debug_set("norm_fused", 0), and the decode tile copies keep reading the original); 1.1 GB for InternVideo2-1B,
+  // 5 GB for Phi-3.5, 9 GB for Llama-3-8B of the 288 GB
+  if (!ctx->nf_allocs.empty()) HIPCHK(ctx, hipDeviceSynchronize());
+  for (void* p : ctx->nf_allocs) if (p) hipFree(p);
+  ctx->nf_allocs.clear();
+  auto folded = [&](const bf16_t* W, const bf16_t* gamma, long rows, int cols, const bf16_t** out) -> int {
+    void* q = nullptr;
+    if (hipMalloc(&q, (size_t)rows * cols * 2) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, GVL_ERR_OOM, "hipMalloc(norm-folded weight copy) failed"); }
+    ctx->nf_allocs.push_back(q);
+    if (gvl_launch_fold_gamma(W, gamma, (bf16_t*)q, rows, cols, nullptr)) return fail(ctx, GVL_ERR_HIP, "fold_gamma launch failed");
+    *out = (const bf16_t*)q;
+    return 0;
+  };
   // fused patch embedding (gvl_patch.hip): tile-order copies of the conv weights, for the geometries the kernel is built for.
   // A repeated finalize frees the previous copies: encodes still in flight on other streams may be reading them -- drain the device first.
   if (!ctx->pw_allocs.empty()) HIPCHK(ctx, hipDeviceSynchronize());
@@ -780,6 +849,11 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
       NEED(VN("fc1.w"), GVL_BF16, (int64_t)I * C, &w.fc1w); NEED(VN("fc1.b"), GVL_F32, I, &w.fc1b);
       NEED(VN("fc2.w"), GVL_BF16, (int64_t)C * I, &w.fc2w); NEED(VN("fc2.b"), GVL_F32, C, &w.fc2b);
 #undef VN
+      if (C % 64 == 0) {
+        int rc = folded(w.qkvw, w.n1, (long)3 * C, C, &w.qkvw_f);
+        if (!rc) rc = folded(w.fc1w, w.n2, (long)I, C, &w.fc1w_f);
+        if (rc) return rc;
+      }
     }
   }
   if (ctx->has_proj) {
@@ -855,6 +929,15 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
       }
       { const int rc = tiled(ctx->l_headw, f.vocab, Hd, 0, 0, &ctx->l_headd, &ctx->l_heads); if (rc) return rc; }
     }
+    // norm-folded prefill weights LAST: the quantised decode formats above replace the row-major weights by their de-quantised values (same stream, in
+    // order), and the fused-RMSNorm prefill must evaluate that same model
+    if (Hd % 64 == 0)
+      for (int l = 0; l < f.layers; ++l) {
+        LlmLayerW& w = ctx->ll[l];
+        int rc = folded(w.qkvw, w.ln1, (long)qkvw, Hd, &w.qkvw_f);
+        if (!rc) rc = folded(w.guw, w.ln2, (long)2 * I, Hd, &w.guw_f);
+        if (rc) return rc;
+      }
   }
   // the retile kernels above (patch weights, decode tile copies) ran on the null stream: a first encode / decode on a NON-blocking stream (torch pool
   // streams, the bench's sV / sL) is not ordered behind them -- finalize returns only when every derived copy is complete
@@ -1238,6 +1321,7 @@ int gvl_debug_set(gvl_ctx* ctx, const char* key, int value) {
   else if (k == "attn_pipe_rows") { if (value != 128 && value != 256) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: attn_pipe_rows must be 128 (default) or 256"); ctx->dbg.attn_pipe_rows = value; }
   else if (k == "patch_fused") ctx->dbg.patch_fused = value != 0;
   else if (k == "varlen_attn") ctx->dbg.varlen_attn = value != 0;
+  else if (k == "norm_fused") ctx->dbg.norm_fused = value != 0;
   else if (k == "vision_in_place") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: vision_in_place must be 0, 1 or 2"); ctx->dbg.vision_in_place = value; }
   else return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: unknown key " + k);
   return 0;
@@ -1316,6 +1400,31 @@ int gvl_op_gemm(gvl_ctx* ctx, const uint16_t* A, const uint16_t* W, void* C, int
   g.bias = bias; g.gamma = gamma; g.resid = resid; g.ldr = N; g.act = act; g.out_f32 = out_f32; g.round_pre_resid = 1; g.tile_cfg = tile_cfg;
   if (const char* e = gvl_lab_env("GVL_LAB_LD")) { int la = 0, lw = 0; if (sscanf(e, "%d,%d", &la, &lw) == 2) { g.lda = la; g.ldw = lw; } }   // LAB: operand row pitches (tools/gemm_lab.py)
   RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
+  return 0;
+}
+// The fused-RMSNorm epilogues at operator level (bf16 output): rowscale [M] f32 or null multiplies the accumulator rows before bias / activation; rowsq
+// [M][rowsq_ld] f32 or null receives the sums of squares of the rounded outputs per aligned 64-column block (N % 64 == 0).
+int gvl_op_gemm_rows(gvl_ctx* ctx, const uint16_t* A, const uint16_t* W, uint16_t* C, int M, int N, int K, const float* bias, const float* gamma,
+                     const uint16_t* resid, int act, const float* rowscale, float* rowsq, int rowsq_ld, int tile_cfg, void* stream) {
+  if (!ctx) return GVL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs g = gemm(A, K, W, C, act == GVL_ACT_SILU_MUL ? N / 2 : N, M, N, K);
+  g.bias = bias; g.gamma = gamma; g.resid = resid; g.ldr = N; g.act = act; g.round_pre_resid = 1; g.tile_cfg = tile_cfg;
+  g.rowscale = rowscale; g.rowsq = rowsq; g.rowsq_ld = rowsq_ld;
+  RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
+  return 0;
+}
+// W' = bf16(W diag(gamma)) and rs = rsqrt(sum of the blocks [b0, b0 + nblk) / cols + eps): the two small kernels around those epilogues
+int gvl_op_fold_gamma(gvl_ctx* ctx, const uint16_t* W, const uint16_t* gamma, uint16_t* Wo, int64_t rows, int cols, void* stream) {
+  if (!ctx) return GVL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_fold_gamma(W, gamma, Wo, (long)rows, cols, st));
+  return 0;
+}
+int gvl_op_rowsq_finish(gvl_ctx* ctx, const float* rowsq, int ld, int b0, int nblk, float* rs, int rows, int cols, float eps, void* stream) {
+  if (!ctx) return GVL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  RUN(GVL_PROF_OTHER, 0, gvl_launch_rowsq_finish(rowsq, ld, b0, nblk, rs, rows, cols, eps, st));
   return 0;
 }
 int gvl_op_attention(gvl_ctx* ctx, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out, int B, int S, int H, int KV, int Dr,

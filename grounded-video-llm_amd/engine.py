@@ -425,6 +425,31 @@ class Engine:
                                        _ptr(resid), act, 1 if out_f32 else 0, tile_cfg, self.stream), "gvl_op_gemm")
         return Cc
 
+    def op_gemm_rows(self, A, W, bias=None, gamma=None, resid=None, act=L.ACT_NONE, rowscale=None, want_rowsq=False, tile_cfg=0):
+        """gvl_op_gemm_rows: the fused-RMSNorm epilogues.  rowscale [M] f32 multiplies the accumulator rows; want_rowsq: also returns the sums of squares of the
+        bf16 outputs per aligned 64-column block, [M, N // 64] f32 (NaN-filled first: every slot must be written)."""
+        M, K = A.shape
+        N = W.shape[0]
+        n_out = N // 2 if act == L.ACT_SILU_MUL else N
+        Cc = torch.empty((M, n_out), dtype=bf, device=self.device)
+        sq = torch.full((M, N // 64), float("nan"), dtype=torch.float32, device=self.device) if want_rowsq else None
+        self._chk(self.lib.gvl_op_gemm_rows(self.ctx, _ptr(A.contiguous()), _ptr(W.contiguous()), _ptr(Cc), M, N, K, _ptr(bias), _ptr(gamma), _ptr(resid), act,
+                                            _ptr(rowscale), _ptr(sq), N // 64 if want_rowsq else 0, tile_cfg, self.stream), "gvl_op_gemm_rows")
+        return (Cc, sq) if want_rowsq else Cc
+
+    def op_fold_gamma(self, W, gamma):
+        W = W.contiguous()
+        out = torch.empty_like(W)
+        self._chk(self.lib.gvl_op_fold_gamma(self.ctx, _ptr(W), _ptr(gamma.contiguous()), _ptr(out), W.shape[0], W.shape[1], self.stream), "gvl_op_fold_gamma")
+        return out
+
+    def op_rowsq_finish(self, sq, cols, eps, b0=0, nblk=None):
+        sq = sq.contiguous()
+        nblk = sq.shape[1] - b0 if nblk is None else nblk
+        rs = torch.empty((sq.shape[0],), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.gvl_op_rowsq_finish(self.ctx, _ptr(sq), sq.shape[1], b0, nblk, _ptr(rs), sq.shape[0], cols, float(eps), self.stream), "gvl_op_rowsq_finish")
+        return rs
+
     def op_attention(self, qkv: torch.Tensor, B, S, H, KV, Dr, scale, causal):
         """qkv bf16 [B*S, (H+2KV)*Dr] fused rows -> out bf16 [B*S, H*Dr]."""
         qkv = qkv.contiguous()

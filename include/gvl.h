@@ -263,6 +263,10 @@ int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launche
  *                      the DMA pieces per MFMA; measured 12 % slower), the remaining rows on the 4-wave form -- bit-identical
  *   "varlen_attn"      1 (default): the causal attention of a ragged prefill group (gvl_prefill_varlen) runs as ONE grid over the query blocks of all its sequences;
  *                      0: one launch per sequence (rounds 2-4) -- bit-identical
+ *   "norm_fused"       1 (default): RMSNorm in front of qkv / fc1 (InternVideo2) and qkv_proj / gate_up_proj (LLM prefill) is fused into the GEMMs around it
+ *                      (row statistics from the producing GEMM's epilogue, norm weight folded into the consuming GEMM's weight, row scale in its epilogue); 0: the
+ *                      separate norm pass of rounds 1-4.  NOT bit-neutral -- the third stated exception below: two activation roundings of the reference
+ *                      (x * rs and the gamma product, both to bf16) are gone and gamma * W is rounded once per weight instead
  *   "patch_fused"      1 (default): the patch embedding of a tower whose geometry the fused kernel covers (patch 14, width 1024 / 1408) runs as ONE kernel
  *                      (gvl_patch.hip: im2col in the operand loader + GEMM + CLS / position rows + CLIP's pre-LayerNorm); 0: the three-pass path (patchify, GEMM,
  *                      embed).  NOT bit-neutral: the fp32 accumulation order over k differs (agreement to fp32 rounding before the bf16 round; tests/test_gpu_towers.py)
@@ -272,8 +276,8 @@ int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launche
  *                      tests/test_gpu_towers.py); the pipelined normal pass keeps the first tile's maximum as the softmax reference for the whole row, so on
  *                      scores where a later tile exceeds it by more than 2^8 the two differ at P-rounding level (bounded at 1.5e-2 of the output scale by
  *                      the sharp-score test there) -- the second stated exception below; mode 2 is bit-identical to 0 on any data
- * None of them may change a single output bit (asserted in tests/test_gpu_llm.py) -- with TWO stated exceptions: "attn_pipe" = 1 on peaked scores
- * (above), and "vision_in_place" = 1 on a head
+ * None of them may change a single output bit (asserted in tests/test_gpu_llm.py) -- with THREE stated exceptions: "norm_fused" and "attn_pipe" = 1 on
+ * peaked scores (above), and "vision_in_place" = 1 on a head
  * dim that is padded (InternVideo2, 88 -> 96) folds the softmax scale and shift into q before its one rounding to bf16, a different (not larger)
  * set of rounding points: modes 0 and 2 are bit-identical to each other, mode 1 is bit-identical to them for CLIP (head dim 64) and agrees within
  * bf16 noise for InternVideo2 (one block 4.1e-3 of the output scale; 39 blocks vs the reference: the same error as the reference's own bf16,
@@ -287,6 +291,16 @@ int gvl_debug_set(gvl_ctx* ctx, const char* key, int value);
 int gvl_op_gemm(gvl_ctx* ctx, const uint16_t* A, const uint16_t* W, void* C, int M, int N, int K,
                 const float* bias, const float* gamma, const void* resid, int act, int out_f32,
                 int tile_cfg, void* stream);
+/* Fused RMSNorm at operator level (round 5; what the towers and the prefill run: models/internvideo2.py:443-448,590-603, modeling_phi3.py:319-324):
+ *   RMSNorm(x) W^T  ==  rs[m] * (x (W diag(gamma))^T),   rs[m] = rsqrt(mean_k x[m][k]^2 + eps)
+ * gvl_op_gemm_rows: gvl_op_gemm with bf16 output plus rowscale ([M] f32 or NULL: multiplies the accumulator rows before bias / activation) and rowsq
+ * ([M][rowsq_ld] f32 or NULL: the GEMM that WRITES the residual stream leaves the sum of squares of its rounded outputs per aligned block of 64 columns;
+ * N % 64 == 0).  gvl_op_fold_gamma: Wo = bf16(W diag(gamma)), W [rows][cols], gamma [cols] bf16.  gvl_op_rowsq_finish: rs[m] = rsqrt((sum of the blocks
+ * [b0, b0 + nblk) of row m) / cols + eps). */
+int gvl_op_gemm_rows(gvl_ctx* ctx, const uint16_t* A, const uint16_t* W, uint16_t* C, int M, int N, int K, const float* bias, const float* gamma,
+                     const uint16_t* resid, int act, const float* rowscale, float* rowsq, int rowsq_ld, int tile_cfg, void* stream);
+int gvl_op_fold_gamma(gvl_ctx* ctx, const uint16_t* W, const uint16_t* gamma, uint16_t* Wo, int64_t rows, int cols, void* stream);
+int gvl_op_rowsq_finish(gvl_ctx* ctx, const float* rowsq, int ld, int b0, int nblk, float* rs, int rows, int cols, float eps, void* stream);
 /* attention over q/k/v bf16 [B,S,H|KV,D] (plain layout; the library re-tiles internally).
  * out bf16 [B,S,H*D].  causal: 0/1. */
 int gvl_op_attention(gvl_ctx* ctx, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out,

@@ -75,3 +75,34 @@ def noise_class(got, ref32, ref_bf16, what, floor=1e-2, cap=BF16_CLASS_CAP, rms_
     assert r_h <= rms_cap * r_b or e_h <= floor, f"{what}: rms error of HIP {r_h:.3e} > {rms_cap} x {r_b:.3e} of the reference's own bf16 evaluation"
     assert r_hb <= 1.6 * max(r_b, r_h), f"{what}: HIP and the reference's bf16 evaluation are further apart ({r_hb:.3e}) than two bf16 evaluations should be"
     return e_h, e_b
+
+
+LFL_MAX_CAP, LFL_RMS_CAP = 1.15, 1.10   # against the LIKE-FOR-LIKE bf16 evaluation of the reference the data supports these (largest observed ratios are printed)
+
+
+def like_for_like(rows, tag, what):
+    """The parity statement of the full-size configs, like for like (round 5).  tests/golden/<tag>_bf16path.npz (oracle/make_golden_bf16path.py) holds the
+    REFERENCE evaluated the way its GPU path runs -- autocast(bf16) CLIP + projectors, bf16 InternVideo2, bf16 LLM on THAT bf16 prefix
+    (llava_next_video.py:134,503-564; inference.py:178-182) -- sampled like <tag>_full.npz.  `rows`: the HIP logits rows, already sampled ([rows][sample]).
+    Asserts  max|HIP - fp32| <= max(1e-2, 1.15 x max|ref_bf16path - fp32|)  and  rms <= 1.10 x rms  (units of the fp32 logit scale), and prints ONE
+    table line per config with the north-star's 1e-2 beside it (collected into profiles/r05_parity_observed.txt)."""
+    import os
+    from conftest import GOLDEN, load_golden
+    path = os.path.join(GOLDEN, tag + "_bf16path.npz")
+    meta, g = load_golden(tag + "_full")
+    key = "logits_steps" if "logits_steps" in g else "logits_rows"
+    r = torch.as_tensor(np.asarray(g[key])).double()
+    h = torch.as_tensor(np.asarray(rows.detach().float().cpu() if isinstance(rows, torch.Tensor) else rows)).double()
+    p = torch.as_tensor(np.load(path)["logits_rows_bf16path"]).double()
+    assert h.shape == r.shape == p.shape, (h.shape, r.shape, p.shape)
+    scale = float(r.abs().max())
+    mx = lambda t: float(t.abs().max()) / scale
+    rms = lambda t: float(t.pow(2).mean().sqrt()) / scale
+    e_h, e_p, r_h, r_p = mx(h - r), mx(p - r), rms(h - r), rms(p - r)
+    worst_row = max(mx(h[i] - r[i]) * scale / scale for i in range(h.shape[0]))
+    print(f"[parity-table] {what} | rows {h.shape[0]} | HIP vs ref-fp32: max {e_h:.3e} rms {r_h:.3e} | reference like-for-like bf16 vs its fp32: max {e_p:.3e} rms {r_p:.3e} | "
+          f"ratio max {e_h / e_p:.2f} rms {r_h / r_p:.2f} | north-star 1e-2 rel: rms {'met' if r_h <= 1e-2 else 'NOT met'} ({r_h / 1e-2:.2f} x), max-abs "
+          f"{'met' if e_h <= 1e-2 else 'not met'} ({e_h / 1e-2:.2f} x; the reference's own bf16 path: {e_p / 1e-2:.2f} x)")
+    assert e_h <= max(1e-2, LFL_MAX_CAP * e_p), f"{what}: HIP max {e_h:.3e} > max(1e-2, {LFL_MAX_CAP} x {e_p:.3e}) of the reference's like-for-like bf16 evaluation"
+    assert r_h <= LFL_RMS_CAP * r_p, f"{what}: HIP rms {r_h:.3e} > {LFL_RMS_CAP} x {r_p:.3e}"
+    return e_h, e_p, r_h, r_p

@@ -124,7 +124,7 @@ def _full_depth_vs_reference_golden(llama, name):
     bf16 evaluation stored in the golden) on the max-abs error, 1.15 x on the RMS error (gpu_util.noise_class)."""
     import numpy as np
     from conftest import load_golden
-    from gpu_util import BF16_CLASS_CAP, check, noise_class
+    from gpu_util import BF16_CLASS_CAP, check, like_for_like, noise_class
     eng, geo = llama
     meta, g = load_golden(name)
     sd, st = meta["seeds"], meta["stride"]
@@ -156,6 +156,7 @@ def _full_depth_vs_reference_golden(llama, name):
     print(f"[parity] {name} logits, prefill row + teacher-forced decode rows (every {step}; of the logit scale):", " ".join(f"{e:.2e}" for e in errs))
     assert max(errs) <= tol
     noise_class(torch.stack([r[::ls].cpu() for r in rows]), g["logits_rows"], g["logits_rows_bf16ref"], f"{name} Llama-3-8B 32 L logits, S={S}, {len(rows)} rows")
+    like_for_like(torch.stack([r[::ls].cpu() for r in rows]), name[:2], f"{name[:2].upper()}  Llama-3-8B, {8 * n_segs} frames, S={S} (end to end)")
     margins = np.asarray(g["top1"]) - np.asarray(g["top2"])
     for i, r in enumerate(rows):
         if margins[i] > 2 * tol * scale:

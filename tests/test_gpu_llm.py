@@ -147,6 +147,15 @@ def test_phi3_full_width_layer():
     seq = eng.seq_alloc(128)
     logits = eng.prefill(seq, x.to(DEV).to(bf), want_logits=True)
     check(logits, g["logits"][0, -1], 1e-2, "phi3 full-width layer last logits vs reference golden")
+    # round 5: the prefill above ran with RMSNorm fused into the GEMMs around it (layers >= 1's input norm, every post-attention norm); the separate
+    # norm pass is held to the same golden, and the two to each other
+    eng.debug_set("norm_fused", 0)
+    s2 = eng.seq_alloc(128)
+    unf = eng.prefill(s2, x.to(DEV).to(bf), want_logits=True)
+    eng.seq_free(s2)
+    eng.debug_set("norm_fused", 1)
+    check(unf, g["logits"][0, -1], 1e-2, "phi3 full-width layer (separate norm pass) vs reference golden")
+    check(logits, unf, 1e-2, "phi3 full-width layer: fused RMSNorm vs the separate norm pass")
     # and one decode step through the full-width GEMV path
     ocfg = _ocfg(geo)
     cache = [None] * geo.layers

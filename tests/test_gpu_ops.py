@@ -103,6 +103,69 @@ def test_gemm_epilogues(eng, cfg):
     check(eng.op_gemm(A, W, act=L.ACT_SILU_MUL, tile_cfg=cfg), ref, 8e-3, "silu-mul epilogue")
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 1408, 1408), (5700, 1408, 1408), (333, 128, 64), (3000, 3072, 1024), (257, 4224, 128)])
+def test_gemm_row_sums_of_squares(eng, M, N, K):
+    """GemmArgs.rowsq (fused RMSNorm, producer side; internvideo2.py:443-448 needs mean(x^2) of the NEW residual stream): the GEMM that writes the stream leaves,
+    per row and aligned 64-column block, the sum of squares of its bf16-ROUNDED outputs.  (1) equals torch on the stored outputs; (2) every slot is written
+    exactly once (NaN-filled buffer), also through the planner's row / column splits; (3) BIT-identical whichever kernel of the launch plan computed the row
+    (256x256 ping-pong incl. its dead-wave tail tiles, 128x128, 64x128) -- the consumer's row scale must not depend on the batch composition."""
+    A = _rand(f"sqA{M}{N}{K}", (M, K)).to(bf)
+    W = _rand(f"sqW{M}{N}{K}", (N, K), K ** -0.5).to(bf)
+    bias = _rand(f"sqb{N}", (N,), 0.5)
+    gam = _rand(f"sqg{N}", (N,), 0.05) + 0.1
+    res = _rand(f"sqr{M}{N}", (M, N), 2.0).to(bf)
+    outs = {}
+    for cfg in (0, 21, 22, 82):
+        for kw in (dict(bias=bias, gamma=gam, resid=res), dict(resid=res), dict()):
+            c, sq = eng.op_gemm_rows(A, W, want_rowsq=True, tile_cfg=cfg, **kw)
+            assert torch.equal(c, eng.op_gemm(A, W, tile_cfg=cfg, **kw)), "the statistics must not change the output"
+            assert torch.isfinite(sq).all(), f"cfg {cfg}: a (row, block) slot was not written"
+            ref = c.float().pow(2).view(M, N // 64, 64).sum(-1)
+            check(sq, ref, 2e-6, f"rowsq {M}x{N}x{K} cfg{cfg} {sorted(kw)}")
+            key = tuple(sorted(kw))
+            if key in outs:
+                assert torch.equal(sq, outs[key]), f"rowsq differs bitwise between tile configurations (cfg {cfg})"
+            outs[key] = sq
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1000, 4224, 1408, "none"), (5700, 6144, 1408, "gelu"), (3000, 1024, 1024, "silu"), (130, 192, 64, "none"), (24588, 4224, 1408, "none")])
+def test_gemm_row_scale_is_rmsnorm_folded(eng, M, N, K, act):
+    """GemmArgs.rowscale + gvl_op_fold_gamma + gvl_op_rowsq_finish (fused RMSNorm, consumer side): rs[m] * (x . (W diag(gamma))^T) against (1) fp32 torch of
+    RMSNorm(x) W^T and (2) the UNFUSED pair this build also ships (rmsnorm_bf16 pass, then the plain GEMM): the two differ only in where roundings sit -- the
+    bound is the bf16 output rounding of either.  Bit-identical across tile configurations."""
+    x = (_rand(f"rsx{M}{K}", (M, K)) * (1.0 + _rand(f"rsm{M}", (M, 1)).abs())).to(bf)           # rows of different scale: rs really varies
+    W = _rand(f"rsW{N}{K}", (N, K), K ** -0.5).to(bf)
+    g = (_rand(f"rsg{K}", (K,), 0.2) + 1.0).to(bf)
+    bias = _rand(f"rsb{N}", (N,), 0.5) if act == "gelu" else None        # the fused-epilogue set the model uses: qkv (no bias), fc1 (bias + GELU), gate_up (SwiGLU)
+    eps = 1e-6
+    a = dict(none=L.ACT_NONE, gelu=L.ACT_GELU, silu=L.ACT_SILU_MUL)[act]
+    rb = lambda t: t.to(bf).float()
+    # the row statistics as the model gets them: from the epilogue of a GEMM that wrote x (identity-free here: any producer gives sum x^2 over 64-blocks)
+    sq = x.float().pow(2).view(M, K // 64, 64).sum(-1).contiguous()
+    rs = eng.op_rowsq_finish(sq, K, eps)
+    check(rs, torch.rsqrt(x.float().pow(2).mean(-1) + eps), 2e-6, "rowsq_finish")
+    Wf = eng.op_fold_gamma(W, g)
+    assert torch.equal(Wf, (W.float() * g.float()).to(bf))
+    got = eng.op_gemm_rows(x, Wf, bias=bias, act=a, rowscale=rs)
+    h32 = x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + eps) * g.float()
+    acc = h32 @ W.float().T + (bias if bias is not None else 0.0)
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(rb(acc))
+    elif act == "silu":
+        accn = rb(acc)
+        ref = accn[:, 1::2] * rb(torch.nn.functional.silu(accn[:, 0::2]))
+    else:
+        ref = acc
+    tol = 1.5e-2 if act == "silu" else 1e-2           # SwiGLU multiplies two rounded factors: the UNFUSED pair measures 1.17e-2 here, the fused one 8.7e-3
+    e_f = check(got, ref, tol, f"fused rmsnorm gemm {M}x{N}x{K} {act} vs fp32")
+    unf = eng.op_gemm(eng.op_rmsnorm(x, g, eps), W, bias=bias, act=a)
+    e_u = check(unf, ref, tol, f"unfused rmsnorm + gemm {M}x{N}x{K} {act} vs fp32")
+    assert e_f <= 1.5 * e_u + 1e-3, f"fused path is further from fp32 ({e_f:.3e}) than the unfused one ({e_u:.3e})"
+    if M <= 6000:
+        for cfg in (21, 22, 82):
+            assert torch.equal(got, eng.op_gemm_rows(x, Wf, bias=bias, act=a, rowscale=rs, tile_cfg=cfg)), f"row-scaled gemm differs bitwise on cfg {cfg}"
+
+
 def test_layernorm_rmsnorm(eng):
     for rows, cols in ((37, 64), (1154, 1024), (9, 4096)):
         x = _rand(f"ln{rows}", (rows, cols), 2.0) + 0.3

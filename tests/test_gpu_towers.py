@@ -80,6 +80,16 @@ def test_iv2(name, tol_g, tol_o):
     eng.debug_set("attn_pipe", 0)              # the plain tile loop (attn_fwd_kernel) instead of the pipelined one: bit-identical
     assert torch.equal(eng.iv2_encode(px.to(DEV)), got)
     eng.debug_set("attn_pipe", 1)
+    # round 5: `got` ran with the RMSNorms fused into the GEMMs around them (row statistics from the producing epilogue, norm weight folded into the
+    # consuming weight, row scale in its epilogue): two activation roundings of the reference are gone, gamma * W is rounded once per weight.  The
+    # separate norm pass (norm_fused = 0) is the arithmetic the oracle emulates; both are held to the reference golden and to each other.
+    eng.debug_set("norm_fused", 0)
+    unf = eng.iv2_encode(px.to(DEV))
+    eng.debug_set("norm_fused", 1)
+    print(f"[parity] {name}: fused vs unfused RMSNorm: {int((unf != got).sum())} of {got.numel()} values differ")
+    check(unf[:, ::st[0], ::st[1]], g["out"], tol_g, f"{name} (separate norm pass) vs reference golden (fp32)")
+    check(unf, ref, tol_o, f"{name} (separate norm pass) vs oracle (bf16 emulation)")
+    check(got, unf.float(), tol_o, f"{name}: fused RMSNorm vs the separate norm pass")
     eng.debug_set("patch_fused", 0)            # round 4: width 1408 runs the patch embedding as ONE kernel; the three-pass path sums in another order
     three = eng.iv2_encode(px.to(DEV))
     eng.debug_set("patch_fused", 1)

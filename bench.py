@@ -264,7 +264,10 @@ class Stepper:
         # InternVideo2 over `iv2_batch` clips per call (default: the whole step -- M = 197 k rows: the GEMM rounds fill better, -3.9 % tower time
         # against one call per clip, tools/iv2_batch_lab.py; the towers are bit-exactly batch-invariant, and ids_match_serial re-checks it)
         nb = max(1, min(self.iv2_batch, len(idx)))
-        vf = torch.cat([self.eng.iv2_encode(self.tp_pool[(idx[c]) * 12:(idx[min(c + nb, len(idx)) - 1] + 1) * 12]) for c in range(0, len(idx), nb)], 0) if nb > 1 else None
+        if nb >= len(idx):                                              # the whole step in ONE call: no torch.cat (of one tensor it is a 554 MB device copy)
+            vf = self.eng.iv2_encode(self.tp_pool[lo:hi])
+        else:
+            vf = torch.cat([self.eng.iv2_encode(self.tp_pool[(idx[c]) * 12:(idx[min(c + nb, len(idx)) - 1] + 1) * 12]) for c in range(0, len(idx), nb)], 0) if nb > 1 else None
         return self._exchange_multi([self.eng.build_visual(cf[c * 12:(c + 1) * 12], vf[c * 12:(c + 1) * 12] if vf is not None else self.eng.iv2_encode(self.px(i)[1]))
                                      for c, i in enumerate(idx)])
 
@@ -697,6 +700,9 @@ def main(argv=None, engine_factory=None):
         prog.enter(f"warmup step {w}")
         _, S = stepfn()
     barrier("before timed region")
+    mark = args.plain and hasattr(eng, "trace_marker") and D.gpu     # profiling runs: bracket the timed steps (tools/rocpd_stats.py --between gvl_trace_marker_kernel)
+    if mark:
+        eng.trace_marker(1); D.sync()
     t0 = time.perf_counter()
     out_timed = None
     for k in range(args.steps):
@@ -704,6 +710,8 @@ def main(argv=None, engine_factory=None):
         out_timed, S = stepfn()
     barrier("after timed region")   # synchronises every stream, incl. the vision encode launched by the last step
     dt = time.perf_counter() - t0
+    if mark:
+        eng.trace_marker(2); D.sync()
     if world > 1:
         prog.enter("all_reduce(MAX) of the step time")
         tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)

@@ -34,8 +34,10 @@ struct LlmLayerW { const bf16_t *ln1, *ln2, *qkvw, *ow, *guw, *downw;
 struct Seq {
   bool used = false; int max_tokens = 0, n_pages = 0; std::vector<int> pages;
   int* d_block_table = nullptr; int* d_pos = nullptr; int pos = 0; int n_gen = 0;
+  bool table_dirty = false;   // `pages` changed on the host (alloc / fork): the device table is rewritten, stream ordered, by the first prefill / decode that uses the sequence
   int* d_tok = nullptr;   // the sequence's latest greedy token (input of its next decode step)
-  int* d_out = nullptr;   // [outlist_cap] generated ids, index = generation step
+  int* d_out = nullptr;   // [outlist_cap] generated ids, index = generation step (device view of host-mapped memory)
+  const int* h_out = nullptr;   // the same list as the host sees it (valid for entries whose step's stream work has completed)
   int* d_ngen = nullptr;  // device copy of n_gen: where the next generated id goes (a decode step carries no host counters)
   unsigned rng_stream = 0;  // sampling: which random stream this sequence draws from (assigned at its prefill)
   int* d_eos = nullptr; volatile int* h_eos = nullptr;   // host-mapped word: generation count at which this sequence produced eos (0 = not yet)
@@ -86,6 +88,7 @@ struct gvl_ctx {
   const bf16_t *c_patchwt = nullptr, *v_patchwt = nullptr;   // null: the tower's geometry takes the three-pass patch embedding
   // (all decode work buffers hold GVL_MAX_DECODE_BATCH rows: one per sequence of a batched decode step)
   float *d_logits = nullptr, *d_part = nullptr; int* d_counters = nullptr; int *d_seq_tok = nullptr, *d_seq_out = nullptr;
+  int* h_seq_out = nullptr;          // d_seq_out is HOST-MAPPED memory (round 5): the selection kernels write the generated ids where the host reads them -- no read-back copy per call
   int nsplit = 16, outlist_cap = 8192, ids_cap = 16384;
   // frame pre-processing scratch (tmp image + tap tables), grown on demand
   void* pre_scratch = nullptr; size_t pre_scratch_bytes = 0;

@@ -98,6 +98,22 @@ int gvl_launch_rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int row
 }
 
 // =====================================================================================================
+// device -> device row copies of the step (packed prefill rows, the visual block of a splice, last-row gathers) as a kernel of this library on the
+// caller's stream: the step's trace then holds no runtime blit kernels, and the copy is an ordinary node under stream capture
+// =====================================================================================================
+__global__ __launch_bounds__(256) void copy16_kernel(const u32x4_t* __restrict__ src, u32x4_t* __restrict__ dst, long n16) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int gvl_launch_copy_bytes(const void* src, void* dst, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return 0;
+  if ((bytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : -3;   // odd sizes: the runtime's copy
+  const long n16 = (long)(bytes >> 4);
+  int blocks = (int)((n16 + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(256), 0, st, (const u32x4_t*)src, (u32x4_t*)dst, n16);
+  return CHECK_LAUNCH();
+}
+
+// =====================================================================================================
 // Fused RMSNorm (round 5), the two small kernels around the GEMM epilogues (GemmArgs.rowscale / rowsq):
 //   fold_gamma:    W'[n][k] = bf16(W[n][k] * gamma[k])   once, at gvl_finalize_weights -- the norm weight rides in the projection that consumes the norm
 //   rowsq_finish:  rs[m] = rsqrt((sum_b rowsq[m][b]) / cols + eps), blocks added in index order (fixed): M x nblk floats in, M floats out

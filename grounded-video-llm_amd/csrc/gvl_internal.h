@@ -213,6 +213,7 @@ int gvl_launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st);
 // ---- elementwise / norm / glue kernels (gvl_elem.hip) ----------------------------------------------
 int gvl_launch_layernorm_f32(const float* x, const float* w, const float* b, bf16_t* y, int rows, int cols, float eps, hipStream_t st);
 int gvl_launch_rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, float eps, hipStream_t st);
+int gvl_launch_copy_bytes(const void* src, void* dst, size_t bytes, hipStream_t st);   // device -> device, 16-byte vectors (falls back to hipMemcpyAsync for odd sizes)
 int gvl_launch_fold_gamma(const bf16_t* W, const bf16_t* gamma, bf16_t* Wo, long rows, int cols, hipStream_t st);   // W' = bf16(W diag(gamma)): fused RMSNorm, consumer weights
 int gvl_launch_rowsq_finish(const float* sq, int ld, int b0, int nblk, float* rs, int rows, int cols, float eps, hipStream_t st);   // partial sums of squares -> rsqrt(mean + eps)
 // im2col for a stride==kernel patch conv.  px f32 [n_img][3][T][HW][HW] (T==1 for CLIP) -> A bf16 [n_img*T*g*g][Kp]

@@ -312,6 +312,21 @@ int build_visual(gvl_ctx* ctx, const float* clip_feats, const bf16_t* iv2_feats,
 // page ids of a batch of equal-length sequences, passed by value to a stream-ordered fill (no host buffer lifetime)
 __global__ void fill_ints_kernel(int* dst, const IntList l) { for (int i = threadIdx.x; i < l.n; i += blockDim.x) dst[i] = l.v[i]; }
 
+// A sequence's page ids -> its device block table, by value in the kernel arguments (256 per launch) on the stream that is about to use the table:
+// no host -> device copy (the runtime implements small ones as a blit kernel plus a staging buffer) and no host buffer lifetime to respect.
+int upload_table(gvl_ctx* ctx, Seq& s, hipStream_t st) {
+  if (!s.table_dirty) return 0;
+  const int np = (int)s.pages.size();
+  for (int p0 = 0; p0 < np; p0 += 256) {
+    IntList l; l.n = np - p0 < 256 ? np - p0 : 256;
+    for (int i = 0; i < l.n; ++i) l.v[i] = s.pages[p0 + i];
+    hipLaunchKernelGGL(fill_ints_kernel, dim3(1), dim3(256), 0, st, s.d_block_table + p0, l);
+  }
+  if (hipGetLastError() != hipSuccess) return fail(ctx, GVL_ERR_HIP, "block table upload failed");
+  s.table_dirty = false;
+  return 0;
+}
+
 // The next token of every row of `am`: argmax (greedy), or one draw per row when gvl_set_sampling switched sampling on
 int pick_tokens(gvl_ctx* ctx, ArgmaxArgs& am, Seq* const* sqs, hipStream_t st) {
   if (!ctx->sample.on) return gvl_launch_argmax(am, st);
@@ -333,6 +348,7 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
   const int qkvw = (H + 2 * KV) * Dr;
   if (nb < 1 || nb > GVL_MAX_PREFILL_BATCH) return fail(ctx, GVL_ERR_ARG, "llm_prefill: batch must be 1 .. 8 sequences");
   if (pos0 != 0 && (nb != 1 || (pos0 & 63) || loss)) return fail(ctx, GVL_ERR_ARG, "llm_prefill: extend takes one sequence whose cached prefix is whole pages");
+  for (int b = 0; b < nb; ++b) { const int rc = upload_table(ctx, *sqs[b], st); if (rc) return rc; }
   int off[GVL_MAX_PREFILL_BATCH + 1]; off[0] = 0;
   bool uniform = true;
   for (int b = 0; b < nb; ++b) { off[b + 1] = off[b] + lens[b]; uniform = uniform && lens[b] == lens[0]; }
@@ -350,7 +366,7 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
     hipLaunchKernelGGL(fill_ints_kernel, dim3(1), dim3(256), 0, st, tb, l);
     table = tb; table_stride = P0;
   }
-  for (int b = 0; b < nb; ++b) HIPCHK(ctx, hipMemcpyAsync(x + (size_t)off[b] * Hd, embeds[b], (size_t)lens[b] * Hd * 2, hipMemcpyDeviceToDevice, st));
+  for (int b = 0; b < nb; ++b) RUN(GVL_PROF_OTHER, 0, gvl_launch_copy_bytes(embeds[b], x + (size_t)off[b] * Hd, (size_t)lens[b] * Hd * 2, st));
   // fused RMSNorm (see iv2_encode): o_proj / down_proj leave the row statistics of the new residual stream, qkv_proj / gate_up_proj consume the raw
   // stream with the norm weight folded in and scale their accumulator rows; layer 0's input norm keeps the pass
   const int NBLK = Hd / 64;
@@ -431,7 +447,7 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
   const bf16_t* last = x + (size_t)(S0 - 1) * Hd;
   int last_stride = S0 * Hd;
   if (n_att > 1) {                         // ragged: gather the nb last rows (h is free by now)
-    for (int b = 0; b < nb; ++b) HIPCHK(ctx, hipMemcpyAsync(h + (size_t)b * Hd, x + (size_t)(off[b + 1] - 1) * Hd, (size_t)Hd * 2, hipMemcpyDeviceToDevice, st));
+    for (int b = 0; b < nb; ++b) RUN(GVL_PROF_OTHER, 0, gvl_launch_copy_bytes(x + (size_t)(off[b + 1] - 1) * Hd, h + (size_t)b * Hd, (size_t)Hd * 2, st));
     last = h; last_stride = Hd;
   }
   for (int b0 = 0; b0 < nb;) {             // the GEMV holds 1, 2 or 4 vectors in LDS: chunks of 4 / 2 / 1 last rows (row results do not depend on the chunking)
@@ -462,6 +478,7 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
   const int qkvw = (H + 2 * KV) * Dr;
   const bool mfma = ctx->decode_mfma;
   if (mfma ? (B < 1 || B > GVL_MAX_DECODE_BATCH) : (B != 1 && B != 2 && B != 4)) return fail(ctx, GVL_ERR_ARG, "decode_step: unsupported batch");
+  for (int b = 0; b < B; ++b) { const int rc = upload_table(ctx, *sqs[b], st); if (rc) return rc; }   // (a no-op after the sequence's prefill; under capture it would be part of the graph -- never dirty there)
   TokPtrs tp; memset(&tp, 0, sizeof(tp)); tp.n = B; for (int b = 0; b < B; ++b) tp.p[b] = sqs[b]->d_tok;
   // RMSNorm in front of qkv / gate_up / lm_head: groups of <= 4 normalise inside the consumer (LDS, like the VALU kernel), larger
   // groups run one norm launch per projection whose output every block of the consumer shares (gvl_decode.hip header)
@@ -589,7 +606,7 @@ int decode_group(gvl_ctx* ctx, Seq* const* sqs, int B, int max_new, int eos_id, 
     // the tokens produced so far (the prefill's first token) were selected without a watch: look at them once, then arm the flags
     HIPCHK(ctx, hipStreamSynchronize(st));
     for (int b = 0; b < B; ++b) {
-      HIPCHK(ctx, hipMemcpy(out_ids[b], sqs[b]->d_out, (size_t)start_gen * 4, hipMemcpyDeviceToHost));
+      memcpy(out_ids[b], sqs[b]->h_out, (size_t)start_gen * 4);          // host-mapped list; the stream was synchronised above
       for (int i = 0; i < start_gen && !done[b]; ++i) if (out_ids[b][i] == eos_id) done[b] = true;
       *sqs[b]->h_eos = 0;
     }
@@ -634,7 +651,7 @@ int decode_group(gvl_ctx* ctx, Seq* const* sqs, int B, int max_new, int eos_id, 
   HIPCHK(ctx, hipStreamSynchronize(st));
   for (int b = 0; b < B; ++b) {
     const int n = sqs[b]->n_gen < max_new ? sqs[b]->n_gen : max_new;
-    HIPCHK(ctx, hipMemcpy(out_ids[b], sqs[b]->d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+    memcpy(out_ids[b], sqs[b]->h_out, (size_t)n * 4);
     int cut = n;
     if (eos_id >= 0) for (int i = 0; i < n; ++i) if (out_ids[b][i] == eos_id) { cut = i + 1; break; }
     *n_out[b] = cut;
@@ -739,7 +756,10 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
     ok &= hipMalloc((void**)&ctx->d_part, NB * f.heads * ctx->nsplit * (ctx->l_D + 2) * 4) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_counters, NB * f.heads * 4) == hipSuccess && hipMemset(ctx->d_counters, 0, NB * f.heads * 4) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_seq_tok, (size_t)gvl_ctx::kMaxSeqs * 4) == hipSuccess;
-    ok &= hipMalloc((void**)&ctx->d_seq_out, (size_t)gvl_ctx::kMaxSeqs * ctx->outlist_cap * 4) == hipSuccess;
+    // generated ids live in host-mapped memory: 4 bytes per token cross PCIe as they are produced, and gvl_decode_greedy* / gvl_seq_read read them after
+    // their stream sync without a device -> host copy (the step's trace holds no runtime blit kernel)
+    ok &= hipHostMalloc((void**)&ctx->h_seq_out, (size_t)gvl_ctx::kMaxSeqs * ctx->outlist_cap * 4, hipHostMallocMapped) == hipSuccess &&
+          hipHostGetDevicePointer((void**)&ctx->d_seq_out, ctx->h_seq_out, 0) == hipSuccess;
     ctx->seq_table_cap = (f.max_seq + 63) / 64;
     ok &= hipMalloc((void**)&ctx->d_seq_tables, (size_t)gvl_ctx::kMaxSeqs * ctx->seq_table_cap * 4) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_seq_pos, (size_t)gvl_ctx::kMaxSeqs * 4) == hipSuccess;
@@ -753,6 +773,7 @@ int gvl_destroy(gvl_ctx* ctx) {
   if (!ctx) return 0;
   hipDeviceSynchronize();
   if (ctx->h_eos_flags) hipHostFree(ctx->h_eos_flags);
+  if (ctx->h_seq_out) hipHostFree(ctx->h_seq_out);
   for (int i = 0; i < 3; ++i) if (ctx->step_ev[i]) hipEventDestroy(ctx->step_ev[i]);
   for (auto& kv : ctx->w) if (kv.second.p) hipFree(kv.second.p);
   for (void* p : ctx->dw_allocs) if (p) hipFree(p);
@@ -761,7 +782,7 @@ int gvl_destroy(gvl_ctx* ctx) {
   for (void* p : ctx->nf_allocs) if (p) hipFree(p);
   ctx->nf_allocs.clear();
   if (ctx->comm) gvl_comm_destroy(ctx);
-  void* ptrs[] = {ctx->d_xn, ctx->d_seq_ngen, ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_out, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
+  void* ptrs[] = {ctx->d_xn, ctx->d_seq_ngen, ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& r : ctx->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   delete ctx;
@@ -1001,7 +1022,7 @@ int gvl_splice(gvl_ctx* ctx, const int64_t* ids, int n_ids, const uint16_t* visu
   const int Hd = ctx->cfg.hidden, n_post = n_ids - 1 - idx;
   // ids travel by value in the kernel arguments: stream ordered, nothing shared between back-to-back splices
   RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_rows_host_ids(ctx->l_embed, text.data(), idx, embeds, Hd, st));
-  if (n_visual > 0) HIPCHK(ctx, hipMemcpyAsync(embeds + (size_t)idx * Hd, visual, (size_t)n_visual * Hd * 2, hipMemcpyDeviceToDevice, st));
+  if (n_visual > 0) RUN(GVL_PROF_OTHER, 0, gvl_launch_copy_bytes(visual, embeds + (size_t)idx * Hd, (size_t)n_visual * Hd * 2, st));
   RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_rows_host_ids(ctx->l_embed, text.data() + idx, n_post, embeds + (size_t)(idx + n_visual) * Hd, Hd, st));
   if (seq_len_out) *seq_len_out = n_ids - 1 + n_visual;
   return 0;
@@ -1028,10 +1049,10 @@ int gvl_seq_alloc(gvl_ctx* ctx, int max_tokens, int* seq_id) {
   s.d_block_table = ctx->d_seq_tables + (size_t)id * ctx->seq_table_cap;
   s.d_pos = ctx->d_seq_pos + id;
   s.d_tok = ctx->d_seq_tok + id;
-  s.d_out = ctx->d_seq_out + (size_t)id * ctx->outlist_cap;
+  s.d_out = ctx->d_seq_out + (size_t)id * ctx->outlist_cap; s.h_out = ctx->h_seq_out + (size_t)id * ctx->outlist_cap;
   s.d_ngen = ctx->d_seq_ngen + id;
   s.d_eos = ctx->d_eos_flags + id; s.h_eos = ctx->h_eos_flags + id;
-  HIPCHK(ctx, hipMemcpy(s.d_block_table, s.pages.data(), (size_t)np * 4, hipMemcpyHostToDevice));   // blocking; d_pos is set by gvl_prefill on ITS stream
+  s.table_dirty = true;                               // written by the first prefill / decode on ITS stream (upload_table); d_pos likewise
   *seq_id = id;
   return 0;
 }
@@ -1063,10 +1084,10 @@ int gvl_seq_fork(gvl_ctx* ctx, int src_seq, int n_tokens, int max_tokens, int* d
   s.d_block_table = ctx->d_seq_tables + (size_t)id * ctx->seq_table_cap;
   s.d_pos = ctx->d_seq_pos + id;
   s.d_tok = ctx->d_seq_tok + id;
-  s.d_out = ctx->d_seq_out + (size_t)id * ctx->outlist_cap;
+  s.d_out = ctx->d_seq_out + (size_t)id * ctx->outlist_cap; s.h_out = ctx->h_seq_out + (size_t)id * ctx->outlist_cap;
   s.d_ngen = ctx->d_seq_ngen + id;
   s.d_eos = ctx->d_eos_flags + id; s.h_eos = ctx->h_eos_flags + id;
-  HIPCHK(ctx, hipMemcpy(s.d_block_table, s.pages.data(), (size_t)np * 4, hipMemcpyHostToDevice));
+  s.table_dirty = true;
   *dst_seq = id;
   return 0;
 }
@@ -1108,12 +1129,12 @@ int gvl_seq_clone(gvl_ctx* ctx, int src_seq, int max_tokens, int* dst_seq, void*
   s.d_block_table = ctx->d_seq_tables + (size_t)id * ctx->seq_table_cap;
   s.d_pos = ctx->d_seq_pos + id;
   s.d_tok = ctx->d_seq_tok + id;
-  s.d_out = ctx->d_seq_out + (size_t)id * ctx->outlist_cap;
+  s.d_out = ctx->d_seq_out + (size_t)id * ctx->outlist_cap; s.h_out = ctx->h_seq_out + (size_t)id * ctx->outlist_cap;
   s.d_ngen = ctx->d_seq_ngen + id;
   s.d_eos = ctx->d_eos_flags + id; s.h_eos = ctx->h_eos_flags + id;
   hipStream_t st = (hipStream_t)stream;
-  HIPCHK(ctx, hipMemcpyAsync(s.d_block_table, s.pages.data(), (size_t)np * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(ctx, hipStreamSynchronize(st));            // s.pages (host) must outlive the copy; also orders the clone behind the source's pending steps on this stream
+  s.table_dirty = true;
+  { const int rc = upload_table(ctx, s, st); if (rc) return rc; }   // by value, on the clone's stream: ordered behind the source's pending steps there
   if (pos & 63)                                       // the partial last page is private: copy the source's (all layers, K and V^T)
     RUN(GVL_PROF_OTHER, 0, gvl_launch_kv_page_copy(ctx->kpool, ctx->vpool, ctx->layer_stride, (size_t)ctx->cfg.kv_heads * 64 * ctx->l_D, ctx->cfg.layers,
                                                    src_pages[shared], s.pages[shared], st));
@@ -1268,8 +1289,8 @@ int gvl_seq_read(gvl_ctx* ctx, int seq_id, int first, int32_t* out_ids, int cap,
   *n_gen = sq.n_gen;
   int n = sq.n_gen - first; if (n > cap) n = cap;
   if (n > 0) {
-    HIPCHK(ctx, hipMemcpyAsync(out_ids, sq.d_out + first, (size_t)n * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream));
+    memcpy(out_ids, sq.h_out + first, (size_t)n * 4);
   }
   return 0;
 }

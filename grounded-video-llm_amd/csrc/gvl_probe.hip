@@ -64,3 +64,12 @@ extern "C" int gvl_probe_mfma(int mode, int waves_per_simd, int iters, double* t
   if (ghz) *ghz = tsum / (blocks * 4) / (ms * 1e3) / 1e3;
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+// A named, do-nothing dispatch that brackets a region in a rocprofv3 --kernel-trace: tools/rocpd_stats.py --between gvl_trace_marker_kernel keeps only the
+// dispatches between the first and the last marker (bench.py --plain puts one in front of the first timed step and one behind the last on every stream
+// it uses), so that the step trace holds the step only -- no weight generation, no pool zeroing.
+__global__ void gvl_trace_marker_kernel(int tag, int* sink) { if (sink && threadIdx.x == 0 && tag == -1234567) *sink = tag; }
+extern "C" int gvl_trace_marker(int tag, void* stream) {
+  hipLaunchKernelGGL(gvl_trace_marker_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tag, (int*)nullptr);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -407,6 +407,11 @@ class Engine:
             self.seq_free(seq)
 
     # ---- measurement -----------------------------------------------------------------------------
+    def trace_marker(self, tag: int = 0, stream=None):
+        """gvl_trace_marker on `stream` (a torch stream; default: the current one): a named empty dispatch that brackets a region of a kernel trace."""
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else self.stream
+        self._chk(self.lib.gvl_trace_marker(int(tag), st), "gvl_trace_marker")
+
     def prof_enable(self, on: bool):
         self._chk(self.lib.gvl_prof_enable(self.ctx, 1 if on else 0), "gvl_prof_enable")
 

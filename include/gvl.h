@@ -329,6 +329,8 @@ int gvl_op_decode_bench(gvl_ctx* ctx, int N, int K, int batch, int mode, int var
  * v_mfma_f32_32x32x16_bf16 -- mode 0 zero / 1 constant / 2 random operands -- and reports TFLOP/s and s_memtime ticks per ns of wall
  * time: the ceiling the power envelope leaves a PERFECT bf16 GEMM at a given switching activity.  Needs no ctx. */
 int gvl_probe_mfma(int mode, int waves_per_simd, int iters, double* tflops, double* ghz, void* stream);
+/* One named do-nothing dispatch (gvl_trace_marker_kernel) on `stream`: brackets a region of a rocprofv3 --kernel-trace (tools/rocpd_stats.py --between). */
+int gvl_trace_marker(int tag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -155,7 +155,8 @@ def _full_depth_vs_reference_golden(llama, name):
     print(f"[parity] {name} Llama-3-8B 32 L, S={S}: the reference's own bf16 evaluation is {ref_bf:.3e} from its fp32 logits (scale {scale:.3f}); bound {tol:.2e}")
     print(f"[parity] {name} logits, prefill row + teacher-forced decode rows (every {step}; of the logit scale):", " ".join(f"{e:.2e}" for e in errs))
     assert max(errs) <= tol
-    noise_class(torch.stack([r[::ls].cpu() for r in rows]), g["logits_rows"], g["logits_rows_bf16ref"], f"{name} Llama-3-8B 32 L logits, S={S}, {len(rows)} rows")
+    # fp32-PREFIX yardstick of rounds 2-4 (the reference's LLM in bf16 on its own fp32 prefix: not like for like, wider RMS cap); binding: like_for_like() below
+    noise_class(torch.stack([r[::ls].cpu() for r in rows]), g["logits_rows"], g["logits_rows_bf16ref"], f"{name} Llama-3-8B 32 L logits, S={S}, {len(rows)} rows", rms_cap=1.20)
     like_for_like(torch.stack([r[::ls].cpu() for r in rows]), name[:2], f"{name[:2].upper()}  Llama-3-8B, {8 * n_segs} frames, S={S} (end to end)")
     margins = np.asarray(g["top1"]) - np.asarray(g["top2"])
     for i, r in enumerate(rows):

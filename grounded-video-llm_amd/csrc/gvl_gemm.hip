@@ -884,6 +884,9 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     //  * cfg 21 = 128x128, 2 blocks / CU: short K or few tiles (CLIP out / fc2: 112 tiles).
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     cfg = (a.K >= 1024 && t256 >= 128) ? 82 : 21;   // CLIP qkv / fc1 (K = 1024, 336 / 448 tiles): 82 measured +8...17 % over 21
+    // short K but thousands of tiles (the three-pass patch GEMM at the bench's M: K = 640, 864 / 4 608 tiles): 82 measured 76.6 vs 83.2 us (CLIP) and 454.6 vs
+    // 477.7 us (InternVideo2, bias) -- profiles/r05_patch_gemm_floor.txt
+    if (cfg == 21 && a.K >= 512 && t256 >= 512) cfg = 82;
   }
   if ((cfg == 82 || cfg == 85) && ((size_t)a.N * a.ldw * 2 >= (1ull << 32) || (size_t)a.M * a.lda * 2 >= (1ull << 32))) cfg = 21;   // 32-bit DMA offsets
   const int epi = (a.act & 3) | ((a.out_f32 ? 1 : 0) << 2) | ((a.resid ? 1 : 0) << 3) | ((a.gamma ? 1 : 0) << 4) | ((a.bias ? 1 : 0) << 5) |

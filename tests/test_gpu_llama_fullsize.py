@@ -124,7 +124,7 @@ def _full_depth_vs_reference_golden(llama, name):
     bf16 evaluation stored in the golden) on the max-abs error, 1.15 x on the RMS error (gpu_util.noise_class)."""
     import numpy as np
     from conftest import load_golden
-    from gpu_util import BF16_CLASS_CAP, check, like_for_like, noise_class
+    from gpu_util import E2E_FP32PREFIX_CAP, check, like_for_like, noise_class
     eng, geo = llama
     meta, g = load_golden(name)
     sd, st = meta["seeds"], meta["stride"]
@@ -141,7 +141,7 @@ def _full_depth_vs_reference_golden(llama, name):
     assert emb.shape[0] == S
     scale = float(np.abs(g["logits_rows"]).max())
     ref_bf = float(np.abs(g["logits_rows_bf16ref"] - g["logits_rows"]).max()) / scale
-    tol = max(1e-2, BF16_CLASS_CAP * ref_bf)
+    tol = max(1e-2, E2E_FP32PREFIX_CAP * ref_bf)
     ls = st["logits"]
     seq = eng.seq_alloc(S + len(meta["forced"]) + 8)
     rows = [eng.prefill(seq, emb, want_logits=True).clone()]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-N profiling passes on the GPU box (run through gpurun): kernel traces of the default and the serial bench, the two PMC
 # traffic passes, MFMA-utilisation counters per GEMM shape.  Outputs under gpurun_out/prof_$1/ ; summaries are copied to profiles/ by hand.
-R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r04}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r05}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 WHAT=${2:-all}
 db() { find "$1" -name "*.db" | head -1; }
@@ -12,8 +12,10 @@ if [[ $WHAT == all || $WHAT == trace ]]; then
   python $R/tools/rocpd_stats.py "$(db $OUT/serial)" $OUT/${TAG}_bench_kernel_stats_serial.txt > /dev/null
   # the launches of the TIMED step (8 clips: batched CLIP / InternVideo2 / ragged prefill / decode) serialised on one stream: 3 steps = 24 clips.
   # `roofline.gemm_ms_per_clip` of the bench line must equal (sum of the gemm_* rows) / 24 of this table.
-  rocprofv3 --kernel-trace -d $OUT/serial_step -- python $R/bench.py --plain --mode serial_step --steps 2 --warmup 1 > $OUT/serial_step.log 2>&1
-  python $R/tools/rocpd_stats.py "$(db $OUT/serial_step)" $OUT/${TAG}_bench_kernel_stats_serial_step.txt > /dev/null
+  rocprofv3 --kernel-trace -d $OUT/serial_step -- python $R/bench.py --plain --mode serial_step --steps 3 --warmup 1 > $OUT/serial_step.log 2>&1
+  # round 5: the table holds the TIMED steps only (3 steps = 24 clips between the two gvl_trace_marker_kernel dispatches bench.py --plain places): no weight
+  # generation, no pool zeroing, and the header counts the at::native / rocclr dispatches inside the window (0)
+  python $R/tools/rocpd_stats.py "$(db $OUT/serial_step)" $OUT/${TAG}_bench_kernel_stats_serial_step.txt --between gvl_trace_marker_kernel > /dev/null
 fi
 if [[ $WHAT == all || $WHAT == pmc ]]; then
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- python $R/bench.py --plain --mode serial_step --steps 1 --warmup 1 > $OUT/fetch.log 2>&1

@@ -99,7 +99,7 @@ def test_c0_encode_images_splice_prefill_greedy(c0):
     assert max(errs) <= tol
     # (fp32-PREFIX yardstick, kept from rounds 2-4: the reference's LLM in bf16 on its own fp32 visual prefix -- one error source fewer than ANY end-to-end bf16 path,
     #  the reference's included; not like for like, hence the wider RMS cap.  The binding statement is like_for_like() below.)
-    noise_class(torch.stack([r[::ls].cpu() for r in rows_c0]), g["logits_steps"], g["logits_steps_bf16ref"], "C0 Phi-3.5 32 L logits, prefill row + 11 teacher-forced decode rows", rms_cap=1.20)
+    noise_class(torch.stack([r[::ls].cpu() for r in rows_c0]), g["logits_steps"], g["logits_steps_bf16ref"], "C0 Phi-3.5 32 L logits, prefill row + 11 teacher-forced decode rows", cap=E2E_FP32PREFIX_CAP, rms_cap=1.20)
     # round 5, the like-for-like statement: the reference evaluated the way its GPU path runs (bf16 vision prefix feeding the bf16 LLM), caps 1.15 / 1.10
     like_for_like(torch.stack([r[::ls].cpu() for r in rows_c0]), "c0", "C0  Phi-3.5, 8 frames, S=384 (end to end)")
     # ---- free-running greedy: same ids as the reference wherever its top-1 margin exceeds the logit tolerance
@@ -179,7 +179,7 @@ def test_c1_headline_config_96_frames_vs_reference_golden(c0):
     print(f"[parity] C1 Phi-3.5 32 L, S={S}: the reference's own bf16 evaluation is {ref_bf:.3e} from its fp32 logits (scale {scale:.3f}); bound {tol:.2e}")
     print("[parity] C1 logits, prefill row + 11 teacher-forced decode rows (of the logit scale):", " ".join(f"{e:.2e}" for e in errs))
     assert max(errs) <= tol
-    noise_class(torch.stack([r[::ls].cpu() for r in rows]), g["logits_rows"], g["logits_rows_bf16ref"], f"C1 Phi-3.5 32 L logits, S={S}, prefill row + 11 decode rows", rms_cap=1.20)   # fp32-prefix yardstick (see C0)
+    noise_class(torch.stack([r[::ls].cpu() for r in rows]), g["logits_rows"], g["logits_rows_bf16ref"], f"C1 Phi-3.5 32 L logits, S={S}, prefill row + 11 decode rows", cap=E2E_FP32PREFIX_CAP, rms_cap=1.20)   # fp32-prefix yardstick (see C0)
     like_for_like(torch.stack([r[::ls].cpu() for r in rows]), "c1", "C1  Phi-3.5, 96 frames, S=3519 (end to end; the headline configuration)")
     margins = np.asarray(g["top1"]) - np.asarray(g["top2"])
     for i, r in enumerate(rows):

@@ -156,7 +156,7 @@ def _full_depth_vs_reference_golden(llama, name):
     print(f"[parity] {name} logits, prefill row + teacher-forced decode rows (every {step}; of the logit scale):", " ".join(f"{e:.2e}" for e in errs))
     assert max(errs) <= tol
     # fp32-PREFIX yardstick of rounds 2-4 (the reference's LLM in bf16 on its own fp32 prefix: not like for like, wider RMS cap); binding: like_for_like() below
-    noise_class(torch.stack([r[::ls].cpu() for r in rows]), g["logits_rows"], g["logits_rows_bf16ref"], f"{name} Llama-3-8B 32 L logits, S={S}, {len(rows)} rows", rms_cap=1.20)
+    noise_class(torch.stack([r[::ls].cpu() for r in rows]), g["logits_rows"], g["logits_rows_bf16ref"], f"{name} Llama-3-8B 32 L logits, S={S}, {len(rows)} rows", cap=E2E_FP32PREFIX_CAP, rms_cap=1.20)
     like_for_like(torch.stack([r[::ls].cpu() for r in rows]), name[:2], f"{name[:2].upper()}  Llama-3-8B, {8 * n_segs} frames, S={S} (end to end)")
     margins = np.asarray(g["top1"]) - np.asarray(g["top2"])
     for i, r in enumerate(rows):

@@ -672,3 +672,32 @@ def test_beam_search_bookkeeping_equals_hf_generate():
             assert got == ref, (seed, k, eos, mx, lp, got, ref)
             n_eos_hits += int(eos is not None and eos in got)
     assert n_eos_hits >= 1, "no case ended by eos: the hypothesis bookkeeping was not exercised"
+
+
+def test_step_only_trace_window(tmp_path):
+    """tools/rocpd_stats.py --between ("trace the step alone"): only dispatches that start between the first and the last marker kernel
+    are summarised, the markers themselves are left out, and the header counts foreign (at::native / rocclr) dispatches inside the window."""
+    import sqlite3
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import rocpd_stats
+    db = str(tmp_path / "t.db")
+    con = sqlite3.connect(db)
+    con.execute("create table kernels (name text, start integer, end integer)")
+    rows = [("void at::native::fill<float>(...)", 0, 50_000), ("__amd_rocclr_fillBufferAligned", 60_000, 90_000),         # set-up: before the first marker
+            ("gvl_trace_marker_kernel(int, int*)", 100_000, 101_000),
+            ("void gemm_pp_kernel<256, 256, 64, 1>(GemmArgs, int, int)", 110_000, 1_110_000), ("attn_iv2_pipe_kernel<4>(AttnArgs)", 1_200_000, 1_700_000),
+            ("void gemm_pp_kernel<256, 256, 64, 1>(GemmArgs, int, int)", 1_800_000, 2_800_000), ("__amd_rocclr_copyBuffer", 2_850_000, 2_860_000),
+            ("gvl_trace_marker_kernel(int, int*)", 3_000_000, 3_001_000),
+            ("void at::native::sum(...)", 3_100_000, 3_200_000)]                                                                  # extras: behind the last marker
+    con.executemany("insert into kernels values (?, ?, ?)", rows)
+    con.commit(); con.close()
+    out = str(tmp_path / "o.txt")
+    rocpd_stats.main(db, out, "gvl_trace_marker_kernel")
+    txt = open(out).read()
+    assert "over 4 dispatches" in txt and "total kernel time 2.510 ms" in txt
+    assert "inside the window: 1" in txt                                  # the one blit kernel between the markers
+    assert "at::native" not in txt.split("\n", 4)[4] and "gvl_trace_marker" not in txt.split("\n", 4)[4]
+    gemm = [l for l in txt.splitlines() if l.startswith("void gemm_pp_kernel")][0].split()
+    assert gemm[-6] == "2" and gemm[-5] == "2.000"                        # calls, total ms
+    rocpd_stats.main(db, out)                                             # without the window: everything
+    assert "over 9 dispatches" in open(out).read()

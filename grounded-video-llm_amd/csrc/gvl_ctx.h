@@ -28,6 +28,7 @@ struct Iv2BlockW { const bf16_t *n1, *n2, *qkvw, *qn, *kn, *projw, *fc1w, *fc2w;
                    const bf16_t *qkvw_f = nullptr, *fc1w_f = nullptr; };   // fused RMSNorm: qkv.w diag(n1), fc1.w diag(n2) (gvl_launch_fold_gamma at finalize)
 struct LlmLayerW { const bf16_t *ln1, *ln2, *qkvw, *ow, *guw, *downw;
                    const bf16_t *qkvw_f = nullptr, *guw_f = nullptr;   // fused RMSNorm (prefill): qkv.w diag(ln1), gate_up.w diag(ln2)
+                   const bf16_t *qkvd_f = nullptr, *gud_f = nullptr;   // ... and their decode tile copies (bf16 decode weights only)
                    const bf16_t *qkvd, *od, *gud, *downd;      // decode copies in MFMA tile order (gvl_decode.hip; bf16, or FP8 e4m3 when cfg.decode_fp8); null on the VALU fallback
                    const float *qkvs, *os, *gus, *downs; };    // FP8 variant: per-row power-of-two scales
 
@@ -80,6 +81,9 @@ struct gvl_ctx {
   int* d_seq_ngen = nullptr;         // [kMaxSeqs]
   bool decode_mfma = false;          // geometry allows the skinny MFMA GEMM decode path (K % 256 == 0 for every projection)
   const bf16_t* l_headd = nullptr;   // lm_head in tile order
+  const bf16_t* l_headd_f = nullptr; // lm_head diag(final norm weight) in tile order: fused RMSNorm on the decode path
+  bf16_t* d_xt = nullptr;            // the decode step's residual rows a second time, raw, in B-operand tile order (written by o_proj / down_proj)
+  float* d_sqpart = nullptr;         // [GVL_MAX_DECODE_BATCH][hidden / 16] partial sums of squares of those rows
   const float* l_heads = nullptr;    // its FP8 row scales
   int fp8 = 0;                       // format of the decode copies: 0 bf16, 1 FP8 e4m3 + row scales, 2 MXFP4 (cfg.decode_fp8 and the geometry allows it)
   std::vector<void*> dw_allocs;      // tile-order weight copies owned by the ctx

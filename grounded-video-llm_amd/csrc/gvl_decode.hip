@@ -210,6 +210,18 @@ __global__ __launch_bounds__(NW * 64, U >= 8 ? 2 : 4) void dgemm_kernel(const Ge
   const int groups = steps / U;
   if (groups > 0) request_w(0, 0);               // the first weight tiles do not depend on the activations: in flight during the norm
                                                  // (requesting the second buffer's tiles here as well: measured +-0)
+  // fused RMSNorm, consumer side: the epilogue waves add up their sequence's partial sums of squares (written by the projection that produced the
+  // residual rows) behind the first weight requests -- lane (g, i) takes a quarter of sequence i's sq_n partials in index order, the four quarters meet
+  // as (q0 + q1) + (q2 + q3): a fixed order that involves sequence i alone
+  // EVERY wave takes a slice: lane (g, i) of wave w adds the sq_n / (4 NW) partials [(4 w + g) per, (4 w + g + 1) per) of sequence i in index order -- a
+  // handful of L2-resident loads that are consumed only at the block's closing reduction, where the epilogue wave adds the 4 NW slice sums in a fixed order
+  // (doing all of it in the epilogue wave up front cost -5 % tok/s at one sequence: 48 loads ahead of its main loop)
+  float sq_mine = 0.f;
+  if (a.sq_in) {
+    const int b_ = i < a.batch ? i : a.batch - 1, per = a.sq_n / (4 * NW);
+    const float* sp_ = a.sq_in + (size_t)b_ * a.sq_n + (4 * wave + g) * per;
+    for (int j = 0; j < per; ++j) sq_mine += sp_[j];
+  }
   if constexpr (XN) {
     // every wave normalises ITS k slice of the (<= 4) residual rows into LDS, B-operand order [step][chunk][batch][8]: element (b, k)
     // at (((k >> 5) * 4 + ((k >> 3) & 3)) * batch + b) * 8 + (k & 7).  Only the 8 slice sums cross waves (one barrier); a wave
@@ -270,8 +282,17 @@ __global__ __launch_bounds__(NW * 64, U >= 8 ? 2 : 4) void dgemm_kernel(const Ge
   // partial sums of the 8 k-slices meet in LDS; wave rb (< RB) adds them in a fixed order and runs that row block's epilogue
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) *(f32x4v_t*)red[wave][rb][lane] = acc[rb];
+  __shared__ float sqred[NW][64];
+  if (a.sq_in) sqred[wave][lane] = sq_mine;
   __syncthreads();
   if (wave < RB) {
+    float rs_col = 1.f;
+    if (a.sq_in) {                                  // slice sums of this lane's sequence i: waves in order, the four g of a wave as (g0 + g1) + (g2 + g3)
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tot += (sqred[w][i] + sqred[w][16 + i]) + (sqred[w][32 + i] + sqred[w][48 + i]);
+      rs_col = rsqrtf(tot / (float)a.K + a.eps);
+    }
     const int rb = wave;
     float v[4];
     {
@@ -285,6 +306,10 @@ __global__ __launch_bounds__(NW * 64, U >= 8 ? 2 : 4) void dgemm_kernel(const Ge
       const int n4 = n0 + rb * 16 + g * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] *= a.wscale[n4 + r < a.N ? n4 + r : a.N - 1];
+    }
+    if (a.sq_in) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= rs_col;   // the RMS factor of this lane's sequence: the weight carries the norm weight, x came in raw
     }
     const int b = i;                             // this lane's sequence
     const int nr = n0 + rb * 16 + g * 4;         // its 4 consecutive logical rows nr .. nr + 3
@@ -339,9 +364,17 @@ __global__ __launch_bounds__(NW * 64, U >= 8 ? 2 : 4) void dgemm_kernel(const Ge
             v[0] = lo_bf(rv[0]) + rbf(v[0]); v[1] = hi_bf(rv[0]) + rbf(v[1]); v[2] = lo_bf(rv[1]) + rbf(v[2]); v[3] = hi_bf(rv[1]) + rbf(v[3]);
           }
           if (a.out_bf16) {
-            const unsigned long long o = (unsigned long long)pack2bf(v[0], v[1]) | ((unsigned long long)pack2bf(v[2], v[3]) << 32);
+            const unsigned p01 = pack2bf(v[0], v[1]), p23 = pack2bf(v[2], v[3]);
+            const unsigned long long o = (unsigned long long)p01 | ((unsigned long long)p23 << 32);
             unsigned long long* dst = (unsigned long long*)(a.out_bf16 + (size_t)b * a.out_stride + nr);
             *dst = o;
+            if (a.out_tiled2) *(unsigned long long*)(a.out_tiled2 + gvl_xt_index(b, nr)) = o;   // 4 consecutive k of one sequence: 8 contiguous bytes of the tile
+            if (a.sq_out) {                      // fused RMSNorm, producer side: sum of squares of the ROUNDED outputs of this 16-row block, per sequence
+              float ss = lo_bf(p01) * lo_bf(p01);
+              ss += hi_bf(p01) * hi_bf(p01); ss += lo_bf(p23) * lo_bf(p23); ss += hi_bf(p23) * hi_bf(p23);
+              const float q0 = __shfl(ss, i, 64), q1 = __shfl(ss, 16 + i, 64), q2 = __shfl(ss, 32 + i, 64), q3 = __shfl(ss, 48 + i, 64);   // the 4 lanes of sequence i
+              if (g == 0) a.sq_out[(size_t)b * (a.N >> 4) + (blockIdx.x * RB + rb)] = (q0 + q1) + (q2 + q3);
+            }
           }
           if (a.out_f32) *(f32x4v_t*)(a.out_f32 + (size_t)b * a.out_stride + nr) = f32x4v_t{v[0], v[1], v[2], v[3]};
         } else {
@@ -372,6 +405,8 @@ int gvl_launch_dgemm(const GemvArgs& a_in, hipStream_t st) {
   if (a.out_tiled && a.act != GVL_ACT_SILU_MUL) return -1;
   if (a.norm_w && (a.batch > GVL_MAX_VALU_BATCH || a.K > 4096 || (a.batch > 1 && a.x_stride % 4))) return -1;
   if (a.rope_on && ((a.Dr & 1) || (a.N & 3))) return -1;
+  if (a.sq_in && (a.norm_w || a.w_fp8 || a.sq_n <= 0 || (a.sq_n & 31))) return -1;                // fused RMSNorm: raw tiled x, folded bf16 weights, 4 x NW (<= 32) equal slices
+  if ((a.sq_out || a.out_tiled2) && ((a.N & 15) || !a.out_bf16 || a.act == GVL_ACT_SILU_MUL || a.rope_on)) return -1;
   if (a.act == GVL_ACT_SILU_MUL && (a.N & 3)) return -1;
   // variant (experiments: GVL_DGEMM_VARIANT = rb*1000 + nw*100 + u*10 + nt; 0 = the measured default)
   static const int env_variant = [] { const char* e = gvl_lab_env("GVL_DGEMM_VARIANT"); return e ? atoi(e) : 0; }();

@@ -291,6 +291,14 @@ struct GemvArgs {
   int w_fp8; const float* wscale; // skinny-GEMM path: 1 = W is the FP8 tile copy, wscale[N] its per-row power-of-two scales; 2 = the MXFP4 tile
                                   // copy, wscale = its E8M0 scale words (gvl_mxfp4_quantise_decode_weight)
   int out_tiled;                  // skinny-GEMM path: the SwiGLU epilogue writes out_bf16 in B-operand tile order (it feeds down_proj)
+  // Fused RMSNorm on the decode path (round 5; skinny-GEMM path, bf16 weights): rmsnorm(x) W^T = rs[b] * (x (W diag gamma)^T) per sequence b.
+  //   PRODUCER (o_proj / down_proj, the residual epilogue; N % 16 == 0): sq_out[b * (N / 16) + block] = sum of squares of the 16 bf16 outputs of that row
+  //   block for sequence b, and out_tiled2 = a second copy of the new residual rows in B-operand tile order (the next projection's x);
+  //   CONSUMER (qkv_proj / gate_up_proj / lm_head; W = the tile copy of the norm-FOLDED weight, x = that raw tiled stream): sq_in[b * sq_n + j], j < sq_n,
+  //   are summed in a fixed order by the epilogue waves while the first weight tiles are in flight; the accumulators are scaled by rsqrt(sum / K + eps).
+  // A sequence's sums and scale depend on its own column only: batched decode == single decode still holds bit for bit.
+  const float* sq_in; int sq_n;
+  float* sq_out; bf16_t* out_tiled2;
 };
 // B-operand tile order of the decode activations: element (sequence j < 16, column k) of a [16][cols] matrix lives at
 // [k / 32][lane = 16 * ((k / 8) % 4) + j][k % 8] -- one k step of the MFMA is 1 KiB of consecutive addresses

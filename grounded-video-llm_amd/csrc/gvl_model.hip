@@ -520,11 +520,19 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
   auto normed_input = [&](GemvArgs& g, const bf16_t* w) {       // the projection reads rmsnorm(d_x) * w
     if (fused_norm) { g.x = ctx->d_x; g.norm_w = w; g.eps = f.rms_eps; } else g.x = ctx->d_xn;
   };
+  // Fused RMSNorm on the decode path (round 5; GemvArgs.sq_*): o_proj / down_proj leave per-sequence partial sums of squares of the new residual rows and a
+  // raw tile-order copy of them; qkv_proj (layers >= 1), gate_up_proj and lm_head run on that raw copy with the norm weight folded into their (tile-order)
+  // weights and scale their accumulators per sequence.  No norm launch (groups > 4: two per layer) and no in-block normalisation (groups <= 4) any more;
+  // layer 0's input norm (no producer projection) keeps the old path.  bf16 decode weights only.
+  const int nblk = Hd >> 4;
+  const bool rs = mfma && !ctx->fp8 && ctx->dbg.norm_fused && ctx->l_headd_f && Hd % 64 == 0 && (nblk & 31) == 0;
+  auto rs_input = [&](GemvArgs& g) { g.x = ctx->d_xt; g.sq_in = ctx->d_sqpart; g.sq_n = nblk; g.eps = f.rms_eps; };
+  auto rs_output = [&](GemvArgs& g) { if (rs) { g.sq_out = ctx->d_sqpart; g.out_tiled2 = ctx->d_xt; } };
   for (int l = 0; l < f.layers; ++l) {
     const LlmLayerW& w = ctx->ll[l];
     bf16_t* Kt = ctx->kpool + (size_t)l * ctx->layer_stride; bf16_t* Vt = ctx->vpool + (size_t)l * ctx->layer_stride;
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? w.qkvd : w.qkvw; g.N = qkvw; g.K = Hd; g.batch = B; g.x_stride = Hd;
-      normed_input(g, w.ln1);
+      if (rs && l > 0) { g.W = w.qkvd_f; rs_input(g); } else normed_input(g, w.ln1);
       // fused epilogue: RoPE + Q write + paged-KV append (replaces a separate qkv_post launch per layer per token)
       g.rope_on = 1; g.cos_s = ctx->cos_s; g.sin_s = ctx->sin_s; g.cos_l = ctx->cos_l; g.sin_l = ctx->sin_l;
       g.rope_switch = ctx->cos_l ? f.rope_orig_max_pos : 0;
@@ -537,22 +545,22 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
       a.out = ctx->d_attn; a.out_stride = H * Dr; a.out_tiled = mfma ? 1 : 0; a.H = H; a.KV = KV; a.D = D; a.Dout = Dr; a.nsplit = ctx->nsplit; a.scale = 1.0f / sqrtf((float)Dr);
       RUN(GVL_PROF_DECODE_ATTN, 4.0 * ctx_tokens * (double)KV * D, gvl_launch_decode_attention(a, st)); }
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? w.od : w.ow; g.N = Hd; g.K = H * Dr; g.x = ctx->d_attn; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
-      g.batch = B; g.x_stride = H * Dr; g.out_stride = Hd;
+      g.batch = B; g.x_stride = H * Dr; g.out_stride = Hd; rs_output(g);
       RUN(GVL_PROF_GEMV, 2.0 * Hd * H * Dr, proj(g, w.os)); }
-    if (!fused_norm) RUN(GVL_PROF_OTHER, 0, gvl_launch_norm_tiled(ctx->d_x, ctx->d_xn, w.ln2, B, Hd, f.rms_eps, st));     // post_attention_layernorm
+    if (!fused_norm && !rs) RUN(GVL_PROF_OTHER, 0, gvl_launch_norm_tiled(ctx->d_x, ctx->d_xn, w.ln2, B, Hd, f.rms_eps, st));     // post_attention_layernorm
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? w.gud : w.guw; g.N = 2 * I; g.K = Hd; g.act = GVL_ACT_SILU_MUL; g.out_bf16 = ctx->d_act;
       g.batch = B; g.x_stride = Hd; g.out_stride = I; g.out_tiled = mfma ? 1 : 0;
-      normed_input(g, w.ln2);
+      if (rs) { g.W = w.gud_f; rs_input(g); } else normed_input(g, w.ln2);
       RUN(GVL_PROF_GEMV, 4.0 * I * Hd, proj(g, w.gus)); }
     { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? w.downd : w.downw; g.N = Hd; g.K = I; g.x = ctx->d_act; g.resid = ctx->d_x; g.out_bf16 = ctx->d_x;
-      g.batch = B; g.x_stride = I; g.out_stride = Hd;
+      g.batch = B; g.x_stride = I; g.out_stride = Hd; rs_output(g);
       RUN(GVL_PROF_GEMV, 2.0 * Hd * I, proj(g, w.downs)); }
-    if (!fused_norm)   // the next layer's input_layernorm, or the final norm in front of lm_head
+    if (!fused_norm && !rs)   // the next layer's input_layernorm, or the final norm in front of lm_head
       RUN(GVL_PROF_OTHER, 0, gvl_launch_norm_tiled(ctx->d_x, ctx->d_xn, l + 1 < f.layers ? ctx->ll[l + 1].ln1 : ctx->l_norm, B, Hd, f.rms_eps, st));
   }
   { GemvArgs g; memset(&g, 0, sizeof(g)); g.W = mfma ? ctx->l_headd : ctx->l_headw; g.N = f.vocab; g.K = Hd; g.bias = ctx->l_headb;
     g.batch = B; g.x_stride = Hd; g.out_stride = f.vocab;
-    normed_input(g, ctx->l_norm);
+    if (rs) { g.W = ctx->l_headd_f; rs_input(g); } else normed_input(g, ctx->l_norm);
     g.out_f32 = ctx->d_logits; RUN(GVL_PROF_GEMV, 2.0 * f.vocab * Hd, proj(g, ctx->l_heads)); }
   { ArgmaxArgs am; memset(&am, 0, sizeof(am)); am.logits = ctx->d_logits; am.n = f.vocab; am.batch = B;   // token, output list, n_gen++ and pos++ on the device
     for (int b = 0; b < B; ++b) { am.tok_ptrs[b] = sqs[b]->d_tok; am.out_lists[b] = sqs[b]->d_out; am.ngen_ptrs[b] = sqs[b]->d_ngen; am.pos_ptrs[b] = sqs[b]->d_pos; }
@@ -755,6 +763,8 @@ int gvl_create(const gvl_config* cfg, gvl_ctx** out) {
     ok &= hipMalloc((void**)&ctx->d_logits, NB * f.vocab * 4) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_part, NB * f.heads * ctx->nsplit * (ctx->l_D + 2) * 4) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_counters, NB * f.heads * 4) == hipSuccess && hipMemset(ctx->d_counters, 0, NB * f.heads * 4) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_xt, NB * f.hidden * 2) == hipSuccess && hipMemset(ctx->d_xt, 0, NB * f.hidden * 2) == hipSuccess;
+    ok &= hipMalloc((void**)&ctx->d_sqpart, NB * ((f.hidden + 15) / 16) * 4) == hipSuccess && hipMemset(ctx->d_sqpart, 0, NB * ((f.hidden + 15) / 16) * 4) == hipSuccess;
     ok &= hipMalloc((void**)&ctx->d_seq_tok, (size_t)gvl_ctx::kMaxSeqs * 4) == hipSuccess;
     // generated ids live in host-mapped memory: 4 bytes per token cross PCIe as they are produced, and gvl_decode_greedy* / gvl_seq_read read them after
     // their stream sync without a device -> host copy (the step's trace holds no runtime blit kernel)
@@ -782,7 +792,7 @@ int gvl_destroy(gvl_ctx* ctx) {
   for (void* p : ctx->nf_allocs) if (p) hipFree(p);
   ctx->nf_allocs.clear();
   if (ctx->comm) gvl_comm_destroy(ctx);
-  void* ptrs[] = {ctx->d_xn, ctx->d_seq_ngen, ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_seq_tok, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
+  void* ptrs[] = {ctx->d_xn, ctx->d_seq_ngen, ctx->arena, ctx->arena_l, ctx->kpool, ctx->vpool, ctx->d_x, ctx->d_qkv, ctx->d_q, ctx->d_attn, ctx->d_act, ctx->d_logits, ctx->d_part, ctx->d_counters, ctx->d_xt, ctx->d_sqpart, ctx->d_seq_tok, ctx->d_seq_tables, ctx->d_seq_pos, ctx->pre_scratch};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& r : ctx->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   delete ctx;
@@ -952,13 +962,37 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
     }
     // norm-folded prefill weights LAST: the quantised decode formats above replace the row-major weights by their de-quantised values (same stream, in
     // order), and the fused-RMSNorm prefill must evaluate that same model
-    if (Hd % 64 == 0)
+    if (Hd % 64 == 0) {
       for (int l = 0; l < f.layers; ++l) {
         LlmLayerW& w = ctx->ll[l];
         int rc = folded(w.qkvw, w.ln1, (long)qkvw, Hd, &w.qkvw_f);
         if (!rc) rc = folded(w.guw, w.ln2, (long)2 * I, Hd, &w.guw_f);
         if (rc) return rc;
       }
+      // the decode path's copies of the folded weights (bf16 decode weights only: a quantised format would quantise gamma * W, another model than
+      // the prefill's): tile order like every decode weight; plus lm_head with the final norm weight
+      ctx->l_headd_f = nullptr;
+      if (ctx->decode_mfma && !ctx->fp8) {
+        auto tiled_f = [&](const bf16_t* W, int N, int K, int dr, int nqk, const bf16_t** out) -> int {
+          void* p = nullptr;
+          if (hipMalloc(&p, (size_t)((N + 15) / 16) * 16 * K * 2) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, GVL_ERR_OOM, "hipMalloc(folded decode weight copy) failed"); }
+          ctx->nf_allocs.push_back(p);
+          if (gvl_retile_decode_weight(W, (bf16_t*)p, N, K, dr, nqk, nullptr)) return fail(ctx, GVL_ERR_HIP, "retile launch failed");
+          *out = (const bf16_t*)p;
+          return 0;
+        };
+        for (int l = 0; l < f.layers; ++l) {
+          LlmLayerW& w = ctx->ll[l];
+          int rc = tiled_f(w.qkvw_f, qkvw, Hd, Dr, f.heads + f.kv_heads, &w.qkvd_f);
+          if (!rc) rc = tiled_f(w.guw_f, 2 * I, Hd, 0, 0, &w.gud_f);
+          if (rc) return rc;
+        }
+        const bf16_t* headf = nullptr;
+        int rc = folded(ctx->l_headw, ctx->l_norm, (long)f.vocab, Hd, &headf);
+        if (!rc) rc = tiled_f(headf, f.vocab, Hd, 0, 0, &ctx->l_headd_f);
+        if (rc) return rc;
+      }
+    }
   }
   // the retile kernels above (patch weights, decode tile copies) ran on the null stream: a first encode / decode on a NON-blocking stream (torch pool
   // streams, the bench's sV / sL) is not ordered behind them -- finalize returns only when every derived copy is complete

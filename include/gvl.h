@@ -263,7 +263,8 @@ int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launche
  *                      the DMA pieces per MFMA; measured 12 % slower), the remaining rows on the 4-wave form -- bit-identical
  *   "varlen_attn"      1 (default): the causal attention of a ragged prefill group (gvl_prefill_varlen) runs as ONE grid over the query blocks of all its sequences;
  *                      0: one launch per sequence (rounds 2-4) -- bit-identical
- *   "norm_fused"       1 (default): RMSNorm in front of qkv / fc1 (InternVideo2) and qkv_proj / gate_up_proj (LLM prefill) is fused into the GEMMs around it
+ *   "norm_fused"       1 (default): RMSNorm in front of qkv / fc1 (InternVideo2) and qkv_proj / gate_up_proj / lm_head (LLM prefill AND, with bf16 decode weights,
+ *                      the decode step) is fused into the GEMMs around it
  *                      (row statistics from the producing GEMM's epilogue, norm weight folded into the consuming GEMM's weight, row scale in its epilogue); 0: the
  *                      separate norm pass of rounds 1-4.  NOT bit-neutral -- the third stated exception below: two activation roundings of the reference
  *                      (x * rs and the gamma product, both to bf16) are gone and gamma * W is rounded once per weight instead

@@ -304,13 +304,6 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
   constexpr int RC = 3;
   u32x4_t qreg[RC], kreg[RC];
   const bool in_regs = WPR == 1 && a.mode == 1 && nq <= RC * 64 && nk <= RC * 64;
-  if (a.mode == 1 && a.k_rs_in) {                   // statistics given (GEMM-epilogue row sums): k only, no reduction
-    k_rs = a.k_rs_in[row];
-    if (in_regs) {
-#pragma unroll
-      for (int i = 0; i < RC; ++i) { const int c = lane + 64 * i; kreg[i] = c < nk ? *(const u32x4_t*)(kr + c * 8) : u32x4_t{0u, 0u, 0u, 0u}; }
-    }
-  } else
   if (a.mode == 1) {
     float sq = 0.f, sk = 0.f;
     if (in_regs) {
@@ -463,7 +456,6 @@ int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st) {
   if ((a.Dr & 7) || (a.mode == 2 && (a.Dr & 15)) || (a.D & 7) || a.D < a.Dr || a.Dr > 128 || (a.ld & 7)) return -1;   // 16-byte chunks; rotate_half partner chunk-aligned
   const int rows = a.B * a.S;
   if (a.q_rs && (a.mode != 1 || a.pos_ptr)) return -1;
-  if (a.k_rs_in && (!a.q_rs || a.mode != 1)) return -1;
   if (a.pos_ptr) {
     if (rows != 1 || a.mode != 2) return -1;
     hipLaunchKernelGGL(qkv_post_kernel<4>, dim3(1), dim3(256), 0, st, a);

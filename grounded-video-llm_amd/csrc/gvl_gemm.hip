@@ -975,7 +975,7 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
       if (stg_ok) switch (epi) {
 #define S_CASE(E) case E: return launch_cfg<128, 128, 2, 2, 1, E, 1>(a, st);
         S_CASE(0) S_CASE(32) S_CASE(33) S_CASE(34) S_CASE(3) S_CASE(44) S_CASE(56) S_CASE(8) S_CASE(4) S_CASE(36)
-        S_CASE(64) S_CASE(67) S_CASE(98) S_CASE(128) S_CASE(136) S_CASE(184) S_CASE(192)     // fused RMSNorm: +64 row scale (consumer), +128 row sums of squares (producer)
+        S_CASE(64) S_CASE(67) S_CASE(98) S_CASE(128) S_CASE(136) S_CASE(184)     // fused RMSNorm: +64 row scale (consumer), +128 row sums of squares (producer)
 #undef S_CASE
         default: break;
       }
@@ -990,7 +990,7 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
       if (stg_ok) switch (epi) {
 #define S_CASE(E) case E: return launch_cfg<64, 128, 2, 2, 1, E, 1, 3>(a, st);
         S_CASE(0) S_CASE(32) S_CASE(33) S_CASE(34) S_CASE(3) S_CASE(44) S_CASE(56) S_CASE(8) S_CASE(4) S_CASE(36)
-        S_CASE(64) S_CASE(67) S_CASE(98) S_CASE(128) S_CASE(136) S_CASE(184) S_CASE(192)
+        S_CASE(64) S_CASE(67) S_CASE(98) S_CASE(128) S_CASE(136) S_CASE(184)
 #undef S_CASE
         default: break;
       }
@@ -1001,7 +1001,7 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
       if (stg_ok) switch (epi) {
 #define PP_CASE(E) case E: return launch_pp<E, 1>(a, st);
         PP_CASE(0) PP_CASE(32) PP_CASE(33) PP_CASE(34) PP_CASE(3) PP_CASE(44) PP_CASE(56) PP_CASE(8) PP_CASE(4) PP_CASE(36)
-        PP_CASE(64) PP_CASE(67) PP_CASE(98) PP_CASE(128) PP_CASE(136) PP_CASE(184) PP_CASE(192)
+        PP_CASE(64) PP_CASE(67) PP_CASE(98) PP_CASE(128) PP_CASE(136) PP_CASE(184)
 #undef PP_CASE
         default: break;
       }

@@ -254,9 +254,6 @@ struct QkvPostArgs {
   int k_ones;                      // K pad column Dr (needs D > Dr) is 1.0 instead of 0 (harmless while q's pad is 0; see AttnArgs.k_ones)
   float* q_rs;                     // mode 1, or null: [B*S] -- the q rows are NOT written; their RMS factor rsqrt(mean q^2 + eps) is, and the attention
                                    //   kernel normalises the q fragments it loads from the qkv matrix itself (AttnArgs.q_rs / q_nw)
-  const float* k_rs_in;            // mode 1 with q_rs, or null: [B*S] RMS factor of the k rows, ALREADY computed (round 5: from the row statistics the qkv
-                                   //   GEMM's epilogue left, GemmArgs.rowsq -> gvl_launch_rowsq_finish) -- then q_rs is an input too (same source) and this pass
-                                   //   neither reads q nor reduces anything: it reads k, scales, writes the K pages
 };
 int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st);
 // HD 2x2 merge + sub_GN newline (Phi): f32 [n,576,C] -> bf16 [n,156,4C]

@@ -119,7 +119,6 @@ size_t iv2_bytes(const gvl_ctx* c, int n) {
   b += al256((size_t)n * f.iv2_heads * c->v_S * c->v_D * 2) + 2 * al256((size_t)n * tiles * f.iv2_heads * 64 * c->v_D * 2);
   b += al256(M * 4);                                   // per-token RMS factor of q (iv2_encode: qrs)
   b += al256(M * ((C + 63) / 64) * 4) + al256(M * 4);  // fused RMSNorm: row sums of squares per 64-column block + the row scale
-  b += al256(M * ((3 * C + 63) / 64) * 4) + al256(M * 4);   // ... of the qkv rows (q / k RMSNorm statistics) + the k row scale
   return b + 4096;
 }
 size_t visual_bytes(const gvl_ctx* c, int n) {
@@ -234,30 +233,22 @@ int iv2_encode(gvl_ctx* ctx, const float* px, int n, bf16_t* out, hipStream_t st
   const int NBLK = C / 64;
   const bool nf = ctx->dbg.norm_fused && C % 64 == 0 && !ctx->vb.empty() && ctx->vb[0].qkvw_f;
   AALLOC(sq, float, (size_t)M * (nf ? NBLK : 1)); AALLOC(nrs, float, (size_t)M);
-  // the q / k RMSNorm statistics (over the full width C, internvideo2.py:590-598) come the same way when q is read in place: the qkv GEMM leaves the row
-  // sums of squares of its 3 C outputs, two finish launches make q_rs (blocks 0 .. NBLK) and k_rs (NBLK .. 2 NBLK), and qkv_post no longer reads q at all
-  // MEASURED AND SWITCHED OFF (profiles/r05_ab_norm_fused.json, same box): the statistics cost the qkv GEMM +0.8 ms per clip (66 blocks of row sums per row)
-  // and two more small launches per block, and qkv_post did not get faster without its q read (it is bound by the K-page write, not by that read): a net loss.
-  const bool qk_stats = false && nf && q_in_place;
-  AALLOC(sq3, float, (size_t)M * (qk_stats ? 3 * NBLK : 1)); AALLOC(krs, float, (size_t)M);
+  // (Taking InternVideo2's q / k RMSNorm statistics the same way -- row sums of squares of the qkv GEMM's 3 C outputs, qkv_post reading k only -- was built
+  //  and measured a net loss: +0.8 ms of GEMM per clip for the 66 blocks per row, two more small launches per block, and a K pass that is bound by its
+  //  scattered page writes, not by the q read it lost.  profiles/r05_ab_norm_fused_with_qk_stats.json; removed.)
   for (int l = 0; l < f.iv2_blocks_run; ++l) {
     const Iv2BlockW& w = ctx->vb[l];
     if (nf && l > 0) {
       RUN(GVL_PROF_OTHER, 0, gvl_launch_rowsq_finish(sq, NBLK, 0, NBLK, nrs, M, C, 1e-6f, st));
-      GemmArgs g = gemm(x, C, w.qkvw_f, qkv, 3 * C, M, 3 * C, C); g.rowscale = nrs; if (qk_stats) { g.rowsq = sq3; g.rowsq_ld = 3 * NBLK; }
+      GemmArgs g = gemm(x, C, w.qkvw_f, qkv, 3 * C, M, 3 * C, C); g.rowscale = nrs;
       RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
     } else {
       RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(x, w.n1, h, M, C, 1e-6f, st));
-      GemmArgs g = gemm(h, C, w.qkvw, qkv, 3 * C, M, 3 * C, C); if (qk_stats) { g.rowsq = sq3; g.rowsq_ld = 3 * NBLK; }
+      GemmArgs g = gemm(h, C, w.qkvw, qkv, 3 * C, M, 3 * C, C);
       RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
-    }
-    if (qk_stats) {
-      RUN(GVL_PROF_OTHER, 0, gvl_launch_rowsq_finish(sq3, 3 * NBLK, 0, NBLK, qrs, M, C, 1e-6f, st));
-      RUN(GVL_PROF_OTHER, 0, gvl_launch_rowsq_finish(sq3, 3 * NBLK, NBLK, NBLK, krs, M, C, 1e-6f, st));
     }
     { QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv; q.ld = 3 * C; q.Q = Q; q.Kt = Kt; q.Vt = vt_pages ? Vt : nullptr; q.B = n; q.S = S; q.H = H; q.KV = H; q.Dr = Dr; q.D = D;
       q.mode = 1; q.qn = w.qn; q.kn = w.kn; q.eps = 1e-6f; q.ones_row = D > Dr ? 1 : 0; q.q_rs = q_in_place ? qrs : nullptr; q.k_ones = D > Dr ? 1 : 0;
-      if (qk_stats) q.k_rs_in = krs;
       RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st)); }
     { AttnArgs a; memset(&a, 0, sizeof(a)); a.Q = Q; a.Kt = Kt; a.Vt = Vt; if (!vt_pages) { a.Vrows = qkv + 2 * C; a.v_ld = 3 * C; } a.O = att; a.B = n; a.H = H; a.KV = H; a.S = S; a.D = D; a.Dout = Dr;
       if (q_in_place) { a.Qrows = qkv; a.q_ld = 3 * C; a.q_rs = qrs; a.q_nw = w.qn; a.k_ones = 1; a.pipe = ctx->dbg.attn_pipe; a.pipe_rows = ctx->dbg.attn_pipe_rows; }      // q read in place, normalised by the attention prologue: no Q write pass

@@ -104,7 +104,7 @@ struct gvl_ctx {
   struct { bool on = false; float inv_temp = 1.f, top_p = 0.f; int top_k = 0; unsigned long long seed = 0; unsigned next_stream = 0; } sample;
   // result-neutral launch parameters (gvl_debug_set): 0 = the launcher's own choice.  decode_graph: a decode group's step is captured once and
   // replayed (hipGraph) for the following tokens -- the host pays one graph launch per token instead of ~165 kernel launches
-  struct { int decode_attn_cpb = 0, decode_attn_hpb = 0; bool decode_graph = true; int vision_in_place = 1, prefill_group = 4, attn_ring = 0, attn_pipe = 1, attn_pipe_rows = 128, patch_fused = 1, varlen_attn = 1, norm_fused = 1; } dbg;
+  struct { int decode_attn_cpb = 0, decode_attn_hpb = 0; bool decode_graph = true; int vision_in_place = 1, prefill_group = 4, attn_ring = 0, attn_pipe = 1, attn_pipe_rows = 128, patch_fused = 1, varlen_attn = 1, norm_fused = 1, last_layer_tail = 1; } dbg;
   // RCCL communicator owned by the ctx (gvl_comm_init); the library is dlopen'ed on first use
   void* comm = nullptr; int comm_rank = 0, comm_world = 1;
   // profiling

@@ -141,6 +141,7 @@ size_t prefill_bytes(const gvl_ctx* c, int S) {
   b += al256((size_t)S * f.inter * 2) + al256((size_t)f.heads * S * c->l_D * 2);
   b += al256((size_t)kLossChunk * f.vocab * 2) + al256((size_t)kLossChunk * f.hidden * 2) + 3 * al256((size_t)S * 4);   // loss tail (gvl_forward_loss)
   b += al256((size_t)S * ((f.hidden + 63) / 64) * 4) + al256((size_t)S * 4);                                          // fused RMSNorm: row statistics + row scale
+  b += (size_t)GVL_MAX_PREFILL_BATCH * (al256((size_t)f.hidden * 2) * 2 + al256((size_t)f.inter * 2) + al256(((f.hidden + 63) / 64) * 4) + 256) + 1024;   // last-layer tail rows
   return b + 4096;
 }
 size_t feats_bytes(const gvl_ctx* c, int n) {
@@ -363,6 +364,7 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
   const int NBLK = Hd / 64;
   const bool nf = ctx->dbg.norm_fused && Hd % 64 == 0 && !ctx->ll.empty() && ctx->ll[0].qkvw_f;
   LALLOC(sq, float, (size_t)M * (nf ? NBLK : 1)); LALLOC(nrs, float, (size_t)M);
+  const bf16_t* tail_rows = nullptr;                  // [nb][Hd]: the sequences' last rows after the last layer, when only they went through its MLP
   // one (RoPE + KV append, attention) launch for the whole batch when the lengths agree, one per sequence otherwise
   const int n_att = (nb == 1 || uniform) ? 1 : nb;
   for (int l = 0; l < f.layers; ++l) {
@@ -406,6 +408,29 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
     }
     { GemmArgs g = gemm(att, H * Dr, w.ow, x, Hd, M, Hd, H * Dr); g.resid = x; g.ldr = Hd; if (nf) { g.rowsq = sq; g.rowsq_ld = NBLK; }
       RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+    // LAST layer, no loss request: nothing downstream reads the MLP output of any row but a sequence's last (the KV cache is complete after qkv_post, the
+    // lm_head takes last rows only) -- gate_up / down run on the nb last rows alone: -2 x M x hidden x 3 inter flops (2.1 % of the prefill's GEMM work at
+    // S = 3.5 k).  The rows are gathered (x and, fused norm, their row statistics); GEMM rows do not depend on their neighbours, so the logits are
+    // bit-identical to the full pass (asserted; gvl_debug_set("last_layer_tail", 0) = the full pass).
+    if (l == f.layers - 1 && !loss && ctx->dbg.last_layer_tail && (!nf || NBLK % 4 == 0)) {
+      int ids[GVL_MAX_PREFILL_BATCH];
+      for (int b = 0; b < nb; ++b) ids[b] = off[b + 1] - 1;
+      LALLOC(xl, bf16_t, (size_t)nb * Hd); LALLOC(actl, bf16_t, (size_t)nb * I);
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_rows_host_ids(x, ids, nb, xl, Hd, st));
+      if (nf) {
+        LALLOC(sql, float, (size_t)nb * NBLK); LALLOC(rsl, float, nb);
+        RUN(GVL_PROF_OTHER, 0, gvl_launch_gather_rows_host_ids((const bf16_t*)sq, ids, nb, (bf16_t*)sql, NBLK * 2, st));      // a row of partial sums = NBLK floats
+        RUN(GVL_PROF_OTHER, 0, gvl_launch_rowsq_finish(sql, NBLK, 0, NBLK, rsl, nb, Hd, f.rms_eps, st));
+        GemmArgs g = gemm(xl, Hd, w.guw_f, actl, I, nb, 2 * I, Hd); g.act = GVL_ACT_SILU_MUL; g.rowscale = rsl; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
+      } else {
+        LALLOC(hl, bf16_t, (size_t)nb * Hd);
+        RUN(GVL_PROF_OTHER, 0, gvl_launch_rmsnorm_bf16(xl, w.ln2, hl, nb, Hd, f.rms_eps, st));
+        GemmArgs g = gemm(hl, Hd, w.guw, actl, I, nb, 2 * I, Hd); g.act = GVL_ACT_SILU_MUL; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
+      }
+      { GemmArgs g = gemm(actl, I, w.downw, xl, Hd, nb, Hd, I); g.resid = xl; g.ldr = Hd; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st)); }
+      tail_rows = xl;
+      continue;
+    }
     if (nf) {
       RUN(GVL_PROF_OTHER, 0, gvl_launch_rowsq_finish(sq, NBLK, 0, NBLK, nrs, M, Hd, f.rms_eps, st));
       GemmArgs g = gemm(x, Hd, w.guw_f, act, I, M, 2 * I, Hd); g.act = GVL_ACT_SILU_MUL; g.rowscale = nrs; RUN(GVL_PROF_GEMM, gvl_gemm_flops(g), gvl_launch_gemm(g, st));
@@ -437,7 +462,8 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
   // last-row-only lm_head: final RMSNorm fused into the GEMV; one weight stream for the nb last rows
   const bf16_t* last = x + (size_t)(S0 - 1) * Hd;
   int last_stride = S0 * Hd;
-  if (n_att > 1) {                         // ragged: gather the nb last rows (h is free by now)
+  if (tail_rows) { last = tail_rows; last_stride = Hd; }
+  else if (n_att > 1) {                    // ragged: gather the nb last rows (h is free by now)
     for (int b = 0; b < nb; ++b) RUN(GVL_PROF_OTHER, 0, gvl_launch_copy_bytes(x + (size_t)(off[b + 1] - 1) * Hd, h + (size_t)b * Hd, (size_t)Hd * 2, st));
     last = h; last_stride = Hd;
   }
@@ -1368,6 +1394,7 @@ int gvl_debug_set(gvl_ctx* ctx, const char* key, int value) {
   else if (k == "patch_fused") ctx->dbg.patch_fused = value != 0;
   else if (k == "varlen_attn") ctx->dbg.varlen_attn = value != 0;
   else if (k == "norm_fused") ctx->dbg.norm_fused = value != 0;
+  else if (k == "last_layer_tail") ctx->dbg.last_layer_tail = value != 0;
   else if (k == "vision_in_place") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: vision_in_place must be 0, 1 or 2"); ctx->dbg.vision_in_place = value; }
   else return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: unknown key " + k);
   return 0;

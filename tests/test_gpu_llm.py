@@ -156,6 +156,17 @@ def test_phi3_full_width_layer():
     eng.debug_set("norm_fused", 1)
     check(unf, g["logits"][0, -1], 1e-2, "phi3 full-width layer (separate norm pass) vs reference golden")
     check(logits, unf, 1e-2, "phi3 full-width layer: fused RMSNorm vs the separate norm pass")
+    # the last layer's MLP runs on the last row only (nothing else reads its output): bit-identical to running it on every row, fused and unfused
+    for nfv in (1, 0):
+        eng.debug_set("norm_fused", nfv)
+        outs = []
+        for tail in (1, 0):
+            eng.debug_set("last_layer_tail", tail)
+            s3 = eng.seq_alloc(128)
+            outs.append(eng.prefill(s3, x.to(DEV).to(bf), want_logits=True).clone())
+            eng.seq_free(s3)
+        assert torch.equal(outs[0], outs[1]), f"last_layer_tail changes the prefill logits (norm_fused={nfv})"
+    eng.debug_set("norm_fused", 1); eng.debug_set("last_layer_tail", 1)
     # and one decode step through the full-width GEMV path
     ocfg = _ocfg(geo)
     cache = [None] * geo.layers

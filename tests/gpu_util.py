@@ -103,7 +103,6 @@ def like_for_like(rows, tag, what):
     mx = lambda t: float(t.abs().max()) / scale
     rms = lambda t: float(t.pow(2).mean().sqrt()) / scale
     e_h, e_p, r_h, r_p = mx(h - r), mx(p - r), rms(h - r), rms(p - r)
-    worst_row = max(mx(h[i] - r[i]) * scale / scale for i in range(h.shape[0]))
     print(f"[parity-table] {what} | rows {h.shape[0]} | HIP vs ref-fp32: max {e_h:.3e} rms {r_h:.3e} | reference like-for-like bf16 vs its fp32: max {e_p:.3e} rms {r_p:.3e} | "
           f"ratio max {e_h / e_p:.2f} rms {r_h / r_p:.2f} | north-star 1e-2 rel: rms {'met' if r_h <= 1e-2 else 'NOT met'} ({r_h / 1e-2:.2f} x), max-abs "
           f"{'met' if e_h <= 1e-2 else 'not met'} ({e_h / 1e-2:.2f} x; the reference's own bf16 path: {e_p / 1e-2:.2f} x)")

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
   int m0 = 0, n0 = 0;
   auto setup = [&](int vid, int& om0, int& on0) {
     // grouped rasterisation inside the XCD's run: walk DOWN a band of GM tile-rows, then the next tile column
-    constexpr int GM = 8;
+    const int GM = a.band;                        // tile rows per band (launch_pp: 8, or 32 / tiles_n when a whole tile row fits the XCD's 32 workgroups)
     const int band = GM * tiles_n;
     const int g = vid / band, first_m = g * GM;
     const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
@@ -780,6 +780,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
 #undef PP_BARRIER
 }
 
+static int g_band_override = 0;                     // A/B only (gvl_debug_set("gemm_band")): process-wide, result-neutral
+void gvl_gemm_set_band(int v) { g_band_override = v; }
 // Phi(x) table of the current device (built once per device; blocking upload on first use, outside any timed region after warmup)
 static const float* gelu_table_device() {
   static const float* tabs[64] = {nullptr};
@@ -820,6 +822,11 @@ static int launch_pp(const GemmArgs& a_in, hipStream_t st) {
   GemmArgs a = a_in;
   const int tiles_m = (a.M - a.m_begin + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const int tiles = tiles_m * tiles_n;
+  // Rasterisation band.  The 32 workgroups of an XCD walk a band of GM tile rows column by column, k-tile by k-tile in lock-step: with GM x tiles_n <= 32 the
+  // WHOLE width of those rows is in flight at once and every A slice is fetched into that XCD's L2 once (N = 1408: 5 rows x 6 columns; the 8 x 4 patch
+  // re-reads the A panel for the columns 4-5 -- 2.4 GB per InternVideo2 fc2 call).  Wider matrices keep 8 rows (8 x 4 patch).
+  if (a.band <= 0) a.band = tiles_n <= 8 ? (32 / tiles_n > 0 ? 32 / tiles_n : 1) : 8;
+  if (g_band_override > 0) a.band = g_band_override;
   static const bool no_persist = gvl_lab_env("GVL_GEMM_NO_PERSIST") != nullptr;                // A/B only
   const int grid = (tiles <= n_cu || no_persist) ? tiles : n_cu;
   static const bool timing = gvl_lab_env("GVL_GEMM_TIMING") != nullptr;                        // anatomy probe (tools/gemm_one.py)

@@ -143,6 +143,7 @@ struct GemmArgs {
   // output row remap: row m -> (m / grp_rows) * grp_stride + (m % grp_rows) + row_off   (grp_rows==0: identity)
   int grp_rows, grp_stride, row_off;
   int tile_cfg;                  // 0 auto; see gvl_launch_gemm
+  int band;                      // ping-pong kernel: tile ROWS per rasterisation band (0 = the launcher's choice); any value gives the same result
   int m_begin;                   // launch covers rows [m_begin, M) -- set internally by the wave-quantisation split
   // Fused RMSNorm (round 5).  CONSUMER side: rowscale[m] (f32, [M]) multiplies row m of the accumulator BEFORE bias / activation -- RMSNorm(x) . W^T =
   // rs[m] * (x . (W diag(gamma))^T): A is the RAW residual stream, W carries the norm weight (gvl_fold_gamma), rs = rsqrt(mean x^2 + eps).
@@ -154,6 +155,7 @@ struct GemmArgs {
   unsigned long long* dbg;       // null, or [grid][8 waves][4] s_memtime stamps of the LAST tile (GVL_GEMM_TIMING=1, ping-pong kernel)
 };
 int gvl_launch_gemm(const GemmArgs& a, hipStream_t st);
+void gvl_gemm_set_band(int v);   // A/B: tile rows per rasterisation band of the ping-pong kernel for every later launch of the process (0 = automatic)
 double gvl_gemm_flops(const GemmArgs& a);
 
 // ---- attention (prefill / vision) -----------------------------------------------------------------

@@ -822,10 +822,11 @@ static int launch_pp(const GemmArgs& a_in, hipStream_t st) {
   GemmArgs a = a_in;
   const int tiles_m = (a.M - a.m_begin + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const int tiles = tiles_m * tiles_n;
-  // Rasterisation band.  The 32 workgroups of an XCD walk a band of GM tile rows column by column, k-tile by k-tile in lock-step: with GM x tiles_n <= 32 the
-  // WHOLE width of those rows is in flight at once and every A slice is fetched into that XCD's L2 once (N = 1408: 5 rows x 6 columns; the 8 x 4 patch
-  // re-reads the A panel for the columns 4-5 -- 2.4 GB per InternVideo2 fc2 call).  Wider matrices keep 8 rows (8 x 4 patch).
-  if (a.band <= 0) a.band = tiles_n <= 8 ? (32 / tiles_n > 0 ? 32 / tiles_n : 1) : 8;
+  // Rasterisation band: the 32 workgroups of an XCD walk a band of GM tile rows column by column, k-tile by k-tile in lock-step (an 8 x 4 patch of tiles).
+  // MEASURED AND NOT ADOPTED (round 5, profiles/r05_ab_gemm_band.json + the PMC passes): GM = 32 / tile columns for narrow matrices (N = 1408: 5 rows x 6
+  // columns, so that an A slice enters the XCD's L2 once) -- +0.4 % clips/s, inside the run-to-run spread, while the family's fabric-side traffic ROSE from
+  // 193 to 231 GB per clip (the W panel is re-read per band, and there are 154 bands instead of 96).  8 rows stay; gvl_debug_set("gemm_band") varies it.
+  if (a.band <= 0) a.band = 8;
   if (g_band_override > 0) a.band = g_band_override;
   static const bool no_persist = gvl_lab_env("GVL_GEMM_NO_PERSIST") != nullptr;                // A/B only
   const int grid = (tiles <= n_cu || no_persist) ? tiles : n_cu;

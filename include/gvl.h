@@ -268,8 +268,8 @@ int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launche
  *                      (row statistics from the producing GEMM's epilogue, norm weight folded into the consuming GEMM's weight, row scale in its epilogue); 0: the
  *                      separate norm pass of rounds 1-4.  NOT bit-neutral -- the third stated exception below: two activation roundings of the reference
  *                      (x * rs and the gamma product, both to bf16) are gone and gamma * W is rounded once per weight instead
- *   "gemm_band"        0 (default): the ping-pong GEMM's rasterisation band is 32 / tile columns rows for matrices of <= 8 tile columns, else 8; 1..64: that many rows
- *                      for every later launch of the PROCESS (A/B only) -- bit-identical
+ *   "gemm_band"        0 (default): the ping-pong GEMM's rasterisation band is 8 tile rows; 1..64: that many rows for every later launch of the PROCESS (A/B only)
+ *                      -- bit-identical
  *   "last_layer_tail"  1 (default): a prefill without a loss request runs the LAST decoder layer's MLP on the sequences' last rows only (nothing else reads its
  *                      output); 0: on every row -- bit-identical
  *   "patch_fused"      1 (default): the patch embedding of a tower whose geometry the fused kernel covers (patch 14, width 1024 / 1408) runs as ONE kernel

@@ -338,6 +338,29 @@ def _rmsnorm(x, w, eps, emu):
     return _r(_r(w, emu) * _r(xn, emu), emu)
 
 
+def rmsnorm_linear_fused(x, norm_w, w, b, eps):
+    """The HIP build's FUSED form of `Linear(RMSNorm(x))` (round 5; csrc/gvl_gemm.hip GemmArgs.rowsq / rowscale, csrc/gvl_elem.hip fold_gamma / rowsq_finish),
+    restated with its rounding points so that the CPU suite can bound it against the reference-order form `_lin(_rmsnorm(x, ...), ...)`
+    (internvideo2.py:443-448 + :587,631; modeling_phi3.py:319-324 + :459,659):
+        W'   = bf16(W * gamma)                                  one rounding per weight (fold_gamma, at gvl_finalize_weights)
+        rs_m = rsqrt(sum_blocks(sum_{64 cols} bf16(x)^2) / C + eps)   fp32; the blocks are added in index order (rowsq_finish)
+        y    = bf16(rs_m * (bf16(x) . W'^T) [+ b])              fp32 accumulate, the row scale on the accumulator, ONE rounding of the output
+    The reference rounds x * rs and then gamma * (x * rs) to bf16 before the GEMM; here those two activation roundings are gone."""
+    xb = x.to(torch.bfloat16).float()
+    C = xb.shape[-1]
+    assert C % 64 == 0
+    wf = (w.to(torch.bfloat16).float() * norm_w.to(torch.bfloat16).float()).to(torch.bfloat16).float()
+    blocks = xb.pow(2).reshape(*xb.shape[:-1], C // 64, 64).sum(-1)
+    tot = torch.zeros_like(blocks[..., 0])
+    for j in range(C // 64):
+        tot = tot + blocks[..., j]
+    rs = torch.rsqrt(tot / C + eps)
+    y = rs[..., None] * F.linear(xb, wf)
+    if b is not None:
+        y = y + b.float()
+    return y.to(torch.bfloat16).float()
+
+
 def iv2_embed(px: torch.Tensor, W, emu=False) -> torch.Tensor:
     """PatchEmbed.forward :721-725 + cls/pos :972-1011.  px [B,3,T,H,W] -> [B,1+T*L,C]."""
     w, b = W["patch_embed.proj.weight"], W["patch_embed.proj.bias"]

@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import gvl_oracle as O
 from grounded_video_llm_amd import synth
@@ -315,3 +316,27 @@ def test_sampler_counter_hash_known_answers_and_distribution():
         cnt[O.sample_token(l, 0.7, 0, None, 1234, 3, st)[0]] += 1
     p = np.exp(l / 0.7); p /= p.sum()
     assert np.all(np.abs(cnt / 6000 - p) <= 4.5 * np.sqrt(p * (1 - p) / 6000))
+
+
+def test_fused_rmsnorm_linear_is_in_the_noise_class_of_the_reference_order():
+    """Round 5: the HIP build fuses RMSNorm into the GEMMs around it (row statistics from the producing epilogue, norm weight folded into the consuming weight,
+    row scale on the accumulator).  oracle.rmsnorm_linear_fused restates that arithmetic with its rounding points; against the fp32 truth it must be no worse than
+    the reference-order bf16 emulation (`_lin(_rmsnorm(...))`: two activation roundings before the GEMM), and the two bf16 forms must sit within bf16 output
+    rounding of each other -- at InternVideo2's and Phi-3.5's widths, with rows of very different scale."""
+    g = torch.Generator(); g.manual_seed(11)
+    for C, N in ((1408, 4224), (3072, 1024)):
+        x = torch.randn((96, C), generator=g) * (0.2 + 3.0 * torch.rand((96, 1), generator=g))
+        x = x.to(torch.bfloat16).float()
+        gamma = 1.0 + 0.2 * torch.randn((C,), generator=g)
+        w = torch.randn((N, C), generator=g) * C ** -0.5
+        b = 0.5 * torch.randn((N,), generator=g)
+        truth = F.linear(O._rmsnorm(x, gamma.to(torch.bfloat16).float(), 1e-6, False), w.to(torch.bfloat16).float(), b)
+        ref_order = O._lin(O._rmsnorm(x, gamma, 1e-6, True), w, b, True)
+        fused = O.rmsnorm_linear_fused(x, gamma, w, b, 1e-6)
+        scale = float(truth.abs().max())
+        e_ref, e_fused = float((ref_order - truth).abs().max()) / scale, float((fused - truth).abs().max()) / scale
+        r_ref, r_fused = float((ref_order - truth).pow(2).mean().sqrt()) / scale, float((fused - truth).pow(2).mean().sqrt()) / scale
+        d = float((fused - ref_order).abs().max()) / scale
+        print(f"[parity] fused RMSNorm + linear C={C} N={N}: vs fp32 max {e_fused:.3e} rms {r_fused:.3e}; reference order max {e_ref:.3e} rms {r_ref:.3e}; fused vs reference order {d:.3e}")
+        assert e_fused <= 1.25 * e_ref + 1e-4 and r_fused <= 1.10 * r_ref
+        assert d <= 8e-3

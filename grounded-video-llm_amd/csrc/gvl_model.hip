@@ -542,7 +542,7 @@ int decode_step(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st) {
   // weights and scale their accumulators per sequence.  No norm launch (groups > 4: two per layer) and no in-block normalisation (groups <= 4) any more;
   // layer 0's input norm (no producer projection) keeps the old path.  bf16 decode weights only.
   const int nblk = Hd >> 4;
-  const bool rs = mfma && !ctx->fp8 && ctx->dbg.norm_fused && ctx->l_headd_f && Hd % 64 == 0 && (nblk & 31) == 0;
+  const bool rs = mfma && !ctx->fp8 && ctx->dbg.norm_fused && ctx->l_headd_f && Hd % 64 == 0 && (nblk & 31) == 0 && nblk <= 256;
   auto rs_input = [&](GemvArgs& g) { g.x = ctx->d_xt; g.sq_in = ctx->d_sqpart; g.sq_n = nblk; g.eps = f.rms_eps; };
   auto rs_output = [&](GemvArgs& g) { if (rs) { g.sq_out = ctx->d_sqpart; g.out_tiled2 = ctx->d_xt; } };
   for (int l = 0; l < f.layers; ++l) {

@@ -1,0 +1,81 @@
+"""-m gpu: the 4-wave / AGPR-accumulator GEMM (gvl_gemm4.hip, tile_cfg 84 / 86 / 87 = loop schedule variants) against the 8-wave ping-pong kernel (82) and the
+128 x 128 kernel (21) -- BIT-identical (every kernel accumulates an output element in the same k order and shares the epilogue arithmetic) -- and against fp32 torch.
+Covers: k-tile counts from the minimum (3) up, odd / even (ring-slot parity carried across the tiles of a persistent workgroup), ragged M and N (rows beyond the
+matrix come back as zeros from the buffer bounds check), more tiles than CUs (persistent walk + next-tile prefetch), every fused epilogue the kernel serves."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, bf, check  # noqa: E402
+from grounded_video_llm_amd import engine as E, lib as L  # noqa: E402
+from gpu_util import tiny_geo  # noqa: E402
+
+A4 = [84, 86, 87]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = E.Engine(tiny_geo(), DEV, towers=())
+    yield e
+    e.close()
+
+
+def _ops(M, N, K, seed):
+    g = torch.Generator(device=DEV); g.manual_seed(seed)
+    A = torch.randn((M, K), device=DEV, generator=g).to(bf)
+    W = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).to(bf)
+    return A, W, g
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 192), (300, 256, 256), (1000, 1408, 1408), (513, 4224, 320), (77, 72 * 4, 448), (2049, 512, 1024),
+                                   (24588, 1408, 384), (70000, 1024, 192), (3519, 3072, 3072)])
+def test_plain_bit_identical_to_the_other_kernels(eng, M, N, K):
+    A, W, _ = _ops(M, N, K, 7)
+    want = eng.op_gemm(A, W, tile_cfg=21)
+    assert torch.equal(want, eng.op_gemm(A, W, tile_cfg=82))
+    for cfg in A4:
+        got = eng.op_gemm(A, W, tile_cfg=cfg)
+        bad = (got != want).nonzero()
+        assert bad.numel() == 0, f"cfg {cfg} {M}x{N}x{K}: {bad.shape[0]} elements differ, first at {bad[0].tolist()}"
+    check(want, A.float() @ W.float().T, 6e-3, f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 1408, 1408), (5000, 512, 192), (3000, 1024, 832)])
+def test_every_fused_epilogue_bit_identical(eng, M, N, K):
+    A, W, g = _ops(M, N, K, 11)
+    bias = torch.randn((N,), device=DEV, generator=g) * 0.5
+    gam = torch.randn((N,), device=DEV, generator=g) * 0.1
+    resb = torch.randn((M, N), device=DEV, generator=g).to(bf)
+    rs = torch.rand((M,), device=DEV, generator=g) + 0.5
+    cases = {
+        "bias": dict(bias=bias), "bias_qgelu": dict(bias=bias, act=L.ACT_QUICK_GELU), "bias_gelu": dict(bias=bias, act=L.ACT_GELU), "silu": dict(act=L.ACT_SILU_MUL),
+        "bias_gamma_resid": dict(bias=bias, gamma=gam, resid=resb), "resid": dict(resid=resb),
+    }
+    for name, kw in cases.items():
+        want = eng.op_gemm(A, W, tile_cfg=82, **kw)
+        for cfg in A4:
+            assert torch.equal(want, eng.op_gemm(A, W, tile_cfg=cfg, **kw)), f"{name} cfg {cfg}"
+    rows = {
+        "rowscale": dict(rowscale=rs), "rowscale_silu": dict(rowscale=rs, act=L.ACT_SILU_MUL), "rowscale_bias_gelu": dict(rowscale=rs, bias=bias, act=L.ACT_GELU),
+    }
+    for name, kw in rows.items():
+        want = eng.op_gemm_rows(A, W, tile_cfg=82, **kw)
+        for cfg in A4:
+            assert torch.equal(want, eng.op_gemm_rows(A, W, tile_cfg=cfg, **kw)), f"{name} cfg {cfg}"
+    if N % 64 == 0:
+        sq = {"rowsq": dict(), "rowsq_resid": dict(resid=resb), "rowsq_bias_gamma_resid": dict(bias=bias, gamma=gam, resid=resb)}
+        for name, kw in sq.items():
+            wc, wq = eng.op_gemm_rows(A, W, want_rowsq=True, tile_cfg=82, **kw)
+            for cfg in A4:
+                c, q = eng.op_gemm_rows(A, W, want_rowsq=True, tile_cfg=cfg, **kw)
+                assert torch.equal(wc, c) and torch.equal(wq, q), f"{name} cfg {cfg}"
+
+
+def test_repeated_launches_are_stable(eng):
+    """race screen: the same launch 20 times must give the same bits (a DMA that lands after its reader shows up as a rare differing tile)"""
+    A, W, _ = _ops(6000, 2048, 1408, 3)
+    want = eng.op_gemm(A, W, tile_cfg=82)
+    for cfg in A4:
+        for _ in range(20):
+            assert torch.equal(want, eng.op_gemm(A, W, tile_cfg=cfg))

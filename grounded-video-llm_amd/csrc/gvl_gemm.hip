@@ -425,15 +425,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
 
 static int g_band_override = 0;                     // A/B only (gvl_debug_set("gemm_band")): process-wide, result-neutral
 void gvl_gemm_set_band(int v) { g_band_override = v; }
-// Which launches of the 256 x 256 kernel take the 4-wave / AGPR form (gvl_gemm4.hip) instead of the 8-wave ping-pong: 0 none, 1 (default) the epilogues where it
-// measured faster on the same box (profiles/r06_gemm4_lab.txt), 2 every epilogue it serves.  Bit-identical either way (gvl_debug_set("gemm_a4"); process-wide).
+// Which launches of the 256 x 256 kernel take a 4-wave / AGPR form (gvl_gemm4.hip, gvl_gemm4p.hip) instead of the 8-wave ping-pong: see big_form_preferred and the
+// dispatch in gvl_launch_gemm.  Bit-identical whatever the value (gvl_debug_set("gemm_a4"); process-wide).
 static int g_a4_mode = 1;
 void gvl_gemm_set_a4(int v) { g_a4_mode = v; }
-static bool a4_preferred(int epi, int K) {
-  (void)K;
-  // its main loop is 3 ... 6 % faster on every shape, its un-overlapped epilogue (ONE wave per SIMD: nothing hides the VALU / LDS latencies) 1.5 ... 1.75 x slower:
-  // the table / sigmoid epilogues at short K lose on balance
-  return !(epi == 98 || epi == 33 || epi == 34);
+// Which form of the 256 x 256 kernel an (epilogue) takes when the library chooses (cfg 80), from same-box interleaved runs on the model's shapes
+// (profiles/r06_gemm4_lab_model.txt; tools/gemm4_lab.py 82,86,88 model):
+//   pipelined 4-wave (88): the epilogues with real VALU / LDS work behind the bf16 rounding -- erf-GELU (98: +5 % over the 8-wave kernel, +10 % over the plain 4-wave
+//                          one), SwiGLU (67: +4.5 %), residual + row statistics (136: +3 ... +7 %; 184: +1 ... +5 %) -- that work rides in the next tile's MFMA gaps;
+//   plain 4-wave (86):     the store-only epilogues (64, 0, ...: +2 ... +4 %; pipelining them buys nothing: what remains exposed either way is the accumulator drain);
+//   8-wave ping-pong (82): CLIP's short-K bias / quick-GELU shapes (32, 33: the 4-wave forms lose 2 ... 4 % there) and everything the 4-wave kernels do not serve.
+static int big_form_preferred(int epi) {
+  switch (epi) {
+    case 98: case 67: case 136: case 184: return 88;
+    case 64: case 0: case 3: case 8: case 128: return 86;
+    default: return 82;
+  }
 }
 // Phi(x) table of the current device (built once per device; blocking upload on first use, outside any timed region after warmup)
 static const float* gelu_table_device() {
@@ -628,7 +635,28 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     const long t128 = (long)((a.M - a.m_begin + 127) / 128) * ((a.N + 127) / 128);
     if (small64 && t128 * 2 <= (long)small64 * n_cu2) cfg = 22;
   }
-  if (cfg == 80) cfg = (g_a4_mode && (g_a4_mode == 2 || a4_preferred(epi, a.K))) ? 86 : 82;
+  // cfg 80 = "the 256 x 256 kernel, the library's choice of form" (what the automatic selection and the planner ask for).  Forms, all bit-identical:
+  // 82 the 8-wave ping-pong kernel; 84 / 86 / 87 the 4-wave kernel (gvl_gemm4.hip, loop schedule 0 / 1 / 2); 88 the 4-wave kernel with the epilogue
+  // pipelined into the next tile's main loop (gvl_gemm4p.hip).  An explicit 84 ... 88 that does not serve the (epilogue, geometry) falls back towards 82.
+  if (cfg == 80 || (cfg >= 84 && cfg <= 88)) {
+    // gemm_a4 (gvl_debug_set): 0 = always the 8-wave kernel, 1 (default) = big_form_preferred, 2 = the plain 4-wave kernel wherever it serves, 3 = the pipelined one
+    // wherever it serves (then the plain one)
+    int form = cfg;
+    if (cfg == 80) form = g_a4_mode == 0 ? 82 : (g_a4_mode == 1 ? big_form_preferred(epi) : (g_a4_mode == 2 ? 86 : 88));
+    GemmArgs b = a;
+    if (b.band <= 0) b.band = 8;
+    if (g_band_override > 0) b.band = g_band_override;
+    if (stg_ok && form == 88) {
+      const int rc4 = gvl_launch_gemm_a4p(b, epi, st);
+      if (rc4 != -2) return rc4;
+      form = 86;
+    }
+    if (stg_ok && form >= 84 && form <= 87) {
+      const int rc4 = gvl_launch_gemm_a4(b, epi, form == 84 ? 0 : (form == 87 ? 2 : 1), st);
+      if (rc4 != -2) return rc4;
+    }
+    cfg = 82;
+  }
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 0>(a, st);            // plain lock-step baseline (tests / A-B)
     // cfg 21 / 82 run the LDS-staged whole-row epilogue (compile-time specialised per fused-epilogue code) whenever the
@@ -659,18 +687,6 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
       if (a.rowscale || a.rowsq) return -1;
       return launch_cfg<64, 128, 2, 2, 1, -1>(a, st);
     }
-    // cfg 80 = "the 256 x 256 kernel, the library's choice of form" (what the automatic selection and the planner ask for): the 4-wave kernel where
-    // a4_preferred says so, else the 8-wave ping-pong.  82 is always the ping-pong kernel, 84 / 86 / 87 always the 4-wave one (tests, A/B).
-    case 84: case 86: case 87: {                            // the 4-wave kernel (gvl_gemm4.hip), loop schedule variant 0 / 1 / 2; what it does not serve falls through to 82
-      if (stg_ok) {
-        GemmArgs b = a;
-        if (b.band <= 0) b.band = 8;
-        if (g_band_override > 0) b.band = g_band_override;
-        const int rc4 = gvl_launch_gemm_a4(b, epi, cfg == 84 ? 0 : (cfg == 87 ? 2 : 1), st);
-        if (rc4 != -2) return rc4;
-      }
-    }
-    [[fallthrough]];
     case 82: {
       if (stg_ok) switch (epi) {
 #define PP_CASE(E) case E: return launch_pp<E, 1>(a, st);

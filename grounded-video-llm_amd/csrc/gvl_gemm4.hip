@@ -147,7 +147,11 @@ __global__ __launch_bounds__(256) void gemm_a4_kernel(const GemmArgs a, int tile
     if (a.dbg) ts1 = __builtin_readcyclecounter();
     const unsigned last_slot = (par + nk - 1u) & 1u;    // the slot of the last k-tile: read out by everybody (barrier of its phase 2) -> staging area
     par = (par + nk) & 1u;
+#ifdef GVL_A4_LAB_NOEPI                              // LAB (wrong results, timing only): what a fully hidden epilogue would be worth
+    if (false) {
+#else
     if (!dead) {
+#endif
       if constexpr (G::has_bias || G::has_gamma) stg_store_bias<NB, EPI>(bgw, lane, ebv, egv);
       gemm_epilogue_staged_rows<MB, NB, EPI, SWZ, PRE, GELU_TAB ? 1 : 0>(a, A4AccRow{}, smem + last_slot * SLOT + wave * STG_BYTES, bgw, mw, nw, lane, rv, rsc, NoHook(), tabp);
     }

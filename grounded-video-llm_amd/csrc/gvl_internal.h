@@ -158,6 +158,8 @@ int gvl_launch_gemm(const GemmArgs& a, hipStream_t st);
 // gvl_gemm4.hip: the 4-wave / AGPR-accumulator form of the 256 x 256 kernel for the staged bf16 epilogue code `epi` (loop schedule variant `var`);
 // -2 = this epilogue or geometry is not served there (the caller launches the 8-wave kernel instead)
 int gvl_launch_gemm_a4(const GemmArgs& a, int epi, int var, hipStream_t st);
+// gvl_gemm4p.hip: the same kernel with the epilogue software-pipelined into the next tile's main loop; -2 as above
+int gvl_launch_gemm_a4p(const GemmArgs& a, int epi, hipStream_t st);
 void gvl_gemm_set_a4(int v);     // A/B: 0 = the 256 x 256 launches stay on the 8-wave ping-pong kernel, 1 (default) = the 4-wave kernel where it is faster, 2 = wherever it serves
 void gvl_gemm_set_band(int v);   // A/B: tile rows per rasterisation band of the ping-pong kernel for every later launch of the process (0 = automatic)
 double gvl_gemm_flops(const GemmArgs& a);

@@ -270,9 +270,11 @@ int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launche
  *                      (x * rs and the gamma product, both to bf16) are gone and gamma * W is rounded once per weight instead
  *   "gemm_band"        0 (default): the ping-pong GEMM's rasterisation band is 8 tile rows; 1..64: that many rows for every later launch of the PROCESS (A/B only)
  *                      -- bit-identical
- *   "gemm_a4"          1 (default): the 256 x 256 GEMM launches take the 4-wave kernel (accumulators in AGPRs, hand-placed k loop: gvl_gemm4.hip) for the fused
- *                      epilogues where it measured faster than the 8-wave ping-pong kernel; 2: for every epilogue it serves; 0: never.  For every later launch
- *                      of the PROCESS -- bit-identical
+ *   "gemm_a4"          which form of the 256 x 256 GEMM kernel a launch takes: 1 (default) per fused epilogue, as measured -- the 4-wave kernel with the epilogue
+ *                      pipelined into the next tile's main loop (gvl_gemm4p.hip) for erf-GELU / SwiGLU / residual + row statistics, the plain 4-wave kernel
+ *                      (gvl_gemm4.hip: accumulators in AGPRs, hand-placed k loop) for store-only epilogues, the 8-wave ping-pong kernel for the rest;
+ *                      0: always the 8-wave kernel; 2: the plain 4-wave kernel wherever it serves; 3: the pipelined one wherever it serves.  For every later
+ *                      launch of the PROCESS -- bit-identical
  *   "last_layer_tail"  1 (default): a prefill without a loss request runs the LAST decoder layer's MLP on the sequences' last rows only (nothing else reads its
  *                      output); 0: on every row -- bit-identical
  *   "patch_fused"      1 (default): the patch embedding of a tower whose geometry the fused kernel covers (patch 14, width 1024 / 1408) runs as ONE kernel

@@ -79,3 +79,69 @@ def test_repeated_launches_are_stable(eng):
     for cfg in A4:
         for _ in range(20):
             assert torch.equal(want, eng.op_gemm(A, W, tile_cfg=cfg))
+
+
+# ---- the pipelined-epilogue form (gvl_gemm4p.hip, tile_cfg 88): the drain + deferred program must reproduce the staged epilogue bit for bit ------------------------
+P_SHAPES = [(256, 256, 320), (300, 512, 384), (1000, 1408, 1408), (513, 4224, 320), (77, 288, 448), (24588, 1408, 384), (70000, 1024, 320), (3519, 3072, 3072), (40000, 2048, 576)]
+
+
+@pytest.mark.parametrize("M,N,K", P_SHAPES)
+def test_pipelined_plain_bias_rowscale_bit_identical(eng, M, N, K):
+    A, W, g = _ops(M, N, K, 5)
+    bias = torch.randn((N,), device=DEV, generator=g) * 0.5
+    rs = torch.rand((M,), device=DEV, generator=g) + 0.5
+    want = eng.op_gemm(A, W, tile_cfg=82)
+    got = eng.op_gemm(A, W, tile_cfg=88)
+    bad = (got != want).nonzero()
+    assert bad.numel() == 0, f"plain {M}x{N}x{K}: {bad.shape[0]} elements differ, first at {bad[0].tolist()}, last at {bad[-1].tolist()}"
+    assert torch.equal(eng.op_gemm(A, W, bias=bias, tile_cfg=82), eng.op_gemm(A, W, bias=bias, tile_cfg=88)), "bias"
+    assert torch.equal(eng.op_gemm_rows(A, W, rowscale=rs, tile_cfg=82), eng.op_gemm_rows(A, W, rowscale=rs, tile_cfg=88)), "rowscale"
+
+
+def test_pipelined_repeated_launches_are_stable(eng):
+    A, W, _ = _ops(20000, 2048, 1408, 3)
+    want = eng.op_gemm(A, W, tile_cfg=82)
+    for _ in range(20):
+        assert torch.equal(want, eng.op_gemm(A, W, tile_cfg=88))
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 1408, 1408), (5000, 512, 1024), (3000, 1024, 1216), (24588, 1408, 1088), (70000, 1024, 1024), (3519, 3072, 3072)])
+def test_pipelined_residual_gamma_row_statistics_bit_identical(eng, M, N, K):
+    A, W, g = _ops(M, N, K, 13)
+    bias = torch.randn((N,), device=DEV, generator=g) * 0.5
+    gam = torch.randn((N,), device=DEV, generator=g) * 0.1
+    resb = torch.randn((M, N), device=DEV, generator=g).to(bf)
+    for name, kw in {"resid": dict(resid=resb), "bias_gamma_resid": dict(bias=bias, gamma=gam, resid=resb)}.items():
+        want = eng.op_gemm(A, W, tile_cfg=82, **kw)
+        got = eng.op_gemm(A, W, tile_cfg=88, **kw)
+        bad = (got != want).nonzero()
+        assert bad.numel() == 0, f"{name} {M}x{N}x{K}: {bad.shape[0]} elements differ, first at {bad[0].tolist()}, last at {bad[-1].tolist()}"
+    for name, kw in {"rowsq": dict(), "rowsq_resid": dict(resid=resb), "rowsq_bias_gamma_resid": dict(bias=bias, gamma=gam, resid=resb)}.items():
+        wc, wq = eng.op_gemm_rows(A, W, want_rowsq=True, tile_cfg=82, **kw)
+        c, q = eng.op_gemm_rows(A, W, want_rowsq=True, tile_cfg=88, **kw)
+        assert torch.equal(wc, c), f"{name} {M}x{N}x{K}: output"
+        bad = (wq != q).nonzero()
+        assert bad.numel() == 0 and not torch.isnan(q).any(), f"{name} {M}x{N}x{K}: {bad.shape[0]} row statistics differ, first at {bad[0].tolist() if bad.numel() else None}"
+
+
+def test_pipelined_in_place_residual(eng):
+    """the residual stream may alias C (x += f(x) W): the deferred program reads a tile's residual rows before it stores them"""
+    A, W, g = _ops(9000, 1408, 1408, 21)
+    x = torch.randn((9000, 1408), device=DEV, generator=g).to(bf)
+    want = eng.op_gemm(A, W, resid=x, tile_cfg=82)
+    for _ in range(3):
+        assert torch.equal(want, eng.op_gemm(A, W, resid=x, tile_cfg=88))
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 1408, 1408), (5000, 512, 1024), (3000, 1024, 1216), (24588, 6144, 1088), (3519, 16384, 3072)])
+def test_pipelined_activations_bit_identical(eng, M, N, K):
+    A, W, g = _ops(M, N, K, 17)
+    bias = torch.randn((N,), device=DEV, generator=g) * 0.5
+    rs = torch.rand((M,), device=DEV, generator=g) + 0.5
+    cases = {"bias_gelu": (eng.op_gemm, dict(bias=bias, act=L.ACT_GELU)), "silu": (eng.op_gemm, dict(act=L.ACT_SILU_MUL)),
+             "rowscale_bias_gelu": (eng.op_gemm_rows, dict(rowscale=rs, bias=bias, act=L.ACT_GELU)), "rowscale_silu": (eng.op_gemm_rows, dict(rowscale=rs, act=L.ACT_SILU_MUL))}
+    for name, (fn, kw) in cases.items():
+        want = fn(A, W, tile_cfg=82, **kw)
+        got = fn(A, W, tile_cfg=88, **kw)
+        bad = (got != want).nonzero()
+        assert bad.numel() == 0, f"{name} {M}x{N}x{K}: {bad.shape[0]} elements differ, first at {bad[0].tolist()}, last at {bad[-1].tolist()}"

@@ -22,6 +22,14 @@ MODEL = [("clip.qkv", 27696, 3072, 1024, "bias"), ("clip.fc1", 27696, 4096, 1024
 EPIS = ["plain", "rs", "bias", "bias_qgelu", "rs_bias_gelu", "rs_silu", "resid_sq", "bias_gamma_resid_sq"]
 if WHAT == "model":
     SHAPES = MODEL
+elif WHAT == "p":          # the shapes the pipelined kernel serves so far
+    SHAPES = [("clip.qkv", 27696, 3072, 1024, "bias"), ("iv2.qkv", 24588, 4224, 1408, "rs"), ("phi.qkv", 14076, 9216, 3072, "rs"), ("sq8192", 8192, 8192, 8192, "plain")]
+elif WHAT == "p4":
+    SHAPES = [("iv2.qkv", 24588, 4224, 1408, "rs"), ("iv2.fc1", 24588, 6144, 1408, "rs_bias_gelu"), ("phi.gu", 14076, 16384, 3072, "rs_silu"), ("clip.qkv", 27696, 3072, 1024, "bias")]
+elif WHAT == "p3":
+    SHAPES = [("iv2.proj", 24588, 1408, 1408, "bias_gamma_resid_sq"), ("iv2.fc2", 24588, 1408, 6144, "bias_gamma_resid_sq"), ("phi.o", 14076, 3072, 3072, "resid_sq"), ("phi.down", 14076, 3072, 8192, "resid_sq")]
+elif WHAT == "p2":
+    SHAPES = [("clip.qkv", 27696, 3072, 1024, "bias"), ("iv2.qkv", 24588, 4224, 1408, "rs")]
 elif WHAT == "epi":
     SHAPES = [(f"{e}@K{k}", 24576, 2048, k, e) for e in EPIS for k in (192, 1408)]
 else:

@@ -881,7 +881,7 @@ def main(argv=None, engine_factory=None):
             traffic = int(pm["families"]["gemm"]["total_traffic_bytes"] / max(1.0, pm["clips_in_trace"] * per_clip))
     except Exception as e:
         traffic_note = f"no usable PMC summary under profiles/ ({type(e).__name__})"
-    roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)", "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS,
+    roofline = {"bound": "mfma", "kernel": "gemm_a4p_kernel / gemm_a4_kernel / gemm_pp_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)", "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "traffic_source": traffic_note if traffic is None else traffic_src + " (separate rocprofv3 --pmc passes of the serial_step bench on THIS source tree -- stamp matches; not measured by this run)",
                 "measured_on": (f"the launches of ONE timed step ({n_prof} clips: CLIP batched over {12 * n_prof} key frames, one ragged prefill, one batched decode) "

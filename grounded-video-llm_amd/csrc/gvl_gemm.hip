@@ -434,10 +434,11 @@ void gvl_gemm_set_a4(int v) { g_a4_mode = v; }
 //   pipelined 4-wave (88): the epilogues with real VALU / LDS work behind the bf16 rounding -- erf-GELU (98: +5 % over the 8-wave kernel, +10 % over the plain 4-wave
 //                          one), SwiGLU (67: +4.5 %), residual + row statistics (136: +3 ... +7 %; 184: +1 ... +5 %) -- that work rides in the next tile's MFMA gaps;
 //   plain 4-wave (86):     the store-only epilogues (64, 0, ...: +2 ... +4 %; pipelining them buys nothing: what remains exposed either way is the accumulator drain);
-//   8-wave ping-pong (82): CLIP's short-K bias / quick-GELU shapes (32, 33: the 4-wave forms lose 2 ... 4 % there) and everything the 4-wave kernels do not serve.
+//                          bias alone (32: +2 %, its slice read once per tile into dead fragment registers);
+//   8-wave ping-pong (82): CLIP's quick-GELU (33: the 4-wave forms lose 1 ... 2 % there), the f32-output epilogues and everything the 4-wave kernels do not serve.
 static int big_form_preferred(int epi) {
   switch (epi) {
-    case 98: case 67: case 136: case 184: return 88;
+    case 98: case 67: case 136: case 184: case 32: return 88;
     case 64: case 0: case 3: case 8: case 128: return 86;
     default: return 82;
   }

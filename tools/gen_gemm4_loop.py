@@ -149,9 +149,9 @@ def tile_asm(var):
     for ins in reads(0, X):
         L += ins
     L += body("FIRST", var)
-    L += [f"s_cmp_eq_u32 s{S_CNT}, 0", "s_cbranch_scc1 Lgvl_a4_pen_%=", "Lgvl_a4_loop_%=:"]
+    L += [f"s_cmp_eq_u32 s{S_CNT}, 0", "s_cbranch_scc1 .Lgvl_a4_pen_%=", ".Lgvl_a4_loop_%=:"]
     L += body("STEADY", var)
-    L += [f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", f"s_cmp_lg_u32 s{S_CNT}, 0", "s_cbranch_scc1 Lgvl_a4_loop_%=", "Lgvl_a4_pen_%=:"]
+    L += [f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", f"s_cmp_lg_u32 s{S_CNT}, 0", "s_cbranch_scc1 .Lgvl_a4_loop_%=", ".Lgvl_a4_pen_%=:"]
     L += body("PENULT", var)
     L += body("LAST", var)
     # the last MFMAs' results must be readable by the v_accvgpr_read of the epilogue (XDL write -> VALU read: 18 wait states for 16 passes)

@@ -497,33 +497,35 @@ def place(bodies, prog):
 
 
 # ---- drain --------------------------------------------------------------------------------------------------------------------------------------------------
+BIAS0 = 160               # the tile's 64 bias floats of this lane, (i, b) -> v[BIAS0 + 16 i + 4 b ...]: the fragment registers, dead once the main loop has ended
+
+
+def bias_reads(i_list):
+    return [f"ds_read_b128 {vr(BIAS0 + 16 * i + 4 * b)}, v{V_BADDR} offset:{(i * 32 + 8 * b) * 4}" for i in i_list for b in range(4)]
+
+
 def drain_row(epi, j):
     """a[block row j] -> (x row scale) (+ bias) -> bf16 pairs in P(j).  Batches of 4 pairs (8 reads, 4 packed ops, 4 converts): a dependent instruction sits >= 4
-    issue slots behind its producer -- one wave per SIMD has nobody else to cover a VALU dependency stall."""
+    issue slots behind its producer -- one wave per SIMD has nobody else to cover a VALU dependency stall.  The bias sits in registers (bias_reads)."""
     f = epi_flags(epi)
     L = []
     if "nodrain" in os.environ.get("GVL_A4P_LAB", ""):
         return L
     rsp, hi = V_RS + 2 * (j // 2), j % 2
     for i in range(NB):
-        for b0 in range(0, 4, 2):                      # two column groups per bias read burst (8 temporaries)
-            bias = {}
-            if f["bias"]:
-                for b in (b0, b0 + 1):
-                    bias[b] = T0 + 8 + 4 * (b - b0)
-                    L.append(f"ds_read_b128 {vr(bias[b])}, v{V_BADDR} offset:{(i * 32 + 8 * b) * 4}")
-                L.append("s_waitcnt lgkmcnt(0)")
+        for b0 in range(0, 4, 2):
             rd, op, cv = [], [], []
             for n, (b, q) in enumerate([(b, q) for b in (b0, b0 + 1) for q in range(2)]):
                 t = T0 + 2 * n
                 a0 = (4 * j + i) * 16 + 4 * b + 2 * q
+                bias = BIAS0 + 16 * i + 4 * b + 2 * q
                 rd += [f"v_accvgpr_read_b32 v{t}, a{a0}", f"v_accvgpr_read_b32 v{t + 1}, a{a0 + 1}"]
                 if f["rs"] and f["bias"]:
-                    op.append(f"v_pk_fma_f32 {vr(t, 2)}, {vr(t, 2)}, {vr(rsp, 2)}, {vr(bias[b] + 2 * q, 2)} op_sel:[0,{hi},0] op_sel_hi:[1,{hi},1]")
+                    op.append(f"v_pk_fma_f32 {vr(t, 2)}, {vr(t, 2)}, {vr(rsp, 2)}, {vr(bias, 2)} op_sel:[0,{hi},0] op_sel_hi:[1,{hi},1]")
                 elif f["rs"]:
                     op.append(f"v_pk_mul_f32 {vr(t, 2)}, {vr(t, 2)}, {vr(rsp, 2)} op_sel:[0,{hi}] op_sel_hi:[1,{hi}]")
                 elif f["bias"]:
-                    op.append(f"v_pk_add_f32 {vr(t, 2)}, {vr(t, 2)}, {vr(bias[b] + 2 * q, 2)}")
+                    op.append(f"v_pk_add_f32 {vr(t, 2)}, {vr(t, 2)}, {vr(bias, 2)}")
                 cv.append(f"v_cvt_pk_bf16_f32 v{preg(j, i, 2 * b + q)}, v{t}, v{t + 1}")
             L += rd + op + cv
     return L
@@ -534,6 +536,10 @@ def end_section(epi, stores):
     gaps of the LAST body's phase 3): a store is issued before the drain overwrites its registers, and no s_waitcnt vmcnt is near -- the next one is the end of phase 2
     of the next tile's first k-tile, > 4 k cycles away."""
     L = []
+    if epi & 32:
+        # bias of column blocks 2, 3 -> fragment set Y (blocks 0, 1 went to set X in the LAST body's phase 3, which multiplies out of Y): ONE exposed LDS round trip
+        # for the tile's 64 values instead of one per (block row, column group) -- 32 of them, ~3 k cycles
+        L += bias_reads([2, 3]) + ["s_waitcnt lgkmcnt(0)"]
     for j in range(MB):
         D = drain_row(epi, j)
         S = stores[j + 1] if j + 1 < MB else []
@@ -593,13 +599,16 @@ def tile_asm(epi, with_deferred):
     for b in bodies:
         for ph in b:
             L += ph.lines()
-    L += [f"s_cmp_eq_u32 s{S_CNT}, 0", "s_cbranch_scc1 Lgvl_a4p_pen_%=", "Lgvl_a4p_loop_%=:"]
+    L += [f"s_cmp_eq_u32 s{S_CNT}, 0", "s_cbranch_scc1 .Lgvl_a4p_pen_%=", ".Lgvl_a4p_loop_%=:"]
     for ph in body("STEADY", epi):
         L += ph.lines()
-    L += [f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", f"s_cmp_lg_u32 s{S_CNT}, 0", "s_cbranch_scc1 Lgvl_a4p_loop_%=", "Lgvl_a4p_pen_%=:"]
+    L += [f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", f"s_cmp_lg_u32 s{S_CNT}, 0", "s_cbranch_scc1 .Lgvl_a4p_loop_%=", ".Lgvl_a4p_pen_%=:"]
     for ph in body("PENULT", epi):
         L += ph.lines()
     last = body("LAST", epi)
+    if epi & 32:
+        for k, ins in enumerate(bias_reads([0, 1])):  # set X is dead in the last k-tile's phase 3 (no next k step to prefetch); the slice landed at the phase-2 wait
+            last[3].gaps[2 * k + 1 if k < 8 else 15].append(ins)
     for k, pair in enumerate(stores[0]):              # the finished tile's block row 0: behind the end-of-phase-2 wait of the last k-tile, in front of the drain
         last[3].gaps[(2 * k) % 16] += pair
     for ph in last:

@@ -930,10 +930,108 @@ def g_free(ns, tag):
                    "seeds": dict(clip=wseed + ".clip", iv2=wseed + ".iv2", proj=wseed + ".proj", llm=wseed + ".llm", sp=tag + ".sp", tp=tag + ".tp")}, f)
 
 
+def g_free2(ns, tag, n_free=16, min_rel=6e-2, max_tries=600):
+    """a free-running continuation that TESTS something.  The round-2 fixtures (<tag>_free.json) keep the clip's prompt and take whatever greedy does with
+    random-init weights: C1 falls into a 2-cycle after one step, C4 repeats one id -- after step 1 they check nothing, and C3's step 7 is a near tie.  Here the
+    prompt's TEXT TAIL (the 63 / 64 ids behind the video) is searched: seed t = 0, 1, ... gives a tail; the reference's fp32 prefix (its own encode_images +
+    prepare_multimodal_inputs, as in g_free) is prefilled ONCE up to the end of the visual tokens and its KV cache reused for every candidate, so a try costs one
+    short extend + n_free cached steps.  The first tail whose fp32 greedy continuation has (a) >= 12 distinct ids among 16 and no period <= 8, and (b) EVERY top-1 /
+    top-2 margin >= 6e-2 of that step's logit scale (three times the bf16 noise of a full-depth evaluation) is kept.  Fixture tests/golden/<tag>_free2.json: ids, the
+    continuation, per-step margins and scales, the bf16-emulated continuation of the oracle for the same prefix (equal by construction of (b); recorded, not assumed),
+    and the number of tails tried.  The GPU tests assert ALL ids equal, no near-tie clause."""
+    import copy
+    import json
+    import time
+    import gvl_oracle as O
+    L = ns.llava
+
+    class Skel(L.LLAVA_NEXT_VIDEO):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+
+        def get_input_embeddings(self):
+            return self.embed
+
+    phi = tag == "c1"
+    hid = 3072 if phi else 4096
+    wseed = "c0" if phi else "c3"
+    n_segs = 32 if tag == "c4" else 12
+    sk = Skel()
+    sk.llm, sk.dtype = ("phi3.5" if phi else "llama3"), torch.float32
+    sp = synth.exact_tensor(tag + ".sp", (1, n_segs, 3, 336, 336))
+    tp = synth.exact_tensor(tag + ".tp", (1, 8 * n_segs, 3, 224, 224))
+    cache_f = _feats_cache_name(tag, n_segs, (wseed + ".clip", wseed + ".iv2", wseed + ".proj"), sp, tp)
+    if not os.path.exists(cache_f):
+        g_free(ns, tag)                                   # computes and caches the reference's encode_images of this clip (and rewrites the old fixture identically)
+    feats = torch.load(cache_f)
+    if phi:
+        Wl = synth.llm_weights("phi3", seed="c0.llm", exact=True)
+        ocfg = O.LLMConfig("phi3", 3072, 8192, 32, 32, 32, 32366, 1e-5, 10000.0, 131072, 4096, *synth.longrope_factors(96))
+        ids0, hi = c0_ids(), 32000
+    else:
+        Wl = synth.llm_weights("llama", 4096, 14336, 32, 32, 8, 128558, True, seed="c3.llm", exact=True)
+        ocfg = O.LLMConfig("llama", 4096, 14336, 32, 32, 8, 128558, 1e-5, 500000.0, 8192, 0, None, None)
+        ids0, hi = c3_ids(), 128000
+    sk.embed = torch.nn.Embedding.from_pretrained(Wl["model.embed_tokens.weight"])
+    e = Wl["model.embed_tokens.weight"]
+    slot = ids0.index(-200)
+    n_tail = len(ids0) - slot - 1
+    tid = torch.tensor([ids0])
+    emb, _, _ = sk.prepare_multimodal_inputs(tid, tid.clone(), torch.ones_like(tid), feats, ["vid"])       # the reference's own splice
+    S = emb.shape[1]
+    Pn = S - n_tail                                          # rows up to the end of the visual tokens: the same for every tail
+    t0 = time.time()
+    with torch.no_grad():
+        base = [None] * ocfg.layers
+        O.llm_forward(ocfg, Wl, emb[0, :Pn], False, base, 0, last_only=True)
+        print(f"[{tag} free2] prefix of {Pn} rows prefilled in {time.time() - t0:.0f}s", flush=True)
+
+        def run(tail, emu=False, cache0=base):
+            c = [[k, v] for k, v in cache0]
+            logits = O.llm_forward(ocfg, Wl, e[torch.tensor(tail)], emu, c, Pn, last_only=True)
+            out, margins, scales, n = [], [], [], S
+            for _ in range(n_free):
+                top2 = torch.topk(logits[-1], 2)
+                tok = int(top2.indices[0])
+                out.append(tok); margins.append(float(top2.values[0] - top2.values[1])); scales.append(float(logits[-1].abs().max()))
+                if len(out) == n_free:
+                    break
+                logits = O.llm_forward(ocfg, Wl, e[tok][None], emu, c, n, last_only=True)
+                n += 1
+            return out, margins, scales
+
+        def periodic(o):
+            return any(all(o[i] == o[i + p] for i in range(4, len(o) - p)) for p in range(1, 9))
+
+        found = None
+        for t in range(max_tries):
+            tail = np.random.RandomState(1000 + t).randint(3, hi, size=n_tail).tolist()
+            out, margins, scales = run(tail)
+            rel = [m / s for m, s in zip(margins, scales)]
+            ok = len(set(out)) >= 12 and not periodic(out) and min(rel) >= min_rel
+            print(f"[{tag} free2] tail seed {t}: distinct {len(set(out))} min margin/scale {min(rel):.3f} {'ACCEPT' if ok else ''} ({time.time() - t0:.0f}s)", flush=True)
+            if ok:
+                found = (t, tail, out, margins, scales)
+                break
+        assert found, "no tail found: raise max_tries"
+        t, tail, out, margins, scales = found
+        # the oracle's bf16-emulated evaluation of the same clip (prefix and steps with the reference's bf16 rounding points)
+        bcache = [None] * ocfg.layers
+        O.llm_forward(ocfg, Wl, emb[0, :Pn], True, bcache, 0, last_only=True)
+        out_b, _, _ = run(tail, emu=True, cache0=bcache)
+    ids = ids0[:slot + 1] + tail
+    with open(os.path.join(OUT, tag + "_free2.json"), "w") as f:
+        json.dump({"tag": tag, "ids": ids, "S": S, "free_ids": out, "margins": margins, "scales": scales, "free_ids_bf16emu": out_b, "tail_seed": 1000 + t, "tails_tried": t + 1,
+                   "criteria": {"n_free": n_free, "min_margin_over_scale": min_rel, "min_distinct": 12, "max_period_excluded": 8},
+                   "seeds": dict(clip=wseed + ".clip", iv2=wseed + ".iv2", proj=wseed + ".proj", llm=wseed + ".llm", sp=tag + ".sp", tp=tag + ".tp")}, f)
+    print(f"[{tag} free2] kept tail seed {1000 + t}: ids {out} bf16-emulated {out_b} equal {out == out_b}", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["int", "clip", "iv2", "phi3", "llama", "glue", "pre", "train"]
     ns = ref_shims.load_reference() if any(w != "pre" for w in which) else None
     for w in which:
         {"int": g_int, "clip": g_clip, "iv2": g_iv2, "phi3": g_phi3, "llama": g_llama, "glue": g_glue, "pre": g_pre, "train": g_train, "c0": g_c0,
          "llama_full": g_llama_full, "lora": g_lora, "c3": g_c3, "c4": g_c4, "c1": g_c1,
-         "free_c1": lambda n: g_free(n, "c1"), "free_c3": lambda n: g_free(n, "c3"), "free_c4": lambda n: g_free(n, "c4")}[w](ns)
+         "free_c1": lambda n: g_free(n, "c1"), "free_c3": lambda n: g_free(n, "c3"), "free_c4": lambda n: g_free(n, "c4"),
+         "free2_c1": lambda n: g_free2(n, "c1"), "free2_c3": lambda n: g_free2(n, "c3"), "free2_c4": lambda n: g_free2(n, "c4")}[w](ns)

@@ -125,6 +125,11 @@ class Dev:
         return g
 
 
+# segments per clip: 12 = the 96-frame configurations (BASELINE configs[1], [2]); GVL_BENCH_SEGS=32 = the 256-frame dense-captioning clip of configs[4] (the CPU plumbing
+# tests run its 8-rank split; every published line is a 12-segment line and says so in config.workload)
+SEGS = int(os.environ.get("GVL_BENCH_SEGS", "12"))
+
+
 def build_engine(dev, frames_per_seg=8, max_segs=12, new_tokens=12, clips_per_step=1, kv_pages=None):
     """kv_pages None: a pool that just holds the step's clips (tests share the GPU with other engines); 0: sized from the free HBM
     once the weights are resident (gvl_finalize_weights) -- what bench.py's main uses."""
@@ -185,20 +190,20 @@ class Stepper:
         self.pool = max(1, pool)
         self.cursor = 0
         fps = geo.frames_per_seg
-        px = [make_pixels(self.D, 42 + 1009 * i + 7919 * rank, 12, fps, hw) for i in range(self.pool)]
+        px = [make_pixels(self.D, 42 + 1009 * i + 7919 * rank, SEGS, fps, hw) for i in range(self.pool)]
         self.sp_pool = torch.cat([p[0] for p in px], 0)          # [pool * 12, 3, 336, 336]: a window of cps clips is one contiguous slice
         self.tp_pool = torch.cat([p[1] for p in px], 0)
         self.prompts = [make_prompt(77 + 31 * i + 7919 * rank) for i in range(self.pool)]
         if world > 1:
             # clip c's segment block b goes to rank (b + c) % world (dist.rotated_encode_plan): every rank encodes exactly 12 segments
-            self.mine = gdist.rotated_encode_plan(12, rank, world)
-            self.gather = gdist.rotated_gather_index(12, rank, world)
-            assert sum(h - l for _, l, h in self.mine) == 12
+            self.mine = gdist.rotated_encode_plan(SEGS, rank, world)
+            self.gather = gdist.rotated_gather_index(SEGS, rank, world)
+            assert sum(h - l for _, l, h in self.mine) == SEGS
 
     # ---- pool access -------------------------------------------------------------------------------------------
     def px(self, i):
         i %= self.pool
-        return self.sp_pool[i * 12:(i + 1) * 12], self.tp_pool[i * 12:(i + 1) * 12]
+        return self.sp_pool[i * SEGS:(i + 1) * SEGS], self.tp_pool[i * SEGS:(i + 1) * SEGS]
 
     def window(self, cps):
         """pool indices of the next cps clips; the pool size is a multiple of cps, so the window is one contiguous slice"""
@@ -222,7 +227,7 @@ class Stepper:
         recv = torch.empty((self.world * send.shape[0], send.shape[1]), dtype=bf, device=self.dev)
         recv = self._allgather(send, recv).view(self.world, cps, rows, -1)
         if all_clips:                                                  # the rank-0-LLM plan: every clip of the round, in clip order
-            idx = [gdist.rotated_gather_index(12, c, self.world) for c in range(self.world)] if self.world > 1 else [[(0, 0, rows // self.L)]]
+            idx = [gdist.rotated_gather_index(SEGS, c, self.world) for c in range(self.world)] if self.world > 1 else [[(0, 0, rows // self.L)]]
             return [[torch.cat([recv[src, c, off * self.L:(off + n) * self.L] for src, off, n in g], 0) for g in idx] for c in range(cps)]
         gather = self.gather if self.world > 1 else [(0, 0, rows // self.L)]
         return [torch.cat([recv[src, c, off * self.L:(off + n) * self.L] for src, off, n in gather], 0) for c in range(cps)]   # clip == rank, segment order
@@ -244,8 +249,8 @@ class Stepper:
         sp, tp = self.px(i)
         if self.h2d:                                                    # extra (untimed for `value`): pixels arrive over PCIe
             k = i % self.pool
-            sp.copy_(self.sp_host[k * 12:(k + 1) * 12], non_blocking=True)
-            tp.copy_(self.tp_host[k * 12:(k + 1) * 12], non_blocking=True)
+            sp.copy_(self.sp_host[k * SEGS:(k + 1) * SEGS], non_blocking=True)
+            tp.copy_(self.tp_host[k * SEGS:(k + 1) * SEGS], non_blocking=True)
         return self._exchange(self.eng.encode_segments(sp, tp))   # [12*L, hidden]
 
     def encode_multi(self, idx):
@@ -256,7 +261,7 @@ class Stepper:
             if self.h2d:
                 return [self.encode(i) for i in idx]
             return self._exchange_multi([self.eng.encode_segments(*self.px(i)) for i in idx])
-        lo, hi = idx[0] * 12, (idx[-1] + 1) * 12
+        lo, hi = idx[0] * SEGS, (idx[-1] + 1) * SEGS
         if self.h2d:
             self.sp_pool[lo:hi].copy_(self.sp_host[lo:hi], non_blocking=True)
             self.tp_pool[lo:hi].copy_(self.tp_host[lo:hi], non_blocking=True)
@@ -267,8 +272,8 @@ class Stepper:
         if nb >= len(idx):                                              # the whole step in ONE call: no torch.cat (of one tensor it is a 554 MB device copy)
             vf = self.eng.iv2_encode(self.tp_pool[lo:hi])
         else:
-            vf = torch.cat([self.eng.iv2_encode(self.tp_pool[(idx[c]) * 12:(idx[min(c + nb, len(idx)) - 1] + 1) * 12]) for c in range(0, len(idx), nb)], 0) if nb > 1 else None
-        return self._exchange_multi([self.eng.build_visual(cf[c * 12:(c + 1) * 12], vf[c * 12:(c + 1) * 12] if vf is not None else self.eng.iv2_encode(self.px(i)[1]))
+            vf = torch.cat([self.eng.iv2_encode(self.tp_pool[(idx[c]) * SEGS:(idx[min(c + nb, len(idx)) - 1] + 1) * SEGS]) for c in range(0, len(idx), nb)], 0) if nb > 1 else None
+        return self._exchange_multi([self.eng.build_visual(cf[c * SEGS:(c + 1) * SEGS], vf[c * SEGS:(c + 1) * SEGS] if vf is not None else self.eng.iv2_encode(self.px(i)[1]))
                                      for c, i in enumerate(idx)])
 
     def stage_times(self, prog=None):
@@ -334,18 +339,18 @@ class Stepper:
         on every rank: pixels from a rank-independent seed), ONE all-gather of the token blocks, prefill + greedy decode on rank 0
         (the other ranks wait at the caller's barrier).  Returns rank 0's ids."""
         if not hasattr(self, "_shared_px"):
-            self._shared_px = make_pixels(self.D, 4242, 12, self.geo.frames_per_seg, (self.sp_pool.shape[-1], self.tp_pool.shape[-1]))
+            self._shared_px = make_pixels(self.D, 4242, SEGS, self.geo.frames_per_seg, (self.sp_pool.shape[-1], self.tp_pool.shape[-1]))
             self._shared_prompt = make_prompt(4242)
         sp, tp = self._shared_px
-        lo, hi = gdist.my_shard(12, self.rank, self.world)
+        lo, hi = gdist.my_shard(SEGS, self.rank, self.world)
         local = self.eng.encode_segments(sp[lo:hi], tp[lo:hi]) if hi > lo else torch.empty((0, self.geo.hidden), dtype=bf, device=self.dev)
         if self.world > 1:
             if self.exchange == "gvl":
-                vis = gdist.allgather_visual(local, 12, self.L, gather=self.eng.allgather_visual)
+                vis = gdist.allgather_visual(local, SEGS, self.L, gather=self.eng.allgather_visual)
             elif torch.distributed.get_backend() == "gloo" and local.device.type != "cpu":
-                vis = gdist.allgather_visual(local.cpu(), 12, self.L).to(self.dev)
+                vis = gdist.allgather_visual(local.cpu(), SEGS, self.L).to(self.dev)
             else:
-                vis = gdist.allgather_visual(local, 12, self.L)
+                vis = gdist.allgather_visual(local, SEGS, self.L)
         else:
             vis = local
         if self.rank != 0:
@@ -646,7 +651,7 @@ def main(argv=None, engine_factory=None):
     if engine_factory is not None:
         eng, geo = engine_factory(dev)
     else:
-        eng, geo = build_engine(dev, max_segs=12 * cps if clip_batch else 12, new_tokens=args.new_tokens, clips_per_step=cps,
+        eng, geo = build_engine(dev, max_segs=SEGS * cps if clip_batch else SEGS, new_tokens=args.new_tokens, clips_per_step=cps,
                                 kv_pages=int(os.environ.get("GVL_BENCH_KV_PAGES", "0")))
     for kv in args.debug_set:
         k, v = kv.split("=")
@@ -770,7 +775,7 @@ def main(argv=None, engine_factory=None):
             torch.distributed.all_gather_object(gathered_ids, list(mine_ids))
             r0 = {"clips_per_s": round(world * args.steps / dtr, 4), "ms_per_round": round(1e3 * dtr / args.steps, 2), "clips_per_round": world,
                   "ids_match_the_per_rank_llm": None if rank != 0 else bool(outs_r0 is not None and [list(o) for o in outs_r0] == gathered_ids),
-                  "plan": f"{world} ranks encode 12 segments each per round (rotated shard of the round's {world} clips), one all-gather, rank 0 prefills the "
+                  "plan": f"{world} ranks encode {SEGS} segments each per round (rotated shard of the round's {world} clips), one all-gather, rank 0 prefills the "
                           f"{world} clips as one ragged pass and decodes them together while every rank encodes the next round"}
             prog.partial["rank0_llm_pipelined"] = r0
             st.cursor = (st.cursor + cps - 1) // cps * cps            # the rounds advanced the pool cursor one clip at a time: back onto a window boundary
@@ -981,7 +986,7 @@ def main(argv=None, engine_factory=None):
                                       f"{args.new_tokens} greedy tokens, {cps} clip{'s' if cps > 1 else ''} per GPU per step" +
                                       ((f" ({2 * cps} clips in flight per GPU: the vision encode of the next {cps} overlaps the ragged prefill + " +
                                         ("batched greedy decode" if cps > 1 else "decode") + f" of the current {cps}" +
-                                        (f"; CLIP tower batched over the {12 * cps} key frames of a step" if clip_batch else "") + ")") if args.mode == "pipelined" else ""),
+                                        (f"; CLIP tower batched over the {SEGS * cps} key frames of a step" if clip_batch else "") + ")") if args.mode == "pipelined" else ""),
                           "clips_per_step": cps, "ms_per_clip": round(1e3 * dt / (args.steps * cps), 2), "prefill_len_max": S, "visual_tokens": 12 * st.L,
                           "distinct_clips_resident": st.pool,
                           "parallelism": "1 GPU" if world == 1 else f"frame-batch sharded over {world} GPUs + all-gather of visual tokens, LLM replica per clip"},

@@ -126,3 +126,25 @@ def test_bench_exchange_through_the_engines_own_communicator_and_rank0_llm_mode(
     r0 = d["rank0_llm_pipelined"]
     assert r0["clips_per_s"] > 0 and r0["clips_per_round"] == 2 and r0["ids_match_the_per_rank_llm"] is True, r0
     assert d["n_ranks_seen_by_rccl"] == 2 and d["gvl_allgather_matches_rank_order"] is True
+
+
+@pytest.mark.parametrize("segs", [12, 32])
+def test_bench_main_at_world_8_through_the_rotated_plan_and_the_rank0_llm_mode(segs):
+    """the configurations nobody has run on 8 devices yet, at WORLD 8 on CPU (gloo, stub engine): 12 segments = BASELINE configs[2] (blocks of
+    2,2,2,2,1,1,1,1 rotated per clip) and 32 segments = configs[4] (4 per rank), through the rotated encode plan, the one all-gather per step over all clips of the
+    round, the sharded single clip and the rank-0-LLM pipelined mode; ids must match the per-rank plan clip by clip and the line must carry the 8 per-rank stage
+    records a first hardware failure would be diagnosed from."""
+    if __import__("torch").cuda.is_available():
+        pytest.skip("plumbing test is for the GPU-less container")
+    outs = _run(8, ("--steps", "2", "--warmup", "1", "--new-tokens", "4", "--exchange", "gvl"), {"GVL_STUB_COMM": "1", "GVL_BENCH_SEGS": str(segs)}, timeout=600)
+    for rc, o, e in outs:
+        assert rc == 0, e[-2000:]
+    lines = [l for l in outs[0][1].splitlines() if l.startswith("{")]
+    assert len(lines) == 1, outs[0][1]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["value"] > 0 and d["ids_match_serial"] is True and d["scaling"] == "weak"
+    assert [p["rank"] for p in d["per_rank_stage_ms"]] == list(range(8))
+    r0 = d["rank0_llm_pipelined"]
+    assert r0["clips_per_s"] > 0 and r0["clips_per_round"] == 8 and r0["ids_match_the_per_rank_llm"] is True, r0
+    assert d["n_ranks_seen_by_rccl"] == 8 and d["gvl_allgather_matches_rank_order"] is True
+    assert d["single_clip_latency_ms_sharded"] > 0

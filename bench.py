@@ -22,9 +22,11 @@ N > 1 (one process per GPU, RCCL), two plans, both reported:
 A watchdog thread turns a hung collective into a JSON line that names the stage every rank was in (`hang`), instead of a silent
 time-out; `n_ranks_seen_by_rccl` is ncclCommCount of a communicator libgvl itself builds over all ranks (gvl_comm_init).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (the bf16 MFMA GEMM), measured live with HIP events
-on the launch stream in one extra profiled ONE-CLIP serial pass (keys say `per_clip_serial`); `cpu_baseline` is the CPU oracle
-timed on a bounded sample on the host cores (rank 0, N == 1 only).
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (the bf16 MFMA GEMM: gemm_a4p / gemm_a4 / gemm_pp / gemm_bf16 kernels), measured
+live with HIP event pairs around every GEMM launch of ONE extra profiled step of the timed kind (8 clips: the launches back to back on one stream;
+`roofline.gemm_ms_per_clip`, `launches_in_profiled_pass`); the one-clip-alone figure of rounds 1-2 is kept under `roofline.one_clip_serial`.
+`roofline.achieved` = 77.59 TFLOP algorithmic GEMM work per clip (78.1 un-padded 2 M N K, minus the 0.53 of the last decoder layer's MLP that a
+prefill without a loss request does not execute) / that time.  `cpu_baseline` is the CPU oracle timed on a bounded sample on the host cores (rank 0, N == 1 only).
 """
 from __future__ import annotations
 

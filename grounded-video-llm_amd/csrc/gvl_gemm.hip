@@ -331,12 +331,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
     u32x2_t ebv, egv;
     float rsc[MB];                                  // fused RMSNorm, consumer side: the row scale of this lane's MB rows, requested with the first k-tile
     char* bgw = smem + PP_BG_OFF + wave * TN * 8;   // bias / gamma scratch of this wave (above the ring and the staging slices)
-#ifdef GVL_PP_ENERGY_LAB
-    bf16x8_t wf[NB], af[MB];
-    u32x4_t lab_dmy[8];
-#pragma unroll
-    for (int q_ = 0; q_ < 8; ++q_) lab_dmy[q_] = u32x4_t{0u, 0u, 0u, 0u};
-#endif
     for (int t = 0; t < nk; ++t) {
       const char* sb = smem + (t & 1) * STAGE_BYTES;
       const bool more = t + 1 < nk;
@@ -347,37 +341,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
           if (ph == 0 && t == 0 && G::has_rowscale) stg_request_rowscale<MB>(a, m0 + wm * TM, lane, rsc);
           if (ph == 0 && !more && PRE_RES) stg_request_resid<MB, NB, EPI_G>(a, m0 + wm * TM, n0 + wn * TN, lane, 0, rv);
         }
-#ifndef GVL_PP_ENERGY_LAB
         bf16x8_t wf[NB], af[MB];
-#endif
         const int coff = ((ph * 2 + h) ^ swz) << 4;
-#ifdef GVL_PP_ENERGY_LAB          // LAB (wrong results, timing only): bit 0 = fragment reads in phase 0 only (1/4 of the LDS reads), bit 1 = no DMA after the first tile
-        if (!(GVL_PP_ENERGY_LAB & 1) || ph == 0) {
-#endif
 #pragma unroll
         for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
 #pragma unroll
         for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
-#ifdef GVL_PP_ENERGY_LAB
-        }
-        if (!(GVL_PP_ENERGY_LAB & 2))
-#endif
-#ifdef GVL_PP_ENERGY_LAB          // bit 2: the DMA always re-reads k-tile (t & 3): same instruction stream and L2 -> LDS bytes, but every line is an L1 / L2 hit
-        if ((GVL_PP_ENERGY_LAB & 8) && ph < 2 && more) {   // bit 3: the same bytes from L2, but into VGPRs (discarded) instead of LDS: the L2 -> CU transfer without the LDS write
-          const bf16_t* sbl = (ph == 0 ? a.W : a.A) + (t + 1) * BK;
-#pragma unroll
-          for (int q_ = 0; q_ < 4; ++q_)
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(lab_dmy[ph * 4 + q_]) : "v"(voff[ph * 4 + q_]), "s"(sbl) : "memory");
-        } else
-        if (ph < 2 && more) stage_half((t + 1) & 1, ((GVL_PP_ENERGY_LAB & 4) ? ((t + 1) & 3) : (t + 1)) * BK, ph);
-        if ((GVL_PP_ENERGY_LAB & 8) && ph == 3) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int q_ = 0; q_ < 8; ++q_) asm volatile("" :: "v"(lab_dmy[q_]));
-        }
-#else
         if (ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
-#endif
         if (ph == 3 && (more || !STAGED)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last k-tile: no DMA pending, residual stays in flight
         if constexpr (STAGED) {
           if (ph == 3 && t == 0 && (G::has_bias || G::has_gamma)) stg_store_bias<NB, EPI_G>(bgw, lane, ebv, egv);

@@ -232,7 +232,7 @@ int iv2_encode(gvl_ctx* ctx, const float* px, int n, bf16_t* out, hipStream_t st
   // kernel turns them into rs[m] = rsqrt(mean + eps), and the consuming GEMM (qkv / fc1) reads the RAW stream x with the norm weight folded into its
   // weight and multiplies its accumulator rows by rs (GemmArgs.rowscale).  Block 0's first norm has no producer GEMM and keeps the pass.
   const int NBLK = C / 64;
-  const bool nf = ctx->dbg.norm_fused && C % 64 == 0 && !ctx->vb.empty() && ctx->vb[0].qkvw_f;
+  const bool nf = ctx->dbg.norm_fused && C % 64 == 0 && (3 * C) % 16 == 0 && f.iv2_inter % 16 == 0 && !ctx->vb.empty() && ctx->vb[0].qkvw_f;   // widths the staged (whole-row) epilogue takes
   AALLOC(sq, float, (size_t)M * (nf ? NBLK : 1)); AALLOC(nrs, float, (size_t)M);
   // (Taking InternVideo2's q / k RMSNorm statistics the same way -- row sums of squares of the qkv GEMM's 3 C outputs, qkv_post reading k only -- was built
   //  and measured a net loss: +0.8 ms of GEMM per clip for the 66 blocks per row, two more small launches per block, and a K pass that is bound by its
@@ -362,7 +362,7 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
   // fused RMSNorm (see iv2_encode): o_proj / down_proj leave the row statistics of the new residual stream, qkv_proj / gate_up_proj consume the raw
   // stream with the norm weight folded in and scale their accumulator rows; layer 0's input norm keeps the pass
   const int NBLK = Hd / 64;
-  const bool nf = ctx->dbg.norm_fused && Hd % 64 == 0 && !ctx->ll.empty() && ctx->ll[0].qkvw_f;
+  const bool nf = ctx->dbg.norm_fused && Hd % 64 == 0 && ((f.heads + 2 * f.kv_heads) * ctx->l_Dr) % 16 == 0 && (2 * f.inter) % 16 == 0 && !ctx->ll.empty() && ctx->ll[0].qkvw_f;   // widths the staged epilogue takes
   LALLOC(sq, float, (size_t)M * (nf ? NBLK : 1)); LALLOC(nrs, float, (size_t)M);
   const bf16_t* tail_rows = nullptr;                  // [nb][Hd]: the sequences' last rows after the last layer, when only they went through its MLP
   // one (RoPE + KV append, attention) launch for the whole batch when the lengths agree, one per sequence otherwise
@@ -602,12 +602,15 @@ int decode_step_replay(gvl_ctx* ctx, Seq* const* sqs, int B, hipStream_t st, Ste
   if (!ctx->dbg.decode_graph || ctx->prof || st == nullptr || sg.failed) return decode_step(ctx, sqs, B, st);
   if (!sg.e) {
     if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); sg.failed = true; return decode_step(ctx, sqs, B, st); }
+    bool was_dirty[GVL_MAX_DECODE_BATCH];                      // upload_table clears table_dirty when it ENQUEUES the upload -- inside a capture that is a recording only
+    for (int b = 0; b < B; ++b) was_dirty[b] = sqs[b]->table_dirty;
     const int rc = decode_step(ctx, sqs, B, st);               // recorded, not executed; the host counters advance once
     const hipError_t ce = hipStreamEndCapture(st, &sg.g);
     if (rc) return rc;
     if (ce != hipSuccess || hipGraphInstantiate(&sg.e, sg.g, nullptr, nullptr, 0) != hipSuccess) {
       (void)hipGetLastError(); sg.failed = true; sg.e = nullptr;
-      for (int b = 0; b < B; ++b) { sqs[b]->pos -= 1; sqs[b]->n_gen -= 1; }
+      // the capture never ran: the block tables it would have written are still unwritten -- the eager step below must upload them
+      for (int b = 0; b < B; ++b) { sqs[b]->pos -= 1; sqs[b]->n_gen -= 1; if (was_dirty[b]) sqs[b]->table_dirty = true; }
       return decode_step(ctx, sqs, B, st);
     }
     HIPCHK(ctx, hipGraphLaunch(sg.e, st));
@@ -853,14 +856,29 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
     }
   }
   // fused RMSNorm (round 5): the norm weight is folded into the projection that consumes the norm -- W' = bf16(W diag(gamma)), a second copy beside the
-  // original (the unfused path, gvl_debug_set("norm_fused", 0), and the decode tile copies keep reading the original); 1.1 GB for InternVideo2-1B,
-  // 5 GB for Phi-3.5, 9 GB for Llama-3-8B of the 288 GB
+  // original (the unfused path, gvl_debug_set("norm_fused", 0), and the decode tile copies keep reading the original).  Memory: the prefill copies are 1.1 GB
+  // (InternVideo2-1B) / 5 GB (Phi-3.5) / 9 GB (Llama-3-8B); with bf16 decode weights their decode tile copies and the folded lm_head come on top: ~10 GB
+  // (Phi-3.5) / ~18 GB (Llama-3-8B) of the 288 GB in all.  They are an OPTIMISATION: env GVL_NORM_FOLD=0 skips them, and a failed allocation releases every
+  // folded copy made so far and carries on -- the launch sequences test the *_f pointers and take the separate norm pass.
   if (!ctx->nf_allocs.empty()) HIPCHK(ctx, hipDeviceSynchronize());
   for (void* p : ctx->nf_allocs) if (p) hipFree(p);
   ctx->nf_allocs.clear();
+  bool nf_on = !(getenv("GVL_NORM_FOLD") && atoi(getenv("GVL_NORM_FOLD")) == 0);
+  auto nf_give_up = [&]() {                          // out of memory: no folded copy at all (a half-folded model would mix the two rounding orders)
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();                     // fold / retile kernels may still be writing the copies
+    for (void* p : ctx->nf_allocs) if (p) hipFree(p);
+    ctx->nf_allocs.clear();
+    for (auto& w : ctx->vb) w.qkvw_f = w.fc1w_f = nullptr;
+    for (auto& w : ctx->ll) w.qkvw_f = w.guw_f = w.qkvd_f = w.gud_f = nullptr;
+    ctx->l_headd_f = nullptr;
+    nf_on = false;
+    fprintf(stderr, "libgvl: no memory for the norm-folded weight copies: RMSNorm runs as separate passes\n");
+  };
   auto folded = [&](const bf16_t* W, const bf16_t* gamma, long rows, int cols, const bf16_t** out) -> int {
+    if (!nf_on) return 0;
     void* q = nullptr;
-    if (hipMalloc(&q, (size_t)rows * cols * 2) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, GVL_ERR_OOM, "hipMalloc(norm-folded weight copy) failed"); }
+    if (hipMalloc(&q, (size_t)rows * cols * 2) != hipSuccess) { nf_give_up(); return 0; }
     ctx->nf_allocs.push_back(q);
     if (gvl_launch_fold_gamma(W, gamma, (bf16_t*)q, rows, cols, nullptr)) return fail(ctx, GVL_ERR_HIP, "fold_gamma launch failed");
     *out = (const bf16_t*)q;
@@ -989,10 +1007,11 @@ int gvl_finalize_weights(gvl_ctx* ctx) {
       // the decode path's copies of the folded weights (bf16 decode weights only: a quantised format would quantise gamma * W, another model than
       // the prefill's): tile order like every decode weight; plus lm_head with the final norm weight
       ctx->l_headd_f = nullptr;
-      if (ctx->decode_mfma && !ctx->fp8) {
+      if (ctx->decode_mfma && !ctx->fp8 && nf_on) {
         auto tiled_f = [&](const bf16_t* W, int N, int K, int dr, int nqk, const bf16_t** out) -> int {
+          if (!nf_on || !W) return 0;
           void* p = nullptr;
-          if (hipMalloc(&p, (size_t)((N + 15) / 16) * 16 * K * 2) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, GVL_ERR_OOM, "hipMalloc(folded decode weight copy) failed"); }
+          if (hipMalloc(&p, (size_t)((N + 15) / 16) * 16 * K * 2) != hipSuccess) { nf_give_up(); return 0; }
           ctx->nf_allocs.push_back(p);
           if (gvl_retile_decode_weight(W, (bf16_t*)p, N, K, dr, nqk, nullptr)) return fail(ctx, GVL_ERR_HIP, "retile launch failed");
           *out = (const bf16_t*)p;

@@ -125,7 +125,10 @@ int gvl_seq_free(gvl_ctx* ctx, int seq_id);
 /* Paged KV pool of this ctx (replaces transformers' DynamicCache, models/modeling_phi3.py:1291 [ext]): pages of 64 tokens over all
  * layers.  cfg.kv_pages > 0 fixes the pool size at gvl_create; cfg.kv_pages <= 0 sizes it in gvl_finalize_weights from the HBM
  * that is free once the weights are resident (env GVL_KV_FRACTION, default 0.85 of it, minus 4 GiB) -- on a 288 GB MI355X about
- * 670 k Phi-3.5 tokens.  Any out pointer may be NULL. */
+ * 670 k Phi-3.5 tokens.  Any out pointer may be NULL.
+ * The fused RMSNorm (gvl_debug_set "norm_fused") keeps norm-folded second copies of qkv / fc1 (InternVideo2) and qkv_proj / gate_up_proj / lm_head (LLM;
+ * with bf16 decode weights also their decode tile copies): about 1.1 GB + 10 GB (Phi-3.5) / 18 GB (Llama-3-8B).  env GVL_NORM_FOLD=0 skips them (the norms
+ * then run as separate passes); a failed allocation does the same by itself -- finalize does not fail for them. */
 /* Prefix sharing (the reference asks three questions about ONE video, inference.py:178-182: the prompts share the system prompt and the
  * 3 420 visual tokens).  gvl_seq_fork makes a new sequence whose first n_tokens (a multiple of 64 = whole KV pages, <= the source's
  * tokens) ARE the source's pages -- referenced, not copied; a page returns to the pool when its last holder is freed -- and reserves

@@ -14,7 +14,7 @@ from grounded_video_llm_amd.build import source_sha16  # noqa: E402
 
 # every kernel that bench.py times under GVL_PROF_GEMM / GVL_PROF_ATTN belongs to the family it is divided by (the fused patch embedding is
 # timed as GEMM and counted in its launches; InternVideo2's attention runs attn_iv2_pipe_kernel)
-FAMILIES = [("gemm", ("gemm_pp_kernel", "gemm_bf16_kernel", "patch_embed_kernel")), ("attention", ("attn_fwd_kernel", "attn_iv2_pipe_kernel")),
+FAMILIES = [("gemm", ("gemm_pp_kernel", "gemm_bf16_kernel", "gemm_a4_kernel", "gemm_a4p_kernel", "patch_embed_kernel")), ("attention", ("attn_fwd_kernel", "attn_iv2_pipe_kernel")),
             ("decode_attention", ("decode_attn_kernel",)), ("gemv", ("gemv_kernel", "dgemm_kernel"))]
 
 

@@ -28,6 +28,11 @@ import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# Code placement of the hand-written stream (MI355X_MICROARCH.md, two-waves item 8): the steady loop's head sits on a 64-byte boundary (measured, same box,
+# profiles/r06_gemm4_placement.txt: the pipelined kernel's InternVideo2 qkv shape 257.0 -> 249.0 us, the others 0.3 ... 0.7 %; 256-byte alignment and a 4-byte shift
+# of the whole statement move nothing further).  LAB: GVL_A4_ALIGN=N overrides (0 = none), GVL_A4_SHIFT=k opens the statement with k s_nop (4 bytes each)
+ALIGN_LOOP = [f".p2align {os.environ.get('GVL_A4_ALIGN', '6')}"] if os.environ.get("GVL_A4_ALIGN", "6") != "0" else []
+SHIFT = ["s_nop 0"] * int(os.environ.get("GVL_A4_SHIFT", "0"))
 OUT = os.path.join(HERE, "..", "grounded-video-llm_amd", "csrc", "gvl_gemm4_loop.inc")
 
 MB, NB = 4, 4
@@ -137,7 +142,7 @@ VARIANTS = {
 
 
 def tile_asm(var):
-    L = [f"s_mov_b32 s{S_M0}, m0", f"s_mov_b32 s{S_KOFF}, 128", f"s_mov_b32 s{S_DMA}, %10", f"s_sub_u32 s{S_CNT}, %11, 3"]
+    L = SHIFT + [f"s_mov_b32 s{S_M0}, m0", f"s_mov_b32 s{S_KOFF}, 128", f"s_mov_b32 s{S_DMA}, %10", f"s_sub_u32 s{S_CNT}, %11, 3"]
     for regs, src in ((RDW, "%0"), (RDA, "%1")):
         L.append(f"v_mov_b32 v{regs[0]}, {src}")
         for ph in range(1, 4):
@@ -149,7 +154,7 @@ def tile_asm(var):
     for ins in reads(0, X):
         L += ins
     L += body("FIRST", var)
-    L += [f"s_cmp_eq_u32 s{S_CNT}, 0", "s_cbranch_scc1 .Lgvl_a4_pen_%=", ".Lgvl_a4_loop_%=:"]
+    L += [f"s_cmp_eq_u32 s{S_CNT}, 0", "s_cbranch_scc1 .Lgvl_a4_pen_%=", *ALIGN_LOOP, ".Lgvl_a4_loop_%=:"]
     L += body("STEADY", var)
     L += [f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", f"s_cmp_lg_u32 s{S_CNT}, 0", "s_cbranch_scc1 .Lgvl_a4_loop_%=", ".Lgvl_a4_pen_%=:"]
     L += body("PENULT", var)

@@ -457,7 +457,7 @@ static int launch_pp(const GemmArgs& a_in, hipStream_t st) {
   // MEASURED AND NOT ADOPTED (round 5, profiles/r05_ab_gemm_band.json + the PMC passes): GM = 32 / tile columns for narrow matrices (N = 1408: 5 rows x 6
   // columns, so that an A slice enters the XCD's L2 once) -- +0.4 % clips/s, inside the run-to-run spread, while the family's fabric-side traffic ROSE from
   // 193 to 231 GB per clip (the W panel is re-read per band, and there are 154 bands instead of 96).  8 rows stay; gvl_debug_set("gemm_band") varies it.
-  if (a.band <= 0) a.band = 8;
+  if (a.band <= 0) a.band = GVL_GEMM_BAND;
   if (g_band_override > 0) a.band = g_band_override;
   static const bool no_persist = gvl_lab_env("GVL_GEMM_NO_PERSIST") != nullptr;                // A/B only
   const int grid = (tiles <= n_cu || no_persist) ? tiles : n_cu;
@@ -615,7 +615,7 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     int form = cfg;
     if (cfg == 80) form = g_a4_mode == 0 ? 82 : (g_a4_mode == 1 ? big_form_preferred(epi) : (g_a4_mode == 2 ? 86 : 88));
     GemmArgs b = a;
-    if (b.band <= 0) b.band = 8;
+    if (b.band <= 0) b.band = GVL_GEMM_BAND;
     if (g_band_override > 0) b.band = g_band_override;
     if (stg_ok && form == 88) {
       const int rc4 = gvl_launch_gemm_a4p(b, epi, st);

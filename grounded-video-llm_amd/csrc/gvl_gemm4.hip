@@ -179,7 +179,7 @@ static int launch_a4(const GemmArgs& a_in, hipStream_t st) {
   GemmArgs a = a_in;
   const int tiles_m = (a.M - a.m_begin + 255) / 256, tiles_n = (a.N + 255) / 256;
   const int tiles = tiles_m * tiles_n;
-  if (a.band <= 0) a.band = 8;
+  if (a.band <= 0) a.band = GVL_GEMM_BAND;
   const int grid = tiles <= n_cu ? tiles : n_cu;
   static const bool timing = gvl_lab_env("GVL_GEMM_TIMING") != nullptr;                        // anatomy probe (LAB builds; tools/gemm4_lab.py)
   if (timing) {

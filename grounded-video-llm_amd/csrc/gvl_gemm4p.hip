@@ -227,7 +227,7 @@ static int launch_a4p(const GemmArgs& a_in, hipStream_t st) {
   if (a.K / BK < A4pAsm<EPI>::MIN_NK) return -2;
   const int tiles_m = (a.M - a.m_begin + 255) / 256, tiles_n = (a.N + 255) / 256;
   const int tiles = tiles_m * tiles_n;
-  if (a.band <= 0) a.band = 8;
+  if (a.band <= 0) a.band = GVL_GEMM_BAND;
   const int grid = tiles <= n_cu ? tiles : n_cu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), a4p_lds<EPI>(), st, a, tiles_m, tiles_n);
   return hipGetLastError() == hipSuccess ? 0 : -3;

@@ -154,6 +154,11 @@ struct GemmArgs {
   const float* act_table;        // set by the launcher: Phi(x) table for the erf-GELU epilogue of the ping-pong kernel (see gvl_gemm.hip)
   unsigned long long* dbg;       // null, or [grid][8 waves][4] s_memtime stamps of the LAST tile (GVL_GEMM_TIMING=1, ping-pong kernel)
 };
+// Rasterisation band of the 256 x 256 kernels: an XCD's 32 workgroups walk a band of this many tile rows column by column.  4 since round 6: the A panel of a
+// band (1 024 rows x K) then fits the XCD's 4 MiB L2 for K <= 1 408 and halves the A re-reads of the wide matrices; same-box A/B of the bench step with the 4-wave
+// kernels: 8 -> 4 rows = 701 -> 686 ms per step (-2.1 %), 2 / 3 / 6 / 16 rows: 694 / 688 / 692 / 732 (profiles/r06_ab_gemm_band.json; per shape: iv2.fc2 +3.7 %,
+// phi.down +4.9 %, the others within +-1.5 %: profiles/r06_gemm_band_shapes.txt).  (Round 5 had tried 5-row bands for N = 1408 only, on the 8-wave kernel.)
+constexpr int GVL_GEMM_BAND = 4;
 int gvl_launch_gemm(const GemmArgs& a, hipStream_t st);
 // gvl_gemm4.hip: the 4-wave / AGPR-accumulator form of the 256 x 256 kernel for the staged bf16 epilogue code `epi` (loop schedule variant `var`);
 // -2 = this epilogue or geometry is not served there (the caller launches the 8-wave kernel instead)

@@ -205,3 +205,32 @@ def test_free_running_greedy_vs_oracle_continuation(llama, tag, n_segs):
     print(f"[parity] {tag.upper()} free-running greedy: {n_same} of {len(got)} ids equal the fp32 continuation; ids {got} vs {fr['free_ids']}; margins/scale {[round(r, 4) for r in rel]}")
     if n_same < len(got):
         assert rel[n_same] < 2 * 2.7e-2, f"greedy id differs at step {n_same} although the margin is {rel[n_same]:.3e} of the logit scale"
+
+
+@pytest.mark.parametrize("tag,n_segs", [("c3", 12), ("c4", 32)])
+def test_free_running_greedy_equals_the_reference_continuations_without_a_near_tie_clause(llama, tag, n_segs):
+    """VERDICT r5 #2, Llama-3-8B (BASELINE configs[3], [4]): tests/golden/<tag>_free2.json -- several prompt tails behind the reference's fp32 prefix, the leading
+    greedy decisions of each whose margin is >= the fixture's bound (three bf16 noises); every kept id must be reproduced exactly (tests/test_gpu_c0.py has the
+    Phi-3.5 twin and the reasoning)."""
+    import json, os
+    from conftest import GOLDEN
+    eng, geo = llama
+    path = os.path.join(GOLDEN, tag + "_free2.json")
+    if not os.path.exists(path):
+        pytest.skip(f"{tag}_free2.json not generated (oracle/make_golden.py free2_{tag})")
+    fr = json.load(open(path))
+    sd = fr["seeds"]
+    sp = synth.exact_tensor(sd["sp"], (1, n_segs, 3, 336, 336), device=DEV)[0]
+    tp = synth.exact_tensor(sd["tp"], (1, 8 * n_segs, 3, 224, 224), device=DEV)
+    tseg = tp.reshape(1, n_segs, 8, 3, 224, 224).permute(0, 1, 3, 2, 4, 5).flatten(0, 1).contiguous()
+    ms = geo.max_segs
+    vis = torch.cat([eng.encode_segments(sp[i:i + ms], tseg[i:i + ms]) for i in range(0, n_segs, ms)], 0)
+    n_dec, pairs = 0, set()
+    for t in fr["tails"]:
+        emb = eng.splice(t["ids"], vis)
+        assert emb.shape[0] == fr["S"]
+        got = eng.generate_ids(emb, len(t["free_ids"]), None)
+        assert min(m / s for m, s in zip(t["margins"], t["scales"])) >= fr["criteria"]["min_margin_over_scale"]
+        assert got == t["free_ids"], f"tail seed {t['tail_seed']}: {got} vs the reference's fp32 continuation {t['free_ids']}"
+        n_dec += len(got); pairs |= {(i, g) for i, g in enumerate(got)}
+    print(f"[parity] {tag.upper()} free-running greedy, {len(fr['tails'])} prompt tails: {n_dec} of {n_dec} ids equal the fp32 continuations ({len(pairs)} distinct (step, id) decisions; no near-tie clause)")

@@ -15,13 +15,14 @@ CFGS = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "82,86").split(",
 WHAT = sys.argv[2] if len(sys.argv) > 2 else "model"
 ROUNDS = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 
+MSCALE = int(os.environ.get("GVL_LAB_MSCALE", "1"))       # 8: the bench's M (8 clips per step)
 MODEL = [("clip.qkv", 27696, 3072, 1024, "bias"), ("clip.fc1", 27696, 4096, 1024, "bias_qgelu"),
          ("iv2.qkv", 24588, 4224, 1408, "rs"), ("iv2.proj", 24588, 1408, 1408, "bias_gamma_resid_sq"), ("iv2.fc1", 24588, 6144, 1408, "rs_bias_gelu"),
          ("iv2.fc2", 24588, 1408, 6144, "bias_gamma_resid_sq"),
          ("phi.qkv", 14076, 9216, 3072, "rs"), ("phi.o", 14076, 3072, 3072, "resid_sq"), ("phi.gu", 14076, 16384, 3072, "rs_silu"), ("phi.down", 14076, 3072, 8192, "resid_sq")]
 EPIS = ["plain", "rs", "bias", "bias_qgelu", "rs_bias_gelu", "rs_silu", "resid_sq", "bias_gamma_resid_sq"]
 if WHAT == "model":
-    SHAPES = MODEL
+    SHAPES = [(n, m * MSCALE if n.startswith("iv2") else m, N, K, mode) for n, m, N, K, mode in MODEL]
 elif WHAT == "p":          # the shapes the pipelined kernel serves so far
     SHAPES = [("clip.qkv", 27696, 3072, 1024, "bias"), ("iv2.qkv", 24588, 4224, 1408, "rs"), ("phi.qkv", 14076, 9216, 3072, "rs"), ("sq8192", 8192, 8192, 8192, "plain")]
 elif WHAT == "p4":
@@ -38,6 +39,7 @@ else:
 
 def main():
     eng = E.Engine(E.TowerGeometry(max_segs=1), "cuda:0", towers=())
+    # "cfg" entries >= 1000 mean: automatic configuration (tile_cfg 0) under gvl_debug_set("gemm_band", cfg - 1000) -- per-shape A/B of the rasterisation band
     tot = {c: 0.0 for c in CFGS}
     for name, M, N, K, mode in SHAPES:
         A = torch.randn((M, K), device="cuda").to(torch.bfloat16)
@@ -58,8 +60,12 @@ def main():
             kw["want_rowsq"] = True
 
         def run(cfg, n):
+            if cfg >= 1000:
+                eng.debug_set("gemm_band", cfg - 1000)
             for _ in range(n):
-                (eng.op_gemm_rows if rows else eng.op_gemm)(A, W, tile_cfg=cfg, **kw)
+                (eng.op_gemm_rows if rows else eng.op_gemm)(A, W, tile_cfg=0 if cfg >= 1000 else cfg, **kw)
+            if cfg >= 1000:
+                eng.debug_set("gemm_band", 0)
         for c in CFGS:
             run(c, 2)
         torch.cuda.synchronize()

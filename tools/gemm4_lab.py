@@ -27,6 +27,9 @@ elif WHAT == "p":          # the shapes the pipelined kernel serves so far
     SHAPES = [("clip.qkv", 27696, 3072, 1024, "bias"), ("iv2.qkv", 24588, 4224, 1408, "rs"), ("phi.qkv", 14076, 9216, 3072, "rs"), ("sq8192", 8192, 8192, 8192, "plain")]
 elif WHAT == "p4":
     SHAPES = [("iv2.qkv", 24588, 4224, 1408, "rs"), ("iv2.fc1", 24588, 6144, 1408, "rs_bias_gelu"), ("phi.gu", 14076, 16384, 3072, "rs_silu"), ("clip.qkv", 27696, 3072, 1024, "bias")]
+elif WHAT == "p5":
+    SHAPES = [("iv2.fc1", 24588, 6144, 1408, "rs_bias_gelu"), ("iv2.fc2", 24588, 1408, 6144, "bias_gamma_resid_sq"), ("phi.o", 14076, 3072, 3072, "resid_sq"),
+              ("phi.gu", 14076, 16384, 3072, "rs_silu"), ("phi.down", 14076, 3072, 8192, "resid_sq")]
 elif WHAT == "p3":
     SHAPES = [("iv2.proj", 24588, 1408, 1408, "bias_gamma_resid_sq"), ("iv2.fc2", 24588, 1408, 6144, "bias_gamma_resid_sq"), ("phi.o", 14076, 3072, 3072, "resid_sq"), ("phi.down", 14076, 3072, 8192, "resid_sq")]
 elif WHAT == "p2":

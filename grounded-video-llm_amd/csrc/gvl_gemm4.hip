@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void gemm_a4_kernel(const GemmArgs a, int tile
 
   int it = bid >> 3;
   if (it >= xcnt) return;
+  if (smem_base & 0x1ffffu) __builtin_trap();        // the ring slots are toggled by XOR 0x10000: the dynamic LDS block must start at a multiple of 128 KiB (it starts at 0)
   if constexpr (GELU_TAB) {                          // once per (persistent) workgroup; its first read is many barriers away
     for (int o = tid * 16; o < GELU_TAB_BYTES; o += 256 * 16) *(u32x4_t*)(smem + TAB_OFF + o) = *(const u32x4_t*)((const char*)a.act_table + o);
   }

@@ -238,3 +238,26 @@ def test_c1_free_running_greedy_equals_the_reference_continuations_without_a_nea
         assert t["free_ids_bf16emu"] == t["free_ids"]
         n_dec += len(got); pairs |= {(i, g) for i, g in enumerate(got)}
     print(f"[parity] C1 free-running greedy, {len(fr['tails'])} prompt tails: {n_dec} of {n_dec} ids equal the fp32 continuations ({len(pairs)} distinct (step, id) decisions; every margin >= 6e-2 of the scale; no near-tie clause)")
+
+
+def test_kernel_form_of_the_big_gemm_changes_no_bit_at_full_size(c0):
+    """gvl_debug_set("gemm_a4"): 0 = every 256 x 256 GEMM on the 8-wave ping-pong kernel (round 5), 1 = the per-epilogue choice (4-wave / pipelined 4-wave / 8-wave),
+    2 / 3 = the plain / pipelined 4-wave kernel wherever it serves.  Every form accumulates an output element in the same k order and shares the epilogue arithmetic, so
+    the full-size towers (InternVideo2: rowscale, erf-GELU, LayerScale + residual + row statistics; CLIP: bias) and the 32-layer prefill logits must be BIT-identical."""
+    eng, geo, meta, g, sp, tseg = c0
+    outs = {}
+    try:
+        for mode in (0, 1, 2, 3):
+            eng.debug_set("gemm_a4", mode)
+            vis = eng.encode_segments(sp, tseg)
+            emb = eng.splice(meta["ids"], vis)
+            seq = eng.seq_alloc(emb.shape[0] + 8)
+            lg = eng.prefill(seq, emb, want_logits=True).clone()
+            eng.seq_free(seq)
+            outs[mode] = (vis.clone(), lg)
+    finally:
+        eng.debug_set("gemm_a4", 1)
+    for mode in (1, 2, 3):
+        assert torch.equal(outs[0][0], outs[mode][0]), f"gemm_a4 = {mode}: visual tokens differ from the 8-wave kernel's"
+        assert torch.equal(outs[0][1], outs[mode][1]), f"gemm_a4 = {mode}: prefill logits differ from the 8-wave kernel's"
+    print("[parity] full-size towers + 32-layer prefill: bit-identical under gemm_a4 = 0 / 1 / 2 / 3 (8-wave, chosen, plain 4-wave, pipelined 4-wave GEMM forms)")

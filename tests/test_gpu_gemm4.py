@@ -145,3 +145,24 @@ def test_pipelined_activations_bit_identical(eng, M, N, K):
         got = fn(A, W, tile_cfg=88, **kw)
         bad = (got != want).nonzero()
         assert bad.numel() == 0, f"{name} {M}x{N}x{K}: {bad.shape[0]} elements differ, first at {bad[0].tolist()}, last at {bad[-1].tolist()}"
+
+
+def test_pipelined_heavy_epilogues_repeated_launches_are_stable(eng):
+    """race screen for the deferred program (LDS staging shared between the drain's bias slice and the transposition passes, residual loads a k-tile ahead of their
+    use, stores at the statement's end): the same launch 15 times per epilogue, several tiles per workgroup, must give the same bits every time"""
+    M, N, K = 40000, 2816, 1408
+    A, W, g = _ops(M, N, K, 23)
+    bias = torch.randn((N,), device=DEV, generator=g) * 0.5
+    gam = torch.randn((N,), device=DEV, generator=g) * 0.1
+    resb = torch.randn((M, N), device=DEV, generator=g).to(bf)
+    rs = torch.rand((M,), device=DEV, generator=g) + 0.5
+    cases = {"rowsq_bias_gamma_resid": dict(bias=bias, gamma=gam, resid=resb, want_rowsq=True), "rowsq_resid": dict(resid=resb, want_rowsq=True),
+             "rowscale_bias_gelu": dict(rowscale=rs, bias=bias, act=L.ACT_GELU), "rowscale_silu": dict(rowscale=rs, act=L.ACT_SILU_MUL)}
+    for name, kw in cases.items():
+        want = eng.op_gemm_rows(A, W, tile_cfg=82, **kw)
+        for it in range(15):
+            got = eng.op_gemm_rows(A, W, tile_cfg=88, **kw)
+            if isinstance(want, tuple):
+                assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1]), f"{name}, launch {it}"
+            else:
+                assert torch.equal(want, got), f"{name}, launch {it}"

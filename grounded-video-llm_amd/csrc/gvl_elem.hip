@@ -288,10 +288,18 @@ template <int WPR>   // waves per token row: 1 -> 4 rows per block (bulk), 4 -> 
 __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row = WPR == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
-  if (row >= a.B * a.S) return;                     // no block-level barrier below
+  if (row >= (a.vl_n ? a.vl_rows[a.vl_n] : a.B * a.S)) return;                     // no block-level barrier below
   constexpr int TEAM = 64 * WPR;
   const int lt = WPR == 1 ? lane : tid;
-  const int b = row / a.S, s_in = row - b * a.S;
+  // ragged group (vl_n > 0): the row's sequence u by <= 8 prefix sums; after that it is that sequence's own single-sequence launch (b = 0, its table, its length)
+  int S_ = a.S, b = 0, s_in = 0, row0 = 0;
+  const int* table = a.block_table;
+  if (a.vl_n) {
+    int u = 0;
+#pragma unroll
+    for (int i = 1; i < GVL_MAX_PREFILL_BATCH; ++i) u += (i < a.vl_n && row >= a.vl_rows[i]) ? 1 : 0;
+    row0 = a.vl_rows[u]; S_ = a.vl_rows[u + 1] - row0; s_in = row - row0; table = a.vl_tables[u];
+  } else { b = row / a.S; s_in = row - b * a.S; }
   const bf16_t* qr = a.qkv + (size_t)row * a.ld;
   const bf16_t* kr = qr + a.H * a.Dr;
   const bf16_t* vr = kr + a.KV * a.Dr;
@@ -338,9 +346,9 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
   if (a.pos_ptr) pos = *a.pos_ptr;
   const float* cosp = a.cos; const float* sinp = a.sin;
   if (a.mode == 2 && a.rope_switch > 0 && pos + 1 > a.rope_switch) { cosp = a.cos_l; sinp = a.sin_l; }
-  const int n_tiles = (a.S + 63) >> 6;
+  const int n_tiles = (S_ + 63) >> 6;
   const int tile = pos >> 6, slot = pos & 63;
-  const int page = a.block_table ? a.block_table[b * a.max_pages + tile] : b * n_tiles + tile;
+  const int page = table ? table[b * a.max_pages + tile] : b * n_tiles + tile;
 
   // one 16-byte chunk (8 elements) of q or k -> transformed chunk
   auto xform = [&](const bf16_t* src, int c, float rs, const bf16_t* nw) -> u32x4_t {
@@ -379,20 +387,20 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
     return o;
   };
   // Q [B][H][S][D]
-  bf16_t* Qb = a.Q + ((size_t)b * a.H * a.S + s_in) * a.D;
+  bf16_t* Qb = a.Q + ((size_t)b * a.H * S_ + s_in) * a.D + (size_t)row0 * a.H * a.D;
   // K page row [page][KV][64][D]
   bf16_t* Kb = a.Kt + ((size_t)page * a.KV) * (64 * a.D) + (size_t)slot * a.D;
   if (in_regs) {
 #pragma unroll
     for (int i = 0; i < RC; ++i) {
       const int c = lane + 64 * i;
-      if (c < nq && !a.q_rs) { const int hd = c / cpr, dc = c - hd * cpr; *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + dc * 8) = norm_chunk(qreg[i], c, q_rs, a.qn); }
+      if (c < nq && !a.q_rs) { const int hd = c / cpr, dc = c - hd * cpr; *(u32x4_t*)(Qb + (size_t)hd * S_ * a.D + dc * 8) = norm_chunk(qreg[i], c, q_rs, a.qn); }
       if (c < nk) { const int hd = c / cpr, dc = c - hd * cpr; *(u32x4_t*)(Kb + (size_t)hd * (64 * a.D) + dc * 8) = norm_chunk(kreg[i], c, k_rs, a.kn); }
     }
   } else {
     if (!a.q_rs) for (int c = lt; c < nq; c += TEAM) {
       const int hd = c / cpr, dc = c - hd * cpr;
-      *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + dc * 8) = xform(qr, c, q_rs, a.qn);
+      *(u32x4_t*)(Qb + (size_t)hd * S_ * a.D + dc * 8) = xform(qr, c, q_rs, a.qn);
     }
     for (int c = lt; c < nk; c += TEAM) {
       const int hd = c / cpr, dc = c - hd * cpr;
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
   }
   if (cpd > cpr) {                                   // zero the head-dim padding (88 -> 96)
     const int np = cpd - cpr;
-    if (!a.q_rs) for (int c = lt; c < a.H * np; c += TEAM) { const int hd = c / np; *(u32x4_t*)(Qb + (size_t)hd * a.S * a.D + (cpr + c % np) * 8) = zero; }
+    if (!a.q_rs) for (int c = lt; c < a.H * np; c += TEAM) { const int hd = c / np; *(u32x4_t*)(Qb + (size_t)hd * S_ * a.D + (cpr + c % np) * 8) = zero; }
     for (int c = lt; c < a.KV * np; c += TEAM) {
       const int hd = c / np;
       u32x4_t v = zero; if (a.k_ones && c % np == 0) v[0] = 0x3F80u;      // bf16 1.0 in column Dr
@@ -422,19 +430,26 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs a) {
 // 16-byte global accesses both ways: 8 head-dim elements of a token in, 8 consecutive tokens of one head-dim row out.
 __global__ __launch_bounds__(256) void v_transpose_kernel(const QkvPostArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t tile[64][136];          // 272-byte rows (16-byte aligned, bank-staggered)
-  const int t = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
+  int t = blockIdx.x, S_ = a.S, row0 = 0;
+  const int hkv = blockIdx.y, b = blockIdx.z;
+  const int* table = a.block_table;
+  if (a.vl_n) {                                         // ragged group: blockIdx.x runs over the 64-token tiles of all sequences
+    int u = 0, t0 = 0;
+    for (; u + 1 < a.vl_n; ++u) { const int nt = (a.vl_rows[u + 1] - a.vl_rows[u] + 63) >> 6; if (t < t0 + nt) break; t0 += nt; }
+    t -= t0; row0 = a.vl_rows[u]; S_ = a.vl_rows[u + 1] - row0; table = a.vl_tables[u];
+  }
   const int tid = threadIdx.x;
   const int s0 = a.pos0 + t * 64;                       // first token (sequence space) of this tile; pos0 is a multiple of 64
-  const int n_tiles = (a.S + 63) >> 6;
+  const int n_tiles = (S_ + 63) >> 6;
   const int tile_idx = s0 >> 6;
-  const int page = a.block_table ? a.block_table[b * a.max_pages + tile_idx] : b * n_tiles + tile_idx;
+  const int page = table ? table[b * a.max_pages + tile_idx] : b * n_tiles + tile_idx;
   const int voff = (a.H + a.KV) * a.Dr + hkv * a.Dr;
   const int cpr = a.Dr >> 3;
   for (int i = tid; i < 64 * cpr; i += 256) {
     const int r = i / cpr, c = i - r * cpr;
     const int s_in = t * 64 + r;
     u32x4_t v = {0u, 0u, 0u, 0u};
-    if (s_in < a.S) v = *(const u32x4_t*)(a.qkv + ((size_t)b * a.S + s_in) * a.ld + voff + c * 8);
+    if (s_in < S_) v = *(const u32x4_t*)(a.qkv + ((size_t)b * S_ + row0 + s_in) * a.ld + voff + c * 8);
     *(u32x4_t*)&tile[r][c * 8] = v;
   }
   __syncthreads();
@@ -454,7 +469,8 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const QkvPostArgs a) {
 
 int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st) {
   if ((a.Dr & 7) || (a.mode == 2 && (a.Dr & 15)) || (a.D & 7) || a.D < a.Dr || a.Dr > 128 || (a.ld & 7)) return -1;   // 16-byte chunks; rotate_half partner chunk-aligned
-  const int rows = a.B * a.S;
+  if (a.vl_n && (a.mode != 2 || a.B != 1 || a.pos0 != 0 || a.pos_ptr || a.vl_n > GVL_MAX_PREFILL_BATCH)) return -1;
+  const int rows = a.vl_n ? a.vl_rows[a.vl_n] : a.B * a.S;
   if (a.q_rs && (a.mode != 1 || a.pos_ptr)) return -1;
   if (a.pos_ptr) {
     if (rows != 1 || a.mode != 2) return -1;
@@ -463,7 +479,8 @@ int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(qkv_post_kernel<1>, dim3((rows + 3) / 4), dim3(256), 0, st, a);
   }
   if (!a.pos_ptr && a.Vt) {                          // Vt == null: the attention kernel reads V in place (AttnArgs.Vrows)
-    const int n_tiles = (a.S + 63) >> 6;
+    int n_tiles = (a.S + 63) >> 6;
+    if (a.vl_n) { n_tiles = 0; for (int u = 0; u < a.vl_n; ++u) n_tiles += (a.vl_rows[u + 1] - a.vl_rows[u] + 63) >> 6; }
     hipLaunchKernelGGL(v_transpose_kernel, dim3(n_tiles, a.KV, a.B), dim3(256), 0, st, a);
   }
   return CHECK_LAUNCH();

@@ -267,6 +267,11 @@ struct QkvPostArgs {
   int k_ones;                      // K pad column Dr (needs D > Dr) is 1.0 instead of 0 (harmless while q's pad is 0; see AttnArgs.k_ones)
   float* q_rs;                     // mode 1, or null: [B*S] -- the q rows are NOT written; their RMS factor rsqrt(mean q^2 + eps) is, and the attention
                                    //   kernel normalises the q fragments it loads from the qkv matrix itself (AttnArgs.q_rs / q_nw)
+  // RAGGED prefill group in one launch (mode 2, B == 1, pos0 == 0; AttnArgs.vl_* on the attention side): vl_n > 0 sequences packed back to back -- sequence u owns
+  // the rows [vl_rows[u], vl_rows[u + 1]) of qkv and of Q ([H][S_u][D] per sequence, at row offset vl_rows[u]) and the block table vl_tables[u]; S is ignored
+  int vl_n;
+  int vl_rows[GVL_MAX_PREFILL_BATCH + 1];
+  const int* vl_tables[GVL_MAX_PREFILL_BATCH];
 };
 int gvl_launch_qkv_post(const QkvPostArgs& a, hipStream_t st);
 // HD 2x2 merge + sub_GN newline (Phi): f32 [n,576,C] -> bf16 [n,156,4C]

@@ -380,7 +380,22 @@ int llm_prefill(gvl_ctx* ctx, Seq* const* sqs, int nb, const bf16_t* const* embe
     // ragged group: RoPE / KV append per sequence (HBM-bound passes), then ONE causal-attention grid over the query blocks of all sequences
     // (AttnArgs.vl_*; 8 launches of ~900 blocks on 768 block slots each -> one of ~7 000: the causal tail is paid once) -- bit-identical per row
     const bool vl_attn = n_att > 1 && ctx->dbg.varlen_attn && pos0 == 0;
-    for (int u = 0; u < n_att; ++u) {
+    // round 6: RoPE / KV append / V^T pages of the group in ONE launch each as well (QkvPostArgs.vl_*: 2 launches per layer instead of 2 per sequence -- 25 + 14 us
+    // launches of 3.5 k rows each, bit-identical per row); varlen_attn = 2 keeps them per sequence (round 5).  One table choice (LongRoPE short / long) per launch.
+    bool vl_post = vl_attn && ctx->dbg.varlen_attn == 1;
+    if (vl_post && f.rope_orig_max_pos > 0 && ctx->cos_l) {
+      const bool l0 = lens[0] > f.rope_orig_max_pos;
+      for (int u = 1; u < nb; ++u) vl_post = vl_post && (lens[u] > f.rope_orig_max_pos) == l0;
+    }
+    if (vl_post) {
+      const bool use_long = f.rope_orig_max_pos > 0 && lens[0] > f.rope_orig_max_pos && ctx->cos_l;
+      QkvPostArgs q; memset(&q, 0, sizeof(q)); q.qkv = qkv; q.ld = qkvw; q.Q = Q; q.Kt = Kt; q.Vt = Vt; q.B = 1; q.H = H; q.KV = KV; q.Dr = Dr; q.D = D; q.mode = 2;
+      q.cos = use_long ? ctx->cos_l : ctx->cos_s; q.sin = use_long ? ctx->sin_l : ctx->sin_s; q.vl_n = nb;
+      for (int u = 0; u < nb; ++u) { q.vl_rows[u] = off[u]; q.vl_tables[u] = sqs[u]->d_block_table; q.S = lens[u] > q.S ? lens[u] : q.S; }
+      q.vl_rows[nb] = off[nb];
+      RUN(GVL_PROF_OTHER, 0, gvl_launch_qkv_post(q, st));
+    }
+    for (int u = 0; u < n_att && !vl_post; ++u) {
       const int S = lens[u], B = n_att == 1 ? nb : 1;
       const int* tbl = n_att == 1 ? table : sqs[u]->d_block_table;
       const int tstride = n_att == 1 ? table_stride : sqs[u]->n_pages;
@@ -1411,7 +1426,7 @@ int gvl_debug_set(gvl_ctx* ctx, const char* key, int value) {
   else if (k == "attn_pipe") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: attn_pipe must be 0, 1 or 2"); ctx->dbg.attn_pipe = value; }
   else if (k == "attn_pipe_rows") { if (value != 128 && value != 256) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: attn_pipe_rows must be 128 (default) or 256"); ctx->dbg.attn_pipe_rows = value; }
   else if (k == "patch_fused") ctx->dbg.patch_fused = value != 0;
-  else if (k == "varlen_attn") ctx->dbg.varlen_attn = value != 0;
+  else if (k == "varlen_attn") ctx->dbg.varlen_attn = value < 0 || value > 2 ? 1 : value;
   else if (k == "norm_fused") ctx->dbg.norm_fused = value != 0;
   else if (k == "last_layer_tail") ctx->dbg.last_layer_tail = value != 0;
   else if (k == "gemm_band") { if (value < 0 || value > 64) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: gemm_band must be 0 (automatic) .. 64"); gvl_gemm_set_band(value); }

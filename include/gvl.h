@@ -264,8 +264,9 @@ int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launche
  *                      2: V only; 0: the round-2 path through Q / K pages and a V^T transpose pass
  *   "attn_pipe_rows"   128 (default): that kernel's 4-wave form (128 query rows per block) for every row; 256: whole 256-row query blocks on its 8-wave form (half
  *                      the DMA pieces per MFMA; measured 12 % slower), the remaining rows on the 4-wave form -- bit-identical
- *   "varlen_attn"      1 (default): the causal attention of a ragged prefill group (gvl_prefill_varlen) runs as ONE grid over the query blocks of all its sequences;
- *                      0: one launch per sequence (rounds 2-4) -- bit-identical
+ *   "varlen_attn"      1 (default): the causal attention of a ragged prefill group (gvl_prefill_varlen) runs as ONE grid over the query blocks of all its sequences,
+ *                      and so do its RoPE / KV-append and V^T-page passes (one launch each per layer); 2: the attention only (round 5), the passes per sequence;
+ *                      0: one launch per sequence for all of them (rounds 2-4) -- bit-identical
  *   "norm_fused"       1 (default): RMSNorm in front of qkv / fc1 (InternVideo2) and qkv_proj / gate_up_proj / lm_head (LLM prefill AND, with bf16 decode weights,
  *                      the decode step) is fused into the GEMMs around it
  *                      (row statistics from the producing GEMM's epilogue, norm weight folded into the consuming GEMM's weight, row scale in its epilogue); 0: the

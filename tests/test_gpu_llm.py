@@ -273,9 +273,10 @@ def test_prefill_varlen_is_bit_identical_to_single(which):
     for lens in ((7, 64, 61, 65, 3, 128, 66, 63), (1, 130, 2, 129, 1, 64, 5, 200), (33, 33, 40, 33, 33, 33, 33, 34)):   # page boundaries, single-token prompts, a near-uniform batch
         xs = [synth.det_tensor(f"pvar.{which}.{S}.{i}", (S, c["hidden"]), 0.5).to(DEV).to(bf) for i, S in enumerate(lens)]
         single = [eng.generate_ids(x, new, None) for x in xs]
-        for n, va in ((2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (8, 1), (5, 0), (8, 0)):
-            # varlen_attn = 1 (default): ONE causal-attention grid over the query blocks of all sequences (attn_fwd_kernel<.., VL = 1>); 0: one launch per
-            # sequence.  Either way every row must carry the bits of its sequence's own prefill (single-sequence launches of the VL = 0 kernel).
+        for n, va in ((2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (8, 1), (5, 2), (8, 2), (5, 0), (8, 0)):
+            # varlen_attn = 1 (default): ONE causal-attention grid over the query blocks of all sequences (attn_fwd_kernel<.., VL = 1>) and ONE RoPE / KV-append
+            # and V^T-page launch for the group (QkvPostArgs.vl_*); 2: the attention grid only; 0: one launch per sequence for everything.
+            # Either way every row must carry the bits of its sequence's own prefill (single-sequence launches of the VL = 0 kernels).
             eng.debug_set("varlen_attn", va)
             seqs = [eng.seq_alloc(lens[i] + new) for i in range(n)]
             eng.prefill_batch(seqs, xs[:n])

@@ -46,6 +46,27 @@ phi.down 3519 3072 8192 resid
 sq8192 8192 8192 8192 plain
 SHAPES
 fi
+if [[ $WHAT == mfma_bench ]]; then
+  # the GEMMs of the TIMED step at the bench's M (8 clips / a 4-sequence prefill group), with the epilogues the model runs (fused RMSNorm forms): matrix-pipe busy
+  # fraction and the shader clock under that load -- their product is what the board's power budget caps
+  : > $OUT/${TAG}_gemm_mfma_util_bench.txt
+  while read name M N K mode; do
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $OUT/mfmab_$name -- python $R/tools/gemm_one.py $M $N $K 0 5 $mode > $OUT/mfmab_$name.log 2>&1
+    python $R/tools/mfma_util.py "$(db $OUT/mfmab_$name)" $name $M $N $K 5 >> $OUT/${TAG}_gemm_mfma_util_bench.txt
+  done <<SHAPES
+iv2.qkv 196704 4224 1408 rs
+iv2.proj 196704 1408 1408 bias_gamma_resid_sq
+iv2.fc1 196704 6144 1408 rs_bias_gelu
+iv2.fc2 196704 1408 6144 bias_gamma_resid_sq
+phi.qkv 14076 9216 3072 rs
+phi.o 14076 3072 3072 resid_sq
+phi.gu 14076 16384 3072 rs_silu
+phi.down 14076 3072 8192 resid_sq
+clip.qkv 221568 3072 1024 bias
+clip.fc1 221568 4096 1024 bias_qgelu
+sq8192 8192 8192 8192 plain
+SHAPES
+fi
 # the rocprofv3 databases are hundreds of MB: only the summaries travel back (gpurun_out/ is capped at 64 MiB)
 find $OUT -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
 rm -f $OUT/*.log.big

@@ -118,7 +118,7 @@ def test_c4_llama3_8b_256_frames_long_context(llama):
     assert both[0] == out[:16] and both[1] == solo2
 
 
-def _full_depth_vs_reference_golden(llama, name):
+def _full_depth_vs_reference_golden(llama, name, norm_fused=1):
     """HIP path: segment encode (in chunks of the per-call workspace) -> splice -> prefill (row S-1) -> teacher-forced decode steps
     through the paged KV cache; every `row_step`-th row against the golden.  Bound: max(1e-2, 1.25 x the error of the reference's own
     bf16 evaluation stored in the golden) on the max-abs error, 1.15 x on the RMS error (gpu_util.noise_class)."""
@@ -129,6 +129,11 @@ def _full_depth_vs_reference_golden(llama, name):
     meta, g = load_golden(name)
     sd, st = meta["seeds"], meta["stride"]
     n_segs, step = meta.get("n_segs", 12), meta.get("row_step", 1)
+    # the caps against the fp32-prefix yardstick were widened (1.25 -> 1.30 max, 1.15 -> 1.20 rms) in the change that fused the RMSNorms into the GEMMs;
+    # with the fusion switched off (the separate norm passes of rounds 1-4) the OLD caps must still hold -- nothing else moved
+    cap, rms_cap = (E2E_FP32PREFIX_CAP, 1.20) if norm_fused else (1.25, 1.15)
+    eng.debug_set("norm_fused", norm_fused)
+    name_ = name + ("" if norm_fused else " [norm_fused = 0]")
     sp = synth.exact_tensor(sd["sp"], (1, n_segs, 3, 336, 336), device=DEV)[0]
     tp = synth.exact_tensor(sd["tp"], (1, 8 * n_segs, 3, 224, 224), device=DEV)
     tseg = tp.reshape(1, n_segs, 8, 3, 224, 224).permute(0, 1, 3, 2, 4, 5).flatten(0, 1).contiguous()
@@ -141,7 +146,7 @@ def _full_depth_vs_reference_golden(llama, name):
     assert emb.shape[0] == S
     scale = float(np.abs(g["logits_rows"]).max())
     ref_bf = float(np.abs(g["logits_rows_bf16ref"] - g["logits_rows"]).max()) / scale
-    tol = max(1e-2, E2E_FP32PREFIX_CAP * ref_bf)
+    tol = max(1e-2, cap * ref_bf)
     ls = st["logits"]
     seq = eng.seq_alloc(S + len(meta["forced"]) + 8)
     rows = [eng.prefill(seq, emb, want_logits=True).clone()]
@@ -150,14 +155,15 @@ def _full_depth_vs_reference_golden(llama, name):
         if (i + 1) % step == 0:
             rows.append(lg.clone())
     eng.seq_free(seq)
+    eng.debug_set("norm_fused", 1)
     assert len(rows) == g["logits_rows"].shape[0]
     errs = [float((r[::ls].cpu().double() - torch.as_tensor(g["logits_rows"][i]).double()).abs().max()) / scale for i, r in enumerate(rows)]
-    print(f"[parity] {name} Llama-3-8B 32 L, S={S}: the reference's own bf16 evaluation is {ref_bf:.3e} from its fp32 logits (scale {scale:.3f}); bound {tol:.2e}")
-    print(f"[parity] {name} logits, prefill row + teacher-forced decode rows (every {step}; of the logit scale):", " ".join(f"{e:.2e}" for e in errs))
+    print(f"[parity] {name_} Llama-3-8B 32 L, S={S}: the reference's own bf16 evaluation is {ref_bf:.3e} from its fp32 logits (scale {scale:.3f}); bound {tol:.2e}")
+    print(f"[parity] {name_} logits, prefill row + teacher-forced decode rows (every {step}; of the logit scale):", " ".join(f"{e:.2e}" for e in errs))
     assert max(errs) <= tol
     # fp32-PREFIX yardstick of rounds 2-4 (the reference's LLM in bf16 on its own fp32 prefix: not like for like, wider RMS cap); binding: like_for_like() below
-    noise_class(torch.stack([r[::ls].cpu() for r in rows]), g["logits_rows"], g["logits_rows_bf16ref"], f"{name} Llama-3-8B 32 L logits, S={S}, {len(rows)} rows", cap=E2E_FP32PREFIX_CAP, rms_cap=1.20)
-    like_for_like(torch.stack([r[::ls].cpu() for r in rows]), name[:2], f"{name[:2].upper()}  Llama-3-8B, {8 * n_segs} frames, S={S} (end to end)")
+    noise_class(torch.stack([r[::ls].cpu() for r in rows]), g["logits_rows"], g["logits_rows_bf16ref"], f"{name_} Llama-3-8B 32 L logits, S={S}, {len(rows)} rows", cap=cap, rms_cap=rms_cap)
+    like_for_like(torch.stack([r[::ls].cpu() for r in rows]), name[:2], f"{name[:2].upper()}  Llama-3-8B, {8 * n_segs} frames, S={S} (end to end{'' if norm_fused else ', norm_fused = 0'})")
     margins = np.asarray(g["top1"]) - np.asarray(g["top2"])
     for i, r in enumerate(rows):
         if margins[i] > 2 * tol * scale:
@@ -176,6 +182,12 @@ def test_c4_full_depth_long_context_vs_reference_golden(llama):
     at real size on one device (tests/golden/c4_full.npz, oracle/make_golden.py c4: 32-segment encode_images, one fp32 forward over
     the prefix plus 63 teacher-forced tokens, every 4th row stored)."""
     _full_depth_vs_reference_golden(llama, "c4_full")
+
+
+def test_c4_with_the_separate_norm_passes_keeps_the_caps_of_rounds_2_to_4(llama):
+    """The same C4 golden with gvl_debug_set("norm_fused", 0): max <= 1.25 x / rms <= 1.15 x the reference's bf16 evaluation on its fp32 prefix -- the caps before the
+    fused RMSNorm (round 5) widened them to 1.30 / 1.20 for the fused path (its largest observed ratio: 1.28 on this config)."""
+    _full_depth_vs_reference_golden(llama, "c4_full", norm_fused=0)
 
 
 @pytest.mark.parametrize("tag,n_segs", [("c3", 12), ("c4", 32)])

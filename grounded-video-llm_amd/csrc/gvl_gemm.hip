@@ -16,6 +16,7 @@
 //     ds_read_b128 lane groups of MI355X_MICROARCH.md §LDS).
 //   * XCD-aware block order: each of the 8 XCDs gets a contiguous range of tiles so that the
 //     A row-panel of a tile row stays in that XCD's private L2.
+#include <atomic>
 #include "gvl_internal.h"
 #include <vector>
 #include <cmath>
@@ -266,6 +267,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
   // (3 + 3 + 2 pieces over the LOAD phases 0/1/2 instead of 4 + 4 was measured 6 % slower at 8192^3: the later pieces land late.)
 #define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
+  // The tile PROTOCOL every wave of the block keeps, live or dead (one definition for both paths -- a change to the barrier count of the live loop
+  // cannot leave the dead-wave path behind):  tile_open | per k-tile t, phase ph: {phase_dma, barrier, [8 MFMAs], barrier} | tile_close
+  auto tile_open = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();                                   // k-tile 0 is in LDS for everybody; everybody is done with the staging slot
+    if (grp == 1) PP_BARRIER();                     // half-phase offset of the second wave group
+  };
+  // this wave's share of the next k-tile's DMA (phases 0 / 1) and the wait for it (phase 3; `wait_last`: also behind the last k-tile)
+  auto phase_dma = [&](int t, int ph, bool more, bool wait_last) {
+    if (ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
+    if (ph == 3 && (more || wait_last)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto tile_close = [&]() { if (grp == 0) PP_BARRIER(); };   // pairs with the extra barrier group 1 took in tile_open
+
   int it = bid >> 3;
   if (it >= xcnt) return;
   if constexpr (GELU_TAB) {                          // once per (persistent) workgroup; first read is many barriers away
@@ -282,22 +297,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
     // issues no MFMA, no LDS read, no epilogue.  (wn is the same for the two waves of a SIMD: SIMDs 1 and 3 idle through such a tile.)  Kept as ONE early
     // block of the tile loop so that the live path's register allocation is untouched (the bias + gamma + residual epilogue sits 11 VGPRs under the limit).
     if ((n0 + wn * TN >= a.N) || (m0 + wm * TM >= a.M)) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PP_BARRIER();
-      if (grp == 1) PP_BARRIER();
+      tile_open();
       for (int t = 0; t < nk; ++t) {
         const bool more = t + 1 < nk;
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
-          if (ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
-          if (ph == 3 && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          phase_dma(t, ph, more, false);
           PP_BARRIER();
           PP_BARRIER();
         }
       }
-      if (grp == 0) PP_BARRIER();
+      tile_close();
       if (it + wpx < xcnt) {                        // the next tile's first k-tile still needs this wave's DMA pieces
-        if constexpr (STG != 0 && EPI >= 0 && !(STG != 0 && EPI >= 0 && !(EPI & 4))) __syncthreads();   // = STAGED && !OVERLAP: the live waves' staging slices overlap ring slot 0
+        if constexpr (STAGED && !OVERLAP) __syncthreads();   // the live waves' staging slices overlap ring slot 0
         setup(xbase + it + wpx, m0, n0); stage_half(0, 0, 0); stage_half(0, 0, 1);
       }
       continue;
@@ -312,9 +324,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PP_BARRIER();                                   // k-tile 0 is in LDS for everybody; everybody is done with the staging slot
-    if (grp == 1) PP_BARRIER();                     // half-phase offset of the second wave group
+    tile_open();
     if (a.dbg) ts1 = __builtin_readcyclecounter();
 
     // 4 phases per k-tile (one 16-wide k-step each): LOAD = 6 ds_read_b128 (+ a half of the next k-tile's DMA in phases
@@ -347,8 +357,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(sb + w_row_off + i * 32 * 128 + coff);
 #pragma unroll
         for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(sb + a_row_off + j * 32 * 128 + coff);
-        if (ph < 2 && more) stage_half((t + 1) & 1, (t + 1) * BK, ph);
-        if (ph == 3 && (more || !STAGED)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last k-tile: no DMA pending, residual stays in flight
+        phase_dma(t, ph, more, !STAGED);            // last k-tile: no DMA pending, the (staged epilogue's) residual request stays in flight
         if constexpr (STAGED) {
           if (ph == 3 && t == 0 && (G::has_bias || G::has_gamma)) stg_store_bias<NB, EPI_G>(bgw, lane, ebv, egv);
         }
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         PP_BARRIER();
       }
     }
-    if (grp == 0) PP_BARRIER();                     // pairs with the extra barrier group 1 took at the start
+    tile_close();
     // every LDS read of the ring is complete (both groups are past their last MFMA phase)
     if (a.dbg) ts2 = __builtin_readcyclecounter();
     const int em0 = m0, en0 = n0;
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
       if constexpr (STAGED) gemm_epilogue_staged<MB, NB, EPI, 0, PRE>(a, acc, smem + wave * STG_BYTES, bgw, em0 + wm * TM, en0 + wn * TN, lane, rv, rsc);
       else gemm_epilogue<TM, TN, MB, NB, EPI>(a, acc, em0, en0, wm, wn, l31, h);
       if (has_next) {
-        if constexpr (STAGED) __syncthreads();      // staging slices overlap ring slot 0
+        if constexpr (STAGED && !OVERLAP) __syncthreads();      // staging slices overlap ring slot 0
         setup(xbase + it + wpx, m0, n0); stage_half(0, 0, 0); stage_half(0, 0, 1);
       }
     }
@@ -393,12 +402,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
 #undef PP_BARRIER
 }
 
-static int g_band_override = 0;                     // A/B only (gvl_debug_set("gemm_band")): process-wide, result-neutral
-void gvl_gemm_set_band(int v) { g_band_override = v; }
+// A/B only (gvl_debug_set("gemm_band" / "gemm_a4")): PROCESS-wide by design (documented in gvl.h), result-neutral; atomics because contexts of several host threads may
+// launch while one of them flips a knob
+static std::atomic<int> g_band_override{0};
+void gvl_gemm_set_band(int v) { g_band_override.store(v, std::memory_order_relaxed); }
 // Which launches of the 256 x 256 kernel take a 4-wave / AGPR form (gvl_gemm4.hip, gvl_gemm4p.hip) instead of the 8-wave ping-pong: see big_form_preferred and the
 // dispatch in gvl_launch_gemm.  Bit-identical whatever the value (gvl_debug_set("gemm_a4"); process-wide).
-static int g_a4_mode = 1;
-void gvl_gemm_set_a4(int v) { g_a4_mode = v; }
+static std::atomic<int> g_a4_mode{1};
+void gvl_gemm_set_a4(int v) { g_a4_mode.store(v, std::memory_order_relaxed); }
 // Which form of the 256 x 256 kernel an (epilogue) takes when the library chooses (cfg 80), from same-box interleaved runs on the model's shapes
 // (profiles/r06_gemm4_lab_model.txt; tools/gemm4_lab.py 82,86,88 model):
 //   pipelined 4-wave (88): the epilogues with real VALU / LDS work behind the bf16 rounding -- erf-GELU (98: +5 % over the 8-wave kernel, +10 % over the plain 4-wave
@@ -458,7 +469,7 @@ static int launch_pp(const GemmArgs& a_in, hipStream_t st) {
   // columns, so that an A slice enters the XCD's L2 once) -- +0.4 % clips/s, inside the run-to-run spread, while the family's fabric-side traffic ROSE from
   // 193 to 231 GB per clip (the W panel is re-read per band, and there are 154 bands instead of 96).  8 rows stay; gvl_debug_set("gemm_band") varies it.
   if (a.band <= 0) a.band = GVL_GEMM_BAND;
-  if (g_band_override > 0) a.band = g_band_override;
+  if (const int bo = g_band_override.load(std::memory_order_relaxed); bo > 0) a.band = bo;
   static const bool no_persist = gvl_lab_env("GVL_GEMM_NO_PERSIST") != nullptr;                // A/B only
   const int grid = (tiles <= n_cu || no_persist) ? tiles : n_cu;
   static const bool timing = gvl_lab_env("GVL_GEMM_TIMING") != nullptr;                        // anatomy probe (tools/gemm_one.py)
@@ -613,10 +624,11 @@ int gvl_launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     // gemm_a4 (gvl_debug_set): 0 = always the 8-wave kernel, 1 (default) = big_form_preferred, 2 = the plain 4-wave kernel wherever it serves, 3 = the pipelined one
     // wherever it serves (then the plain one)
     int form = cfg;
-    if (cfg == 80) form = g_a4_mode == 0 ? 82 : (g_a4_mode == 1 ? big_form_preferred(epi) : (g_a4_mode == 2 ? 86 : 88));
+    const int a4m = g_a4_mode.load(std::memory_order_relaxed);
+    if (cfg == 80) form = a4m == 0 ? 82 : (a4m == 1 ? big_form_preferred(epi) : (a4m == 2 ? 86 : 88));
     GemmArgs b = a;
     if (b.band <= 0) b.band = GVL_GEMM_BAND;
-    if (g_band_override > 0) b.band = g_band_override;
+    if (const int bo = g_band_override.load(std::memory_order_relaxed); bo > 0) b.band = bo;
     if (stg_ok && form == 88) {
       const int rc4 = gvl_launch_gemm_a4p(b, epi, st);
       if (rc4 != -2) return rc4;

@@ -10,7 +10,13 @@
 // Reference shapes: models/internvideo2.py:587,603,631-634; models/modeling_phi3.py:459-464,659-663.
 #include "gvl_gemm_epi.h"
 #include "gvl_gemm4p_loop.inc"
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(16))) unsigned int u32x16_t;
@@ -52,6 +58,15 @@ template <int EPI> struct A4pAsm;
   };
 GVL_A4P_EPI_LIST(GVL_A4P_DEF)
 #undef GVL_A4P_DEF
+// NARROW statements (tools/gen_gemm4p.py, body(nb = 2)): a tile with <= 128 valid columns -- N = 1408 = 5.5 tile columns: every sixth tile of InternVideo2's proj /
+// fc2 -- runs as 4 waves x (128 rows x 64 columns): 32 instead of 64 MFMAs per wave and k-tile, none of them on the zero half.  Same deferred program, same k order
+// per output element: same bits.
+// The tile statements of these epilogues hold BOTH codes and branch on a flag the host puts into vp[12] (the row-scale slot: these epilogues have none): two asm statements under a C++ `if` made hipcc spill P at the join.
+constexpr int A4P_NARROW_MAX_NK = 32;
+template <int EPI> struct A4pNarrow { static constexpr bool has = false; static constexpr int MIN_NK = 1 << 30; };
+#define GVL_A4P_DEFN(E) template <> struct A4pNarrow<E> { static constexpr bool has = true; static constexpr int MIN_NK = GVL_A4P_MIN_NK_N_E##E; };
+GVL_A4P_NARROW_LIST(GVL_A4P_DEFN)
+#undef GVL_A4P_DEFN
 }  // namespace
 
 // LDS: ring 2 x 64 KiB | staging 4 waves x 4 KiB (the bias slice of a tile is DMA'd there for its drain) | LayerScale scratch 2 buffers x 4 x 512 B  OR  the Phi
@@ -91,14 +106,29 @@ __global__ __launch_bounds__(256) void gemm_a4p_kernel(const GemmArgs a, int til
   const unsigned pitchW = (unsigned)a.ldw * 2u, pitchA = (unsigned)a.lda * 2u;
   const unsigned ldcb = (unsigned)a.ldc * 2u, ldrb = (unsigned)a.ldr * 2u, ldqb = (unsigned)a.rowsq_ld * 4u;
   const unsigned nk = (unsigned)(a.K / BK);
+  // narrow tiles (A4pNarrow): the column tile that holds <= 128 real columns; wave (wm, wn) then owns columns 64 wn ... 64 wn + 63 of it
+  // Only for K <= A4P_NARROW_MAX_NK k-tiles: a narrow k-tile is 1 024 MFMA cycles, less than the latency of an operand piece that comes from HBM -- at K = 6144
+  // (InternVideo2 fc2: A streams from HBM) a narrow tile measured 1.16 x a full one; at K = 1408 (proj: A is the attention output, cache-resident) ~0.7 x
+  const bool can_narrow = A4pNarrow<EPI>::has && a.narrow && (int)nk >= A4pNarrow<EPI>::MIN_NK && (int)nk <= A4P_NARROW_MAX_NK;
+  auto is_narrow = [&](int n0_) { return can_narrow && a.N - n0_ <= 128; };
   // LayerScale gamma -> buffer `gb` of the wave's gamma scratch (read by the deferred program one statement LATER: two buffers, alternating per tile).  The bias is
   // not staged by this code at all: the loop statement DMAs the tile's slice into the idle staging area (tools/gen_gemm4p.py, LAST body)
   auto store_gamma = [&](const u32x2_t& gv, unsigned gb) {
     if constexpr (G::has_gamma) *(u32x2_t*)(smem + A4P_GAMMA_OFF + gb * 2048 + wave * 512 + fresh_lane() * 8) = gv;
   };
 
-  int it = bid >> 3;
-  if (it >= xcnt) return;
+  // Tile walk: round j of this XCD = the wpx consecutive tiles [j wpx, (j + 1) wpx) of its chunk (what its CUs run at the same time: the L2 sharing set); workgroup c
+  // takes offset (c + rot[j]) mod wpx of the round.  rot = 0 is the fixed assignment of rounds <= 6a; with NARROW tiles (0.7 of a tile's time, every sixth tile at
+  // N = 1408) the fixed assignment hands all of them to a quarter of the CUs and nobody finishes earlier -- the launcher's rot table (balance_rounds) spreads them evenly.
+  const int cw = bid >> 3;
+  if (cw >= xcnt) return;
+  const int rounds = (xcnt + wpx - 1) / wpx;
+  auto vid_of = [&](int j) -> int {                  // tile of round j, or -1 (only the last round can leave a workgroup without one)
+    int o = cw + (int)a.rot[j & (GVL_GEMM_ROT_LEN - 1)];
+    o = o >= wpx ? o - wpx : o;
+    const int v = j * wpx + o;
+    return (j < rounds && v < xcnt) ? xbase + v : -1;
+  };
   if (smem_base & 0x1ffffu) __builtin_trap();        // the ring slots are toggled by XOR 0x10000: the dynamic LDS block must start at a multiple of 128 KiB (it starts at 0)
 
   // scalar block A: what does not change from tile to tile (dma_other, the scratch addresses are patched per tile)
@@ -123,22 +153,24 @@ __global__ __launch_bounds__(256) void gemm_a4p_kernel(const GemmArgs a, int til
   sb.set(12, ldcb * 8u); sb.set(13, ldrb * 8u); sb.set(14, ldqb * 8u);
 
   // per-tile pieces -------------------------------------------------------------------------------------------------------------------------------------
-  auto loop_params = [&](int m0, int n0, int m0n, int n0n, bool has_next, unsigned par) {
+  auto loop_params = [&](int m0, int n0, int m0n, int n0n, bool has_next, unsigned par, bool narrow) {
+    const int wcol = wn * (narrow ? 64 : TN);
     const int lane = fresh_lane();
     const int l31 = lane & 31, h = lane >> 5;
     const unsigned rd_lane = (unsigned)(l31 * 128 + ((h ^ ((l31 >> 1) & 7)) << 4));    // this lane's k-step-0 chunk of fragment row l31
     const int rowl = wave * 8 + (lane >> 3);                                            // DMA piece i covers tile rows 32 i + rowl, chunk lane & 7 of the LDS row
     const unsigned dma_lane = (unsigned)(((lane & 7) ^ ((rowl >> 1) & 7)) << 4);
-    vp[0] = smem_base + par * SLOT + (unsigned)(wn * TN * 128) + rd_lane; vp[1] = smem_base + par * SLOT + (unsigned)(BN * 128 + wm * TM * 128) + rd_lane;
+    vp[0] = smem_base + par * SLOT + (unsigned)(wcol * 128) + rd_lane; vp[1] = smem_base + par * SLOT + (unsigned)(BN * 128 + wm * TM * 128) + rd_lane;
     vp[2] = (unsigned)(n0 + rowl) * pitchW + dma_lane; vp[3] = (unsigned)(m0 + rowl) * pitchA + dma_lane;
     vp[4] = has_next ? (unsigned)(n0n + rowl) * pitchW + dma_lane : 0x80000000u; vp[5] = has_next ? (unsigned)(m0n + rowl) * pitchA + dma_lane : 0x80000000u;
-    vp[11] = (unsigned)(n0 + wn * TN + lane) * 4u;                                       // bias of this tile's columns (beyond N: out of the resource's range -> 0)
+    vp[11] = (unsigned)(n0 + wcol + lane) * 4u;                                       // bias of this tile's columns (beyond N: out of the resource's range -> 0)
     sa.set(10, smem_base + (par ^ 1u) * SLOT + (unsigned)wave * 1024u);
   };
   // the deferred program's view of a finished tile (wave tile at mw, nw): resources over its existing rows, per-lane offsets (row lane >> 3, 16-byte piece lane & 7)
-  auto defer_params = [&](int m0, int n0) {
+  auto defer_params = [&](int m0, int n0, bool narrow) {
     const int lane = fresh_lane();
-    const int mw = m0 + wm * TM, nw = n0 + wn * TN;
+    const int mw = m0 + wm * TM, nw = n0 + wn * (narrow ? 64 : TN);
+    const int nlim = narrow && nw + 64 < a.N ? nw + 64 : a.N;      // narrow: the wave tile IS its first 64 columns (a scalar limit: a per-lane `&& !(narrow && half)` made hipcc spill vp)
     const int rows_ok = a.M - mw < TM ? (a.M - mw > 0 ? a.M - mw : 0) : TM;
     const unsigned long long pc = (unsigned long long)a.C + (unsigned long long)(mw + a.row_off) * ldcb;
     sb.set(0, __builtin_amdgcn_readfirstlane((unsigned)pc)); sb.set(1, __builtin_amdgcn_readfirstlane((unsigned)(pc >> 32)) & 0xffffu); sb.set(2, (unsigned)rows_ok * ldcb);
@@ -154,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm_a4p_kernel(const GemmArgs a, int til
     for (int half = 0; half < 2; ++half) {
       // SwiGLU: the wave tile has 64 OUTPUT columns (one 128-byte piece row), at column nw / 2 of the [M, N / 2] output
       const int col = G::silu ? (nw >> 1) + (lane & 7) * 8 : nw + half * 64 + (lane & 7) * 8;
-      const bool ok = G::silu ? (half == 0 && col < (a.N >> 1)) : col < a.N;
+      const bool ok = G::silu ? (half == 0 && col < (a.N >> 1)) : col < nlim;
       vp[6 + half] = ok ? (unsigned)(lane >> 3) * ldcb + (unsigned)col * 2u : 0x80000000u;
       if constexpr (G::has_resid) vp[8 + half] = ok ? (unsigned)(lane >> 3) * ldrb + (unsigned)col * 2u : 0x80000000u;
     }
@@ -162,57 +194,121 @@ __global__ __launch_bounds__(256) void gemm_a4p_kernel(const GemmArgs a, int til
       // row statistics: lane L keeps, per piece k, the sum of pass L & 7 = (block row j, column half) for row 32 j + 8 k + (L >> 3): one store per k writes them all
       const int pj = (lane & 7) >> 1, phalf = lane & 1;
       const int blk = (nw >> 6) + phalf;
-      vp[10] = blk * 64 < a.N ? (unsigned)(32 * pj + (lane >> 3)) * ldqb + (unsigned)blk * 4u : 0x80000000u;
+      vp[10] = blk * 64 < nlim ? (unsigned)(32 * pj + (lane >> 3)) * ldqb + (unsigned)blk * 4u : 0x80000000u;
     }
   };
   auto load_rs = [&](int m0, float (&rs)[MB]) {
     if constexpr (G::has_rowscale) stg_request_rowscale<MB>(a, m0 + wm * TM, fresh_lane(), rs);
   };
   auto load_gamma = [&](int n0, u32x2_t& gv) {        // the two gamma values of columns nw + 2 lane, + 1 (overhanging columns read a valid address and are never stored)
-    if constexpr (G::has_gamma) { int c0 = n0 + wn * TN + fresh_lane() * 2; c0 = c0 + 2 <= a.N ? c0 : a.N - 2; gv = *(const u32x2_t*)(a.gamma + c0); }
+    if constexpr (G::has_gamma) { int c0 = n0 + wn * (is_narrow(n0) ? 64 : TN) + fresh_lane() * 2; c0 = c0 + 2 <= a.N ? c0 : a.N - 2; gv = *(const u32x2_t*)(a.gamma + c0); }
   };
 
   PRegs P;
   int m0, n0, m0n = 0, n0n = 0;
-  tile_of(xbase + it, m0, n0);
+  int jr = 0;
+  tile_of(vid_of(0), m0, n0);
   unsigned par = 0;
   float rs[MB], rsn[MB];
   u32x2_t gv, gvn;
   load_rs(m0, rs);
   load_gamma(n0, gv);
-  bool has_next = it + wpx < xcnt;
-  if (has_next) tile_of(xbase + it + wpx, m0n, n0n);
-  loop_params(m0, n0, m0n, n0n, has_next, par);
+  int vnext = vid_of(1);
+  bool has_next = vnext >= 0;
+  if (has_next) tile_of(vnext, m0n, n0n);
+  bool nar = is_narrow(n0);
+  loop_params(m0, n0, m0n, n0n, has_next, par, nar);
   asm volatile(GVL_A4P_DMA_TILE_ASM : : GVL_A4P_IN(vp, sa, sb) : "memory", "scc", GVL_A4P_CLOBBER_SGPRS, "v232", "v233");
   unsigned gb = 0;                                   // gamma buffer of the tile about to run
   store_gamma(gv, gb);
   if (has_next) { load_rs(m0n, rsn); load_gamma(n0n, gvn); }
 #pragma unroll
-  for (int j = 0; j < MB; ++j) vp[12 + j] = G::has_rowscale ? __builtin_bit_cast(unsigned, rs[j]) : 0u;
+  for (int j = 0; j < MB; ++j) vp[12 + j] = G::has_rowscale ? __builtin_bit_cast(unsigned, rs[j]) : ((A4pNarrow<EPI>::has && j == 0 && nar) ? 1u : 0u);   // (no row scale: slot 12 = the narrow flag)
   A4pAsm<EPI>::tile0(P, vp, sa, sb);
   par = (par + nk) & 1u;
   int m0p = m0, n0p = n0;
-  for (it += wpx; it < xcnt; it += wpx) {
+  bool narp = nar;
+  for (jr = 1; has_next; ++jr) {
     m0 = m0n; n0 = n0n;
-    has_next = it + wpx < xcnt;
-    if (has_next) tile_of(xbase + it + wpx, m0n, n0n);
+    vnext = vid_of(jr + 1);
+    has_next = vnext >= 0;
+    if (has_next) tile_of(vnext, m0n, n0n);
     // the operands requested one tile ahead have landed (the loop statement waited for every vector-memory operation of this wave)
     sa.set(13, smem_base + A4P_GAMMA_OFF + gb * 2048u + (unsigned)wave * 512u);      // the deferred program of this statement belongs to the PREVIOUS tile
     gb ^= 1u;
     store_gamma(gvn, gb);
+    nar = is_narrow(n0);
 #pragma unroll
-    for (int j = 0; j < MB; ++j) vp[12 + j] = G::has_rowscale ? __builtin_bit_cast(unsigned, rsn[j]) : 0u;
+    for (int j = 0; j < MB; ++j) vp[12 + j] = G::has_rowscale ? __builtin_bit_cast(unsigned, rsn[j]) : ((A4pNarrow<EPI>::has && j == 0 && nar) ? 1u : 0u);
     if (has_next) { load_rs(m0n, rsn); load_gamma(n0n, gvn); }
-    loop_params(m0, n0, m0n, n0n, has_next, par);
-    defer_params(m0p, n0p);
+    loop_params(m0, n0, m0n, n0n, has_next, par, nar);
+    defer_params(m0p, n0p, narp);
     A4pAsm<EPI>::tile(P, vp, sa, sb);
     par = (par + nk) & 1u;
-    m0p = m0; n0p = n0;
+    m0p = m0; n0p = n0; narp = nar;
   }
-  defer_params(m0p, n0p);
+  defer_params(m0p, n0p, narp);
   sa.set(13, smem_base + A4P_GAMMA_OFF + gb * 2048u + (unsigned)wave * 512u);
   A4pAsm<EPI>::flush(P, vp, sa, sb);
 }
+
+// Which offset of its XCD's round a workgroup takes (GemmArgs.rot), chosen so that the NARROW tiles (cost ~0.7 of a tile) are spread evenly over the workgroups: a greedy
+// pass over the rounds, one shift per round for all XCDs, minimising the largest accumulated load (then the sum of squares).  Mirrors the kernel's walk exactly
+// (chunk per XCD, band rasterisation).  Cached per geometry: a few hundred thousand cheap steps once per shape.
+namespace {
+struct RotKey { int tm, tn, band, grid, n_tail; bool operator<(const RotKey& o) const { return std::tie(tm, tn, band, grid, n_tail) < std::tie(o.tm, o.tn, o.band, o.grid, o.n_tail); } };
+struct RotTab { unsigned char r[GVL_GEMM_ROT_LEN]; };
+std::mutex g_rot_mu;
+std::map<RotKey, RotTab> g_rot_cache;
+}  // namespace
+static void balance_rounds(int tiles_m, int tiles_n, int band, int grid, bool last_col_narrow, unsigned char (&rot)[GVL_GEMM_ROT_LEN]) {
+  memset(rot, 0, sizeof(rot));
+  if (!last_col_narrow || grid < 16) return;
+  const RotKey key{tiles_m, tiles_n, band, grid, 1};
+  { std::lock_guard<std::mutex> lk(g_rot_mu); auto it = g_rot_cache.find(key); if (it != g_rot_cache.end()) { memcpy(rot, it->second.r, sizeof(rot)); return; } }
+  const int nwg = tiles_m * tiles_n, q = nwg >> 3, r = nwg & 7;
+  int xbase[8], xcnt[8], wpx[8], max_rounds = 0;
+  for (int x = 0; x < 8; ++x) {
+    xbase[x] = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q; xcnt[x] = q + (x < r ? 1 : 0); wpx[x] = (grid + 7 - x) >> 3;
+    if (wpx[x] > 0) max_rounds = std::max(max_rounds, (xcnt[x] + wpx[x] - 1) / wpx[x]);
+  }
+  auto cost = [&](int vid) {                    // narrow: the last tile column
+    const int bw = band * tiles_n, g = vid / bw, first_m = g * band, gm = std::min(band, tiles_m - first_m);
+    return (vid - g * bw) / gm == tiles_n - 1 ? 0.7f : 1.0f;
+  };
+  std::vector<float> load(8 * 64, 0.f);
+  RotTab tab; memset(tab.r, 0, sizeof(tab.r));
+  const int w0 = wpx[0];
+  bool uniform = w0 <= 64; for (int x = 0; x < 8; ++x) uniform = uniform && wpx[x] == w0;     // one shift must mean the same thing on every XCD
+  if (uniform && max_rounds <= GVL_GEMM_ROT_LEN) {
+    for (int j = 0; j < max_rounds; ++j) {
+      int best = 0; float best_mx = 1e30f, best_sq = 1e30f;
+      for (int sft = 0; sft < w0; ++sft) {
+        float mx = 0.f, sq = 0.f;
+        for (int x = 0; x < 8; ++x)
+          for (int c = 0; c < w0; ++c) {
+            int o = c + sft; o = o >= w0 ? o - w0 : o;
+            const int v = j * w0 + o;
+            const float l = load[x * 64 + c] + (v < xcnt[x] ? cost(xbase[x] + v) : 0.f);
+            mx = std::max(mx, l); sq += l * l;
+          }
+        if (mx < best_mx - 1e-4f || (mx < best_mx + 1e-4f && sq < best_sq - 1e-3f)) { best = sft; best_mx = mx; best_sq = sq; }
+      }
+      tab.r[j] = (unsigned char)best;
+      for (int x = 0; x < 8; ++x)
+        for (int c = 0; c < w0; ++c) {
+          int o = c + best; o = o >= w0 ? o - w0 : o;
+          const int v = j * w0 + o;
+          if (v < xcnt[x]) load[x * 64 + c] += cost(xbase[x] + v);
+        }
+    }
+  }
+  memcpy(rot, tab.r, sizeof(rot));
+  std::lock_guard<std::mutex> lk(g_rot_mu); g_rot_cache[key] = tab;
+}
+
+static std::atomic<int> g_narrow{1};          // A/B only, process-wide like gemm_a4 / gemm_band
+void gvl_gemm_set_narrow(int v) { g_narrow.store(v, std::memory_order_relaxed); }
 
 template <int EPI>
 static int launch_a4p(const GemmArgs& a_in, hipStream_t st) {
@@ -228,7 +324,11 @@ static int launch_a4p(const GemmArgs& a_in, hipStream_t st) {
   const int tiles_m = (a.M - a.m_begin + 255) / 256, tiles_n = (a.N + 255) / 256;
   const int tiles = tiles_m * tiles_n;
   if (a.band <= 0) a.band = GVL_GEMM_BAND;
+  a.narrow = g_narrow.load(std::memory_order_relaxed);
   const int grid = tiles <= n_cu ? tiles : n_cu;
+  // gemm_narrow: 1 = narrow tiles + balanced walk, 2 = narrow tiles on the fixed walk (A/B), 0 = neither
+  const bool has_narrow_col = A4pNarrow<EPI>::has && a.narrow && a.K / BK >= A4pNarrow<EPI>::MIN_NK && a.K / BK <= A4P_NARROW_MAX_NK && tiles_n * 256 - a.N >= 128;
+  balance_rounds(tiles_m, tiles_n, a.band, grid, has_narrow_col && a.narrow == 1, a.rot);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), a4p_lds<EPI>(), st, a, tiles_m, tiles_n);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

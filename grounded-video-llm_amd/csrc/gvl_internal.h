@@ -25,6 +25,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 constexpr int GVL_MAX_DECODE_BATCH = 16;  // sequences decoded together: the weight stream is read ONCE for all of them;
                                           // = the 16 columns of the MFMA B operand of the skinny decode GEMM (gvl_decode.hip)
 constexpr int GVL_MAX_VALU_BATCH = 4;     // the round-1 VALU GEMV (fallback for K % 256 != 0 geometries) holds B vectors in LDS: 1, 2 or 4
+constexpr int GVL_GEMM_ROT_LEN = 64;     // GemmArgs.rot entries (a power of two; longer walks repeat the table)
 constexpr int GVL_MAX_PREFILL_BATCH = 8;  // most sequences whose rows share one pass of the prefill GEMMs (gvl_debug_set prefill_group picks 1 .. 8; default 4)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a host may hold one gvl_ctx per device in ONE process
@@ -144,6 +145,8 @@ struct GemmArgs {
   int grp_rows, grp_stride, row_off;
   int tile_cfg;                  // 0 auto; see gvl_launch_gemm
   int band;                      // ping-pong kernel: tile ROWS per rasterisation band (0 = the launcher's choice); any value gives the same result
+  unsigned char rot[64];         // pipelined 4-wave kernel: workgroup c of an XCD takes offset (c + rot[round & 63]) mod (workgroups of the XCD) of its XCD's round (0: fixed)
+  int narrow;                    // set by the pipelined 4-wave launcher: tiles with <= 128 real columns run its narrow statements (gvl_debug_set "gemm_narrow"); result-neutral
   int m_begin;                   // launch covers rows [m_begin, M) -- set internally by the wave-quantisation split
   // Fused RMSNorm (round 5).  CONSUMER side: rowscale[m] (f32, [M]) multiplies row m of the accumulator BEFORE bias / activation -- RMSNorm(x) . W^T =
   // rs[m] * (x . (W diag(gamma))^T): A is the RAW residual stream, W carries the norm weight (gvl_fold_gamma), rs = rsqrt(mean x^2 + eps).
@@ -166,6 +169,7 @@ int gvl_launch_gemm_a4(const GemmArgs& a, int epi, int var, hipStream_t st);
 // gvl_gemm4p.hip: the same kernel with the epilogue software-pipelined into the next tile's main loop; -2 as above
 int gvl_launch_gemm_a4p(const GemmArgs& a, int epi, hipStream_t st);
 void gvl_gemm_set_a4(int v);     // A/B: 0 = the 256 x 256 launches stay on the 8-wave ping-pong kernel, 1 (default) = the 4-wave kernel where it is faster, 2 = wherever it serves
+void gvl_gemm_set_narrow(int v); // A/B: 0 = the pipelined 4-wave kernel runs a half-empty column tile (N = 1408: every sixth) as a full one (rounds <= 6a), 1 (default) = as a narrow tile
 void gvl_gemm_set_band(int v);   // A/B: tile rows per rasterisation band of the ping-pong kernel for every later launch of the process (0 = automatic)
 double gvl_gemm_flops(const GemmArgs& a);
 

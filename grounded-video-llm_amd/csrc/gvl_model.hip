@@ -1431,6 +1431,7 @@ int gvl_debug_set(gvl_ctx* ctx, const char* key, int value) {
   else if (k == "last_layer_tail") ctx->dbg.last_layer_tail = value != 0;
   else if (k == "gemm_band") { if (value < 0 || value > 64) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: gemm_band must be 0 (automatic) .. 64"); gvl_gemm_set_band(value); }
   else if (k == "gemm_a4") { if (value < 0 || value > 3) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: gemm_a4 must be 0 .. 3"); gvl_gemm_set_a4(value); }
+  else if (k == "gemm_narrow") gvl_gemm_set_narrow(value < 0 || value > 2 ? 1 : value);
   else if (k == "vision_in_place") { if (value < 0 || value > 2) return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: vision_in_place must be 0, 1 or 2"); ctx->dbg.vision_in_place = value; }
   else return fail(ctx, GVL_ERR_ARG, "gvl_debug_set: unknown key " + k);
   return 0;

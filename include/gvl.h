@@ -279,6 +279,9 @@ int gvl_prof_read(gvl_ctx* ctx, int category, double* total_ms, int64_t* launche
  *                      (gvl_gemm4.hip: accumulators in AGPRs, hand-placed k loop) for store-only epilogues, the 8-wave ping-pong kernel for the rest;
  *                      0: always the 8-wave kernel; 2: the plain 4-wave kernel wherever it serves; 3: the pipelined one wherever it serves.  For every later
  *                      launch of the PROCESS -- bit-identical
+ *   "gemm_narrow"      1 (default): the pipelined 4-wave kernel runs a column tile with <= 128 real columns (N = 1408 = 5.5 tile columns: every sixth tile of
+ *                      InternVideo2's proj / fc2) as a NARROW tile -- 4 waves x (128 rows x 64 columns), no MFMA on the empty half; 0: as a full tile.  For every
+ *                      later launch of the PROCESS -- bit-identical
  *   "last_layer_tail"  1 (default): a prefill without a loss request runs the LAST decoder layer's MLP on the sequences' last rows only (nothing else reads its
  *                      output); 0: on every row -- bit-identical
  *   "patch_fused"      1 (default): the patch embedding of a tower whose geometry the fused kernel covers (patch 14, width 1024 / 1408) runs as ONE kernel

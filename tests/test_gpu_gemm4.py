@@ -166,3 +166,41 @@ def test_pipelined_heavy_epilogues_repeated_launches_are_stable(eng):
                 assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1]), f"{name}, launch {it}"
             else:
                 assert torch.equal(want, got), f"{name}, launch {it}"
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 1408, 1408), (24588, 1408, 1024), (9000, 1344, 1408), (5000, 1472, 1088), (3000, 128, 1408), (70001, 384, 1024), (20000, 1408, 6144), (8000, 1408, 2048),
+                                   (6000, 1408, 960)])
+def test_narrow_column_tiles_bit_identical(eng, M, N, K):
+    """The pipelined kernel runs a column tile with <= 128 real columns as a NARROW tile (4 waves x 128 rows x 64 columns: tools/gen_gemm4p.py body(nb = 2); N = 1408 =
+    5.5 tile columns is InternVideo2's proj / fc2).  gvl_debug_set("gemm_narrow", 0 | 1) must not change a bit of the output or of the row statistics, against the 8-wave
+    kernel, for tails of 128 / 64 columns (and 192: stays a wide tile), N <= 128 (every tile narrow), K at the narrow statement's minimum (16 k-tiles) and below it (K = 960: wide code), at its maximum (K = 2048) and above it (K = 6144: wide code -- operands from HBM arrive slower than a narrow k-tile runs)."""
+    A, W, g = _ops(M, N, K, 29)
+    bias = torch.randn((N,), device=DEV, generator=g) * 0.5
+    gam = torch.randn((N,), device=DEV, generator=g) * 0.1
+    resb = torch.randn((M, N), device=DEV, generator=g).to(bf)
+    kw = dict(bias=bias, gamma=gam, resid=resb)
+    wc, wq = eng.op_gemm_rows(A, W, want_rowsq=True, tile_cfg=82, **kw)
+    try:
+        for nar in (1, 2, 0, 1):      # 1: narrow tiles + the balanced tile walk (GemmArgs.rot), 2: narrow tiles on the fixed walk, 0: neither
+            eng.debug_set("gemm_narrow", nar)
+            for rep in range(2):
+                c, q = eng.op_gemm_rows(A, W, want_rowsq=True, tile_cfg=88, **kw)
+                bad = (c != wc).nonzero()
+                assert bad.numel() == 0, f"gemm_narrow={nar} {M}x{N}x{K}: {bad.shape[0]} outputs differ, first at {bad[0].tolist()}, last at {bad[-1].tolist()}"
+                badq = (q != wq).nonzero()
+                assert badq.numel() == 0 and not torch.isnan(q).any(), f"gemm_narrow={nar} {M}x{N}x{K}: {badq.shape[0]} row statistics differ, first at {badq[0].tolist() if badq.numel() else None}"
+    finally:
+        eng.debug_set("gemm_narrow", 1)
+
+
+def test_narrow_column_tiles_in_place_residual_repeated(eng):
+    """race screen: x += LayerScale(att W^T + b) in place with the statistics, N = 1408, many tiles per workgroup, narrow and wide statements alternating inside a workgroup"""
+    M, N, K = 60000, 1408, 1408
+    A, W, g = _ops(M, N, K, 31)
+    bias = torch.randn((N,), device=DEV, generator=g) * 0.5
+    gam = torch.randn((N,), device=DEV, generator=g) * 0.1
+    x = torch.randn((M, N), device=DEV, generator=g).to(bf)
+    wc, wq = eng.op_gemm_rows(A, W, want_rowsq=True, tile_cfg=82, bias=bias, gamma=gam, resid=x)
+    for _ in range(12):
+        c, q = eng.op_gemm_rows(A, W, want_rowsq=True, tile_cfg=88, bias=bias, gamma=gam, resid=x)
+        assert torch.equal(c, wc) and torch.equal(q, wq)

@@ -63,11 +63,16 @@ def main():
             kw["want_rowsq"] = True
 
         def run(cfg, n):
-            if cfg >= 1000:
+            # cfg 2000 / 2001 / 2002: automatic configuration under gvl_debug_set("gemm_narrow", 0 / 1 / 2) -- A/B of the narrow column tiles
+            if cfg >= 2000:
+                eng.debug_set("gemm_narrow", cfg - 2000)
+            elif cfg >= 1000:
                 eng.debug_set("gemm_band", cfg - 1000)
             for _ in range(n):
                 (eng.op_gemm_rows if rows else eng.op_gemm)(A, W, tile_cfg=0 if cfg >= 1000 else cfg, **kw)
-            if cfg >= 1000:
+            if cfg >= 2000:
+                eng.debug_set("gemm_narrow", 1)
+            elif cfg >= 1000:
                 eng.debug_set("gemm_band", 0)
         for c in CFGS:
             run(c, 2)

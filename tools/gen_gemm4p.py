@@ -97,9 +97,9 @@ def mfma(j, i, f, czero):
     return f"v_mfma_f32_32x32x16_bf16 {acc(j, i)}, {vr(f.w[i])}, {vr(f.a[j])}, " + ("0" if czero else acc(j, i))
 
 
-def reads(ph, dst):
+def reads(ph, dst, nb=NB):
     out = []
-    for i in range(NB):
+    for i in range(nb):
         out.append([f"ds_read_b128 {vr(dst.w[i])}, v{RDW[ph]} offset:{i * 4096}"])
     out[-1].append(f"v_xor_b32 v{RDW[ph]}, 0x{SLOT:x}, v{RDW[ph]}")
     for j in range(MB):
@@ -118,60 +118,88 @@ def piece(op):
 
 
 class Phase:
-    def __init__(self):
-        self.pre, self.gaps, self.post, self.mf = [], [[] for _ in range(16)], [], []
-        self.extra = [0] * 16        # deferred instructions placed per gap
+    def __init__(self, ngaps=16, cap=None):
+        self.pre, self.gaps, self.post, self.mf = [], [[] for _ in range(ngaps)], [], []
+        self.cap = cap               # instructions per gap (None: the module's CAP)
 
     def lines(self):
         L = list(self.pre)
-        for n in range(16):
+        for n in range(len(self.gaps)):
             L.append(self.mf[n])
             L += self.gaps[n]
         return L + self.post
 
 
-def body(kind, epi=0):
-    """one k-tile as 4 Phase objects"""
+DMA_ORDER = os.environ.get("GVL_A4P_DMAORDER", "WA")      # LAB: "AW" = the A pieces in phase 3, the W pieces in phase 0 of the next k-tile
+NARROW_CAP = int(os.environ.get("GVL_A4P_NCAP", "9"))     # instructions per MFMA gap of a NARROW body (half the gaps per k-tile carry the same deferred program)
+
+
+def body(kind, epi=0, nb=NB):
+    """one k-tile as 4 Phase objects.  nb = 4: the 128 x 128 wave tile (16 MFMAs per phase).  nb = 2 (NARROW, a tile with <= 128 valid columns -- N = 1408's last
+    column tile): the wave tile is 128 rows x 64 columns (wave (wm, wn) -> columns 64 wn ...), 8 MFMAs per phase, two W fragments per k step, and the steady k-tiles
+    fetch only the 4 W pieces that hold real rows; the prefetch of the NEXT tile's first k-tile (PENULT / LAST) stays complete -- that tile may be a wide one."""
     phs = []
+    ng = MB * nb
+    narrow = nb != NB
     for p in range(4):
-        ph = Phase()
+        ph = Phase(ng, NARROW_CAP if narrow else None)
         use, nxt = (X, Y) if p % 2 == 0 else (Y, X)
         if p < 3:
             ph.pre.append("s_waitcnt lgkmcnt(0)")
         if not (kind == "LAST" and p == 3):
-            for g, ins in zip(READ_GAPS, reads((p + 1) % 4, nxt)):
+            for g, ins in zip(READ_GAPS, reads((p + 1) % 4, nxt, nb)):
                 ph.gaps[g] += ins
         plan = []
+        nw_own = 4 if narrow else 8             # W pieces of THIS tile's k-tiles
+        # which operand's pieces go first (phase 3 of k-tile t: a full k-tile to land) and which second (phase 0 of k-tile t + 1: three phases): DMA_ORDER
+        a_first = DMA_ORDER == "AW"
         if p == 0:
-            srcA = f"v{V_VOAN}" if kind == "LAST" else f"v{V_VOA}"
             if kind == "FIRST":
-                plan = [("W", i) for i in range(8)] + [("A", i) for i in range(8)]
-                ph.pre += [f"v_mov_b32 v{RW}, v{V_VOW}", f"v_mov_b32 v{RA}, {srcA}"]
+                plan = [("W", i) for i in range(nw_own)] + [("A", i) for i in range(8)]
+                ph.pre += [f"v_mov_b32 v{RW}, v{V_VOW}", f"v_mov_b32 v{RA}, v{V_VOA}"]
+            elif DMA_ORDER == "P3":
+                plan = []
+            elif a_first:
+                plan = [("W", i) for i in range(8 if kind == "LAST" else nw_own)]
+                ph.pre += [f"v_mov_b32 v{RW}, " + (f"v{V_VOWN}" if kind == "LAST" else f"v{V_VOW}")]
             else:
                 plan = [("A", i) for i in range(8)]
-                ph.pre += [f"v_mov_b32 v{RA}, {srcA}"]
+                ph.pre += [f"v_mov_b32 v{RA}, " + (f"v{V_VOAN}" if kind == "LAST" else f"v{V_VOA}")]
         if p == 3 and kind != "LAST":
-            plan = [("W", i) for i in range(8)]
-            ph.pre += [f"v_mov_b32 v{RW}, " + (f"v{V_VOWN}" if kind == "PENULT" else f"v{V_VOW}")]
+            if DMA_ORDER == "P3":           # LAB: both operands in phase 3 (a full k-tile to land for both)
+                plan = [("W", i) for i in range(8 if kind == "PENULT" else nw_own)] + [("A", i) for i in range(8)]
+                ph.pre += [f"v_mov_b32 v{RW}, " + (f"v{V_VOWN}" if kind == "PENULT" else f"v{V_VOW}"), f"v_mov_b32 v{RA}, " + (f"v{V_VOAN}" if kind == "PENULT" else f"v{V_VOA}")]
+            elif a_first:
+                plan = [("A", i) for i in range(8)]
+                ph.pre += [f"v_mov_b32 v{RA}, " + (f"v{V_VOAN}" if kind == "PENULT" else f"v{V_VOA}")]
+            else:
+                plan = [("W", i) for i in range(8 if kind == "PENULT" else nw_own)]
+                ph.pre += [f"v_mov_b32 v{RW}, " + (f"v{V_VOWN}" if kind == "PENULT" else f"v{V_VOW}")]
         if plan:
-            dg = DMA_GAPS16 if len(plan) == 16 else DMA_GAPS8
+            if narrow:
+                dg = [k * ng // len(plan) for k in range(len(plan))]        # spread over the 8 gaps (12 pieces: two in every other gap)
+            else:
+                dg = DMA_GAPS16 if len(plan) == 16 else DMA_GAPS8
             ph.pre.append(m0_for(*plan[0]))
             for k, (op, i) in enumerate(plan):
                 ph.gaps[dg[k]] += piece(op)
                 if k + 1 < len(plan):
                     ph.gaps[dg[k]].append(m0_for(*plan[k + 1]))
+                    if dg[k + 1] == dg[k]:
+                        ph.gaps[dg[k]].append("s_nop 0")       # M0 write -> LDS-DMA issue needs a wait state when no MFMA separates them
         if p == 1 and kind == "LAST" and (epi & 32):
             # the bias slice of this tile (128 floats of the wave's columns) -> the wave's staging area, idle since the deferred program ended; waited for by the
             # end-of-phase-2 vmcnt(0) below, read by the drain.  No DMA piece of the loop is pending in this phase: M0 is free.
-            ph.gaps[8] += [f"s_mov_b32 m0, s{S_LSTG}"]
-            ph.gaps[9] += [f"buffer_load_dword v{V_VOB}, {sr(S_RSB)}, 0 offen lds"]
-            ph.gaps[10] += [f"buffer_load_dword v{V_VOB}, {sr(S_RSB)}, 0 offen offset:256 lds"]
+            g0 = ng // 2
+            ph.gaps[g0] += [f"s_mov_b32 m0, s{S_LSTG}"]
+            ph.gaps[g0 + 1] += [f"buffer_load_dword v{V_VOB}, {sr(S_RSB)}, 0 offen lds"]
+            ph.gaps[g0 + 2] += [f"buffer_load_dword v{V_VOB}, {sr(S_RSB)}, 0 offen offset:256 lds"]
         if p == 1 and kind != "LAST":
             ph.gaps[0] += [f"s_mov_b32 s{S_KOFF}, 0" if kind == "PENULT" else f"s_add_u32 s{S_KOFF}, s{S_KOFF}, 128", f"s_xor_b32 s{S_DMA}, s{S_DMA}, 0x{SLOT:x}"]
         if p == 2:
             ph.post += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
         for j in range(MB):
-            for i in range(NB):
+            for i in range(nb):
                 ph.mf.append(mfma(j, i, use, kind == "FIRST" and p == 0))
         # LAB: GVL_A4P_LAB=synthK[d] -- K synthetic VALU fillers in EVERY gap of every body (d: one dependent chain instead of independent registers):
         # what a gap can really absorb (profiles/r06_gemm4p_filler_capacity.txt)
@@ -179,7 +207,7 @@ def body(kind, epi=0):
         if "synth" in lab:
             k = int(lab[lab.index("synth") + 5])
             dep = lab[lab.index("synth") + 6:lab.index("synth") + 7] == "d"
-            for g in range(16):
+            for g in range(ng):
                 for x in range(k):
                     r = T0 + (0 if dep else (g * k + x) % 16)
                     ph.gaps[g].append(f"v_add_u32 v{r}, v{r}, v{r}")
@@ -476,7 +504,7 @@ def place(bodies, prog):
         ph = bodies[pos[0]][pos[1]]
         if vm and pos[1] != 3:
             return False
-        return len(ph.gaps[pos[2]]) < CAP
+        return len(ph.gaps[pos[2]]) < (ph.cap or CAP)
 
     for kind, *rest in prog.items:
         if kind == "PH":
@@ -492,7 +520,7 @@ def place(bodies, prog):
             continue
         vm = kind == "VM"
         while True:
-            if pos[2] >= 16:
+            if pos[0] < len(bodies) and pos[2] >= len(bodies[pos[0]][pos[1]].gaps):
                 advance_phase()
                 continue
             if ok_here(vm):
@@ -509,7 +537,7 @@ def bias_reads(i_list):
     return [f"ds_read_b128 {vr(BIAS0 + 16 * i + 4 * b)}, v{V_BADDR} offset:{(i * 32 + 8 * b) * 4}" for i in i_list for b in range(4)]
 
 
-def drain_row(epi, j):
+def drain_row(epi, j, nb=NB):
     """a[block row j] -> (x row scale) (+ bias) -> bf16 pairs in P(j).  Batches of 4 pairs (8 reads, 4 packed ops, 4 converts): a dependent instruction sits >= 4
     issue slots behind its producer -- one wave per SIMD has nobody else to cover a VALU dependency stall.  The bias sits in registers (bias_reads)."""
     f = epi_flags(epi)
@@ -517,7 +545,7 @@ def drain_row(epi, j):
     if "nodrain" in os.environ.get("GVL_A4P_LAB", ""):
         return L
     rsp, hi = V_RS + 2 * (j // 2), j % 2
-    for i in range(NB):
+    for i in range(nb):
         for b0 in range(0, 4, 2):
             rd, op, cv = [], [], []
             for n, (b, q) in enumerate([(b, q) for b in (b0, b0 + 1) for q in range(2)]):
@@ -536,7 +564,7 @@ def drain_row(epi, j):
     return L
 
 
-def end_section(epi, stores):
+def end_section(epi, stores, nb=NB):
     """behind the last MFMA: the drain, block row by block row, with the finished tile's stores of row j + 1 spread through the drain of row j (row 0's stores sit in the
     gaps of the LAST body's phase 3): a store is issued before the drain overwrites its registers, and no s_waitcnt vmcnt is near -- the next one is the end of phase 2
     of the next tile's first k-tile, > 4 k cycles away."""
@@ -544,9 +572,9 @@ def end_section(epi, stores):
     if epi & 32:
         # bias of column blocks 2, 3 -> fragment set Y (blocks 0, 1 went to set X in the LAST body's phase 3, which multiplies out of Y): ONE exposed LDS round trip
         # for the tile's 64 values instead of one per (block row, column group) -- 32 of them, ~3 k cycles
-        L += bias_reads([2, 3]) + ["s_waitcnt lgkmcnt(0)"]
+        L += (bias_reads([2, 3]) if nb == NB else []) + ["s_waitcnt lgkmcnt(0)"]
     for j in range(MB):
-        D = drain_row(epi, j)
+        D = drain_row(epi, j, nb)
         S = stores[j + 1] if j + 1 < MB else []
         if not D:
             for pair in S:
@@ -579,19 +607,23 @@ def lane_setup(epi=0):
             f"v_lshlrev_b32 v{V_RADDR}, 7, v{u}", f"v_lshl_or_b32 v{V_RADDR}, v{t}, 4, v{V_RADDR}", f"v_add_u32 v{V_RADDR}, s{S_LSTG}, v{V_RADDR}"]
 
 
-def tile_asm(epi, with_deferred):
+def tile_asm(epi, with_deferred, nb=NB):
+    """nb = 2: the NARROW statement (body()): same deferred program (it belongs to the PREVIOUS tile, whatever that tile's kind), same stores; the main loop and the drain
+    cover column blocks 0, 1 only.  P of blocks 2, 3 keeps stale values: the next statement's program transposes and 'stores' them through offsets the host marked
+    invalid (0x80000000: dropped by the buffer bounds check)."""
     prog = deferred(epi) if (with_deferred and "nodefer" not in os.environ.get("GVL_A4P_LAB", "")) else Prog()
     stores = end_stores(epi) if with_deferred else [[] for _ in range(MB)]
+    ng = MB * nb
     # bodies that may carry deferred work: FIRST, E1 .. EU (unrolled STEADY), then the loop, PENULT, LAST
     u = 0
     while True:
-        bodies = [body("FIRST", epi)] + [body("STEADY", epi) for _ in range(u)]
+        bodies = [body("FIRST", epi, nb)] + [body("STEADY", epi, nb) for _ in range(u)]
         try:
             place(bodies, prog)
             break
         except RuntimeError:
             u += 1
-            assert u < 24, "deferred program too long"
+            assert u < 40, "deferred program too long"
     L = SHIFT + [f"s_mov_b32 s{S_M0}, m0", f"s_mov_b32 s{S_KOFF}, 128", f"s_mov_b32 s{S_DMA}, s{S_DMAO}", f"s_sub_u32 s{S_CNT}, s{S_NK}, {3 + u}"]
     for regs, src in ((RDW, V_RDW0), (RDA, V_RDA0)):
         L.append(f"v_mov_b32 v{regs[0]}, v{src}")
@@ -599,28 +631,29 @@ def tile_asm(epi, with_deferred):
             L.append(f"v_xor_b32 v{regs[ph]}, 0x{ph << 5:x}, v{regs[0]}")
     L += lane_setup(epi)
     L += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
-    for ins in reads(0, X):
+    for ins in reads(0, X, nb):
         L += ins
     for b in bodies:
         for ph in b:
             L += ph.lines()
-    L += [f"s_cmp_eq_u32 s{S_CNT}, 0", "s_cbranch_scc1 .Lgvl_a4p_pen_%=", *ALIGN_LOOP, ".Lgvl_a4p_loop_%=:"]
-    for ph in body("STEADY", epi):
+    sfx = "" if nb == NB else "n"
+    L += [f"s_cmp_eq_u32 s{S_CNT}, 0", f"s_cbranch_scc1 .Lgvl_a4p_pen{sfx}_%=", *ALIGN_LOOP, f".Lgvl_a4p_loop{sfx}_%=:"]
+    for ph in body("STEADY", epi, nb):
         L += ph.lines()
-    L += [f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", f"s_cmp_lg_u32 s{S_CNT}, 0", "s_cbranch_scc1 .Lgvl_a4p_loop_%=", ".Lgvl_a4p_pen_%=:"]
-    for ph in body("PENULT", epi):
+    L += [f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", f"s_cmp_lg_u32 s{S_CNT}, 0", f"s_cbranch_scc1 .Lgvl_a4p_loop{sfx}_%=", f".Lgvl_a4p_pen{sfx}_%=:"]
+    for ph in body("PENULT", epi, nb):
         L += ph.lines()
-    last = body("LAST", epi)
+    last = body("LAST", epi, nb)
     if epi & 32:
         for k, ins in enumerate(bias_reads([0, 1])):  # set X is dead in the last k-tile's phase 3 (no next k step to prefetch); the slice landed at the phase-2 wait
-            last[3].gaps[2 * k + 1 if k < 8 else 15].append(ins)
+            last[3].gaps[(2 * k + 1 if k < 8 else 15) if nb == NB else k].append(ins)
     for k, pair in enumerate(stores[0]):              # the finished tile's block row 0: behind the end-of-phase-2 wait of the last k-tile, in front of the drain
-        last[3].gaps[(2 * k) % 16] += pair
+        last[3].gaps[(2 * k) % 16 if nb == NB else k % ng] += pair
     for ph in last:
         L += ph.lines()
     # the last MFMAs' results must be readable by v_accvgpr_read (XDL write -> VALU read: 18 wait states for 16 passes)
     L += ["s_nop 15", "s_nop 3"]
-    L += end_section(epi, stores)
+    L += end_section(epi, stores, nb)
     L += [f"s_mov_b32 m0, s{S_M0}"]
     return L, u
 
@@ -654,6 +687,7 @@ def dma_tile_asm():
 
 
 EPIS = [0, 32, 64, 128, 8, 136, 184, 98, 3, 67]
+NARROW_EPIS = [184]       # epilogues that also get the narrow statements (InternVideo2 proj / fc2: N = 1408 = 5.5 tile columns)
 
 
 def macro(name, lines):
@@ -665,14 +699,27 @@ def render():
     for e in EPIS:
         t0, u0 = tile_asm(e, False)
         t1, u1 = tile_asm(e, True)
+        un = None
+        if e in NARROW_EPIS:
+            # ONE statement holds both codes and branches on s_narrow: two asm statements under a C++ `if` made hipcc spill P (134 VGPRs) at the join
+            n0_, _ = tile_asm(e, False, 2)
+            n1_, un = tile_asm(e, True, 2)
+            # the flag travels in v[V_RS] (these epilogues have no row scale; the statistics that live there are written later in the statement): a per-tile scalar
+            # in the s[36:51] block made hipcc build that tuple in VGPRs ("V_READFIRSTLANE_B32 of a tuple")
+            assert not epi_flags(e)["rs"]
+            both = lambda wide, nar: ([f"v_readfirstlane_b32 s{S_OC}, v{V_RS}", f"s_cmp_eq_u32 s{S_OC}, 0", "s_cbranch_scc1 .Lgvl_a4p_wide_%="] + nar
+                                      + ["s_branch .Lgvl_a4p_end_%=", ".Lgvl_a4p_wide_%=:"] + wide + [".Lgvl_a4p_end_%=:"])
+            t0, t1 = both(t0, n0_), both(t1, n1_)
         o += macro(f"GVL_A4P_TILE0_E{e}", t0) + macro(f"GVL_A4P_TILE_E{e}", t1) + macro(f"GVL_A4P_FLUSH_E{e}", flush_asm(e))
         o += [f"#define GVL_A4P_MIN_NK_E{e} {3 + u1}", ""]
+        if un is not None:
+            o += [f"#define GVL_A4P_MIN_NK_N_E{e} {3 + un}", ""]
     o += macro("GVL_A4P_DMA_TILE_ASM", dma_tile_asm())
     acl = ", ".join(f'"a{i}"' for i in range(256))
     vcl = ", ".join(f'"v{i}"' for i in range(V_LO, V_HI + 1))
     scl = ", ".join(f'"s{i}"' for i in S_WORK) + ', "vcc"'
     o += [f"#define GVL_A4P_CLOBBER_AGPRS {acl}", f"#define GVL_A4P_CLOBBER_VGPRS {vcl}", f"#define GVL_A4P_CLOBBER_SGPRS {scl}", ""]
-    o += ["#define GVL_A4P_EPI_LIST(X) " + " ".join(f"X({e})" for e in EPIS), ""]
+    o += ["#define GVL_A4P_EPI_LIST(X) " + " ".join(f"X({e})" for e in EPIS), "#define GVL_A4P_NARROW_LIST(X) " + " ".join(f"X({e})" for e in NARROW_EPIS), ""]
     return "\n".join(o)
 
 

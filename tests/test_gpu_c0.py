@@ -247,8 +247,9 @@ def test_kernel_form_of_the_big_gemm_changes_no_bit_at_full_size(c0):
     eng, geo, meta, g, sp, tseg = c0
     outs = {}
     try:
-        for mode in (0, 1, 2, 3):
-            eng.debug_set("gemm_a4", mode)
+        for mode in (0, 1, 2, 3, 10, 12):              # 10 / 12: the default form with gemm_narrow = 0 / 2 (full-width half tiles / narrow tiles on the fixed tile walk)
+            eng.debug_set("gemm_a4", 1 if mode >= 10 else mode)
+            eng.debug_set("gemm_narrow", mode - 10 if mode >= 10 else 1)
             vis = eng.encode_segments(sp, tseg)
             emb = eng.splice(meta["ids"], vis)
             seq = eng.seq_alloc(emb.shape[0] + 8)
@@ -257,7 +258,8 @@ def test_kernel_form_of_the_big_gemm_changes_no_bit_at_full_size(c0):
             outs[mode] = (vis.clone(), lg)
     finally:
         eng.debug_set("gemm_a4", 1)
-    for mode in (1, 2, 3):
+        eng.debug_set("gemm_narrow", 1)
+    for mode in (1, 2, 3, 10, 12):
         assert torch.equal(outs[0][0], outs[mode][0]), f"gemm_a4 = {mode}: visual tokens differ from the 8-wave kernel's"
         assert torch.equal(outs[0][1], outs[mode][1]), f"gemm_a4 = {mode}: prefill logits differ from the 8-wave kernel's"
-    print("[parity] full-size towers + 32-layer prefill: bit-identical under gemm_a4 = 0 / 1 / 2 / 3 (8-wave, chosen, plain 4-wave, pipelined 4-wave GEMM forms)")
+    print("[parity] full-size towers + 32-layer prefill: bit-identical under gemm_a4 = 0 / 1 / 2 / 3 (8-wave, chosen, plain 4-wave, pipelined 4-wave GEMM forms) and gemm_narrow = 0 / 1 / 2")

@@ -14,8 +14,9 @@ CSRC = os.path.join(HERE, "csrc")
 # LAB builds (A/B of two kernel variants on one GPU box, loaded through GVL_LIB_PATH): GVL_BUILD_TAG=x GVL_BUILD_DEFS="-DFOO=1" -> libgvl_x.so
 TAG = os.environ.get("GVL_BUILD_TAG", "")
 OUT = os.path.join(HERE, f"libgvl_{TAG}.so" if TAG else "libgvl.so")
-SOURCES = ["gvl_gemm.hip", "gvl_gemm4.hip", "gvl_gemm4p.hip", "gvl_attn.hip", "gvl_elem.hip", "gvl_decode.hip", "gvl_model.hip", "gvl_host.hip", "gvl_pre.hip", "gvl_probe.hip", "gvl_patch.hip"]
-HEADERS = ["gvl_internal.h", "gvl_ctx.h", "gvl_gemm_epi.h", "gvl_gemm4_loop.inc", "gvl_gemm4p_loop.inc", os.path.join("..", "..", "include", "gvl.h")]
+SOURCES = ["gvl_gemm.hip", "gvl_gemm4.hip", "gvl_gemm4p.hip", "gvl_attn.hip", "gvl_elem.hip", "gvl_decode.hip", "gvl_model.hip", "gvl_vision.hip", "gvl_llm.hip", "gvl_host.hip", "gvl_pre.hip",
+           "gvl_probe.hip", "gvl_patch.hip"]
+HEADERS = ["gvl_internal.h", "gvl_ctx.h", "gvl_model.h", "gvl_gemm_epi.h", "gvl_gemm4_loop.inc", "gvl_gemm4p_loop.inc", os.path.join("..", "..", "include", "gvl.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result", "-Wno-cuda-compat",
          # MFMA accumulators in VGPRs (gfx950 has a unified file): no v_accvgpr_read/write copies around the softmax / epilogue VALU
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
@@ -27,7 +28,7 @@ def source_sha16() -> str:
     stamp equals the tree it runs from -- a PMC figure of other code is not this run's figure."""
     import hashlib
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, f) for f in sorted(SOURCES + ["gvl_internal.h", "gvl_ctx.h", "gvl_gemm_epi.h", "gvl_gemm4_loop.inc", "gvl_gemm4p_loop.inc"])] + [os.path.join(HERE, "..", "bench.py")]
+    files = [os.path.join(CSRC, f) for f in sorted(SOURCES + ["gvl_internal.h", "gvl_ctx.h", "gvl_model.h", "gvl_gemm_epi.h", "gvl_gemm4_loop.inc", "gvl_gemm4p_loop.inc"])] + [os.path.join(HERE, "..", "bench.py")]
     for f in files:
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode() + b"\0" + fh.read())

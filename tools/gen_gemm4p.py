@@ -89,7 +89,7 @@ def preg(j, i, r):
 
 # ---- main loop (schedule variant 1 of gen_gemm4_loop.py, physical operands) -----------------------------------------------------------------------------
 READ_GAPS = [0, 1, 2, 3, 4, 5, 6, 7]
-DMA_GAPS8 = [0, 2, 4, 6, 8, 10, 12, 14]
+DMA_GAPS8 = [int(x) for x in os.environ.get("GVL_A4P_DMAGAPS", "0,2,4,6,8,10,12,14").split(",")]     # LAB override: which MFMA gaps of a phase carry its 8 DMA pieces
 DMA_GAPS16 = list(range(16))
 
 
